@@ -1,0 +1,716 @@
+/*
+ * qbold_oracle.c -- CPU restatement of the qBOLD-VI voxel-wise ELBO hot path.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see qbold_oracle.h for the full statement).
+ *
+ * Every function cites the reference file:line it restates (paths relative to the reference
+ * repository root).  Arithmetic is carried out in `real` (float for the parity build) in the
+ * reference's order of operations; Python-side double constants are folded in double and cast to
+ * `real` exactly where TensorFlow would convert them to a float32 tensor.
+ */
+#define _GNU_SOURCE
+#include "qbold_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define R(x) ((real)(x))
+
+#if defined(QBO_DOUBLE)
+#define r_exp exp
+#define r_log log
+#define r_sqrt sqrt
+#define r_tanh tanh
+#define r_cos cos
+#define r_fabs fabs
+#define r_lgamma lgamma
+#define r_log1p log1p
+#else
+#define r_exp expf
+#define r_log logf
+#define r_sqrt sqrtf
+#define r_tanh tanhf
+#define r_cos cosf
+#define r_fabs fabsf
+#define r_lgamma lgammaf
+#define r_log1p log1pf
+#endif
+
+int qbo_real_bytes(void) { return (int)sizeof(real); }
+
+void qbo_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Bessel J0 / J1.  tf.math.special.bessel_j0 (signals.py:170) dispatches to Eigen's
+ * generic_j0<T,float>, which is Cephes single-precision j0f.c (Moshier): rational/polynomial
+ * in z=x^2 on [0,2] (with the 1 - z/4 shortcut below 1e-3), modulus/phase asymptotic form above.
+ * The float64 build uses libm's j0/j1 as "truth".
+ * ---------------------------------------------------------------------------------------- */
+#if !defined(QBO_DOUBLE)
+static inline float polevl(float x, const float *c, int n) {
+    float r = c[0];
+    for (int i = 1; i <= n; ++i) r = r * x + c[i];
+    return r;
+}
+
+static const float J0_MO[8] = {-6.838999669318810E-002f, 1.864949361379502E-001f,
+                               -2.145007480346739E-001f, 1.197549369473540E-001f,
+                               -3.560281861530129E-003f, -4.969382655296620E-002f,
+                               -3.355424622293709E-006f, 7.978845717621440E-001f};
+static const float J0_PH[8] = {3.242077816988247E+001f,  -3.630592630518434E+001f,
+                               1.756221482109099E+001f,  -4.974978466280903E+000f,
+                               1.001973420681837E+000f,  -1.939906941791308E-001f,
+                               6.490598792654666E-002f,  -1.249992184872738E-001f};
+static const float J0_JP[5] = {-6.068350350393235E-008f, 6.388945720783375E-006f,
+                               -3.969646342510940E-004f, 1.332913422519003E-002f,
+                               -1.729150680240724E-001f};
+#define J0_DR1 5.78318596294678452118f
+#define PIO4F 0.7853981633974483096f
+
+real qbo_j0(real xx) {
+    float x = fabsf(xx);
+    if (x <= 2.0f) {
+        float z = x * x;
+        if (x < 1.0e-3f) return 1.0f - 0.25f * z;
+        return (z - J0_DR1) * polevl(z, J0_JP, 4);
+    }
+    float q = 1.0f / x;
+    float w = 1.0f / sqrtf(x); /* Eigen: prsqrt(y); Cephes: sqrtf(q) */
+    float p = w * polevl(q, J0_MO, 7);
+    w = q * q;
+    float xn = q * polevl(w, J0_PH, 7) - PIO4F;
+    return p * cosf(xn + x);
+}
+
+static const float J1_JP[5] = {-4.878788132172128E-009f, 6.009061827883699E-007f,
+                               -4.541343896997497E-005f, 1.937383947804541E-003f,
+                               -3.405537384615824E-002f};
+static const float J1_MO[8] = {6.913942741265801E-002f,  -2.284801500053359E-001f,
+                               3.138238455499697E-001f,  -2.102302420403875E-001f,
+                               5.435364690523026E-003f,  1.493389585089498E-001f,
+                               4.976029650847191E-006f,  7.978845453073848E-001f};
+static const float J1_PH[8] = {-4.497014141919556E+001f, 5.073465654089319E+001f,
+                               -2.485774108720340E+001f, 7.222973196770240E+000f,
+                               -1.544842782180211E+000f, 3.503787691653334E-001f,
+                               -1.637986776941202E-001f, 3.749989509080821E-001f};
+#define J1_Z1 1.46819706421238932572E1f
+#define THPIO4F 2.35619449019234492885f
+
+real qbo_j1(real xx) {
+    float x = fabsf(xx);
+    float r;
+    if (x <= 2.0f) {
+        float z = x * x;
+        r = (z - J1_Z1) * x * polevl(z, J1_JP, 4);
+    } else {
+        float q = 1.0f / x;
+        float w = sqrtf(q);
+        float p = w * polevl(q, J1_MO, 7);
+        w = q * q;
+        float xn = q * polevl(w, J1_PH, 7) - THPIO4F;
+        r = p * cosf(xn + x);
+    }
+    return xx < 0 ? -r : r;
+}
+#else
+real qbo_j0(real x) { return j0(x); }
+real qbo_j1(real x) { return j1(x); }
+#endif
+
+void qbo_j0_array(const real *x, real *y, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) y[i] = qbo_j0(x[i]);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * tau grid -- signals.py:34-35: tf.range(start, end, step, dtype=float32).
+ * size = ceil(|end-start|/|step|) (TF RangeSize, computed in double from the float32-cast
+ * limits); element i = start + i*step in float32 (multiply form; the accumulate form used by
+ * older TF differs by <= 1 ulp at a few i).
+ * ---------------------------------------------------------------------------------------- */
+int qbo_taus(const qbo_phys *P, real *taus) {
+    real s = R(P->tau_start), e = R(P->tau_end), d = R(P->tau_step);
+    int T = (int)ceil(fabs((double)e - (double)s) / fabs((double)d));
+    if (T > QBO_MAX_T) T = QBO_MAX_T;
+    for (int i = 0; i < T; ++i) taus[i] = s + R(i) * d;
+    return T;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Tissue integral -- signals.py:159-185 (compose / integral).
+ *   int_parts = tf.linspace(1e-5, 1, 129)                                       :166-168
+ *   y = (2+u)*sqrt(1-u)*(1 - J0(1.5*(tau*dw)*u)) / (3*u^2)                       :169-171
+ *   Simpson: (y_a + y_b + 4 y_m) * (h/3), h = (u[2]-u[0])/2, reduce_sum          :180-185
+ * tf.linspace float32: start + i*delta with delta=(stop-start)/(num-1), last element = stop.
+ * ---------------------------------------------------------------------------------------- */
+#define NNODE 129
+static real g_u[NNODE];
+static real g_pre[NNODE]; /* (2+u)*sqrt(1-u) */
+static real g_den[NNODE]; /* 3*u^2 */
+static real g_h3;
+static int g_nodes_ready = 0;
+
+static void init_nodes(void) {
+    if (g_nodes_ready) return;
+#pragma omp critical(qbo_nodes)
+    {
+        if (!g_nodes_ready) {
+            real a = R(1e-5), b = R(1);
+            real delta = (b - a) / R(NNODE - 1);
+            for (int i = 0; i < NNODE; ++i) g_u[i] = a + R(i) * delta;
+            g_u[NNODE - 1] = b;
+            for (int i = 0; i < NNODE; ++i) {
+                g_pre[i] = (R(2) + g_u[i]) * r_sqrt(R(1) - g_u[i]);
+                g_den[i] = R(3.0) * (g_u[i] * g_u[i]);
+            }
+            real h = (g_u[2] - g_u[0]) / R(2.0);
+            g_h3 = h / R(3.0);
+            g_nodes_ready = 1;
+        }
+    }
+}
+
+static inline real node_y(real x, int i) {
+    real arg = (R(1.5) * x) * g_u[i];
+    return g_pre[i] * (R(1.0) - qbo_j0(arg)) / g_den[i];
+}
+
+real qbo_tissue_F(real x) {
+    init_nodes();
+    real y[NNODE];
+    for (int i = 0; i < NNODE; ++i) y[i] = node_y(x, i);
+    real acc = 0;
+    for (int m = 0; m < (NNODE - 1) / 2; ++m)
+        acc += (y[2 * m] + y[2 * m + 2] + R(4.0) * y[2 * m + 1]) * g_h3;
+    return acc;
+}
+
+void qbo_tissue_F_array(const real *x, real *F, int64_t n) {
+    init_nodes();
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) F[i] = qbo_tissue_F(x[i]);
+}
+
+/* d/dx of the Simpson sum: d/dx[1-J0(1.5 x u)] = 1.5 u J1(1.5 x u). */
+real qbo_tissue_dF(real x) {
+    init_nodes();
+    real y[NNODE];
+    for (int i = 0; i < NNODE; ++i) {
+        real arg = (R(1.5) * x) * g_u[i];
+        y[i] = g_pre[i] * (R(1.5) * g_u[i] * qbo_j1(arg)) / g_den[i];
+    }
+    real acc = 0;
+    for (int m = 0; m < (NNODE - 1) / 2; ++m)
+        acc += (y[2 * m] + y[2 * m + 2] + R(4.0) * y[2 * m + 1]) * g_h3;
+    return acc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Forward signal model -- signals.py:55-114 (no misalignment, no noise), calc_tissue :152-209,
+ * calc_blood :233-247, calculate_dw_static :142-144.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int T;
+    real taus[QBO_MAX_T];
+    real dw_coef;  /* (4/3) pi gamma b0 dchi hct                signals.py:144 */
+    real e_te_r2t; /* exp(-te*r2t)                              signals.py:172 */
+    real m_bld_nb; /* m_bld * nb                                signals.py:102-107 */
+    real g0_c1;    /* (4/45) hct (1-hct)                        signals.py:239 */
+    real g0_c2;    /* 4 pi b0 dchi                              signals.py:239 */
+    real half_g2;  /* 0.5*gamma^2                               signals.py:241 */
+    real td2;      /* td^2                                      signals.py:241 */
+    real e_r2b_te; /* exp(-r2b*te)                              signals.py:241 */
+    real blood_B[QBO_MAX_T]; /* bracket of signals.py:242-247, per tau */
+    real r2t_te;
+} fwd_consts;
+
+static void make_consts(const qbo_phys *P, fwd_consts *c) {
+    c->T = qbo_taus(P, c->taus);
+    c->dw_coef = R((4.0 / 3.0) * M_PI * P->gamma * P->b0 * P->dchi * P->hct);
+    c->e_te_r2t = r_exp(R(-P->te * P->r2t));
+    c->r2t_te = R(-P->r2t * P->te);
+    /* m_bld: tf.math.exp of python floats -> float32 scalars          signals.py:105 */
+    real e1 = r_exp(R(-(P->tr - P->ti) / P->t1b));
+    real e2 = r_exp(R(-P->ti / P->t1b));
+    real m_bld = R(1) - (R(2) - e1) * e2;
+    c->m_bld_nb = m_bld * R(0.775);
+    c->g0_c1 = R((4.0 / 45.0) * P->hct * (1.0 - P->hct));
+    c->g0_c2 = R(4.0 * M_PI * P->b0 * P->dchi);
+    c->half_g2 = R(0.5 * (P->gamma * P->gamma));
+    double r2b = 1.0 / 0.189;
+    double td = (pow(2.6, 2.0) / 2.0) * 1e-3;
+    c->td2 = R(td * td);
+    c->e_r2b_te = r_exp(R(-r2b * P->te));
+    real te = R(P->te), tdr = R(td);
+    real te_td = R(P->te / td);
+    real s0 = r_sqrt(R(0.25 + (P->te / td)));
+    for (int t = 0; t < c->T; ++t) {
+        real a = r_sqrt(R(0.25) + ((te + c->taus[t]) / tdr));
+        real b = r_sqrt(R(0.25) + ((te - c->taus[t]) / tdr));
+        c->blood_B[t] = te_td + s0 + R(1.5) - (R(2.0) * a) - (R(2.0) * b);
+    }
+}
+
+static inline void signal_one(const qbo_phys *P, const fwd_consts *c, real oef, real dbv,
+                              real *out) {
+    real dw = c->dw_coef * oef;
+    real bw;
+    real g = 0;
+    if (P->include_blood) {
+        bw = c->m_bld_nb * dbv;
+        real t = c->g0_c2 * oef;
+        real g0 = c->g0_c1 * (t * t);
+        g = (c->half_g2 * g0) * c->td2;
+    } else {
+        bw = dbv; /* signals.py:110 */
+    }
+    real tw = R(1) - bw;
+    for (int t = 0; t < c->T; ++t) {
+        real tissue;
+        if (P->full_model) {
+            real F = qbo_tissue_F(c->taus[t] * dw);
+            tissue = r_exp(-dbv * F) * c->e_te_r2t;
+        } else { /* signals.py:194-207 */
+            real tc = R(1.0) / dw;
+            real r2p = dw * dbv;
+            real rt = r2p * c->taus[t];
+            if (r_fabs(c->taus[t]) < tc)
+                tissue = r_exp(c->r2t_te) * r_exp(-(R(0.3) * (rt * rt)) / dbv);
+            else
+                tissue = r_exp(c->r2t_te) * r_exp(dbv - rt);
+        }
+        real blood = 0;
+        if (P->include_blood) blood = c->e_r2b_te * r_exp(-g * c->blood_B[t]);
+        out[t] = tw * tissue + bw * blood;
+    }
+}
+
+void qbo_signal_fwd(const qbo_phys *P, const real *oef_dbv, real *signal, int64_t V) {
+    fwd_consts c;
+    make_consts(P, &c);
+    init_nodes();
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < V; ++v)
+        signal_one(P, &c, oef_dbv[2 * v], oef_dbv[2 * v + 1], signal + v * c.T);
+}
+
+void qbo_signal_jac(const qbo_phys *P, const real *oef_dbv, real *jac, int64_t V) {
+    fwd_consts c;
+    make_consts(P, &c);
+    init_nodes();
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < V; ++v) {
+        real oef = oef_dbv[2 * v], dbv = oef_dbv[2 * v + 1];
+        real dw = c.dw_coef * oef;
+        real bw = P->include_blood ? c.m_bld_nb * dbv : dbv;
+        real dbw = P->include_blood ? c.m_bld_nb : R(1);
+        real t2 = c.g0_c2 * oef;
+        real g = (c.half_g2 * (c.g0_c1 * (t2 * t2))) * c.td2;
+        real dg = oef != 0 ? R(2) * g / oef : 0;
+        for (int t = 0; t < c.T; ++t) {
+            real x = c.taus[t] * dw;
+            real tissue, dt_doef, dt_ddbv;
+            if (P->full_model) {
+                real F = qbo_tissue_F(x), dF = qbo_tissue_dF(x);
+                tissue = r_exp(-dbv * F) * c.e_te_r2t;
+                dt_ddbv = -F * tissue;
+                dt_doef = -dbv * dF * (c.taus[t] * c.dw_coef) * tissue;
+            } else {
+                real tc = R(1.0) / dw, r2p = dw * dbv, rt = r2p * c.taus[t];
+                if (r_fabs(c.taus[t]) < tc) {
+                    tissue = r_exp(c.r2t_te) * r_exp(-(R(0.3) * (rt * rt)) / dbv);
+                    /* exponent = -0.3 (dw tau)^2 dbv */
+                    real k = c.taus[t] * dw;
+                    dt_ddbv = -R(0.3) * k * k * tissue;
+                    dt_doef = -R(0.6) * k * (c.taus[t] * c.dw_coef) * dbv * tissue;
+                } else {
+                    tissue = r_exp(c.r2t_te) * r_exp(dbv - rt);
+                    dt_ddbv = (R(1) - dw * c.taus[t]) * tissue;
+                    dt_doef = -(c.dw_coef * dbv * c.taus[t]) * tissue;
+                }
+            }
+            real blood = 0, db_doef = 0;
+            if (P->include_blood) {
+                blood = c.e_r2b_te * r_exp(-g * c.blood_B[t]);
+                db_doef = -dg * c.blood_B[t] * blood;
+            }
+            real *j = jac + (v * c.T + t) * 2;
+            j[0] = (R(1) - bw) * dt_doef + bw * db_doef;
+            j[1] = (R(1) - bw) * dt_ddbv + dbw * (blood - tissue);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder (voxel-wise) -- model.py:97-113 (normalise_data), :115-223 (create_encoder).
+ * ---------------------------------------------------------------------------------------- */
+static inline real clipr(real v, real lo, real hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static inline void normalise_one(const qbo_loss_cfg *C, const real *x, real *n, int T) {
+    real c[QBO_MAX_T];
+    for (int t = 0; t < T; ++t) c[t] = clipr(x[t], R(1e-2), R(1e8)); /* model.py:101 */
+    real den;
+    if (C->multi_image_normalisation) /* model.py:104: reduce_mean over se-1..se+1 */
+        den = (c[C->se_idx - 1] + c[C->se_idx] + c[C->se_idx + 1]) / R(3);
+    else
+        den = c[C->se_idx]; /* model.py:106 */
+    for (int t = 0; t < T; ++t) n[t] = r_log(c[t] / den); /* model.py:108 */
+}
+
+void qbo_normalise(const qbo_loss_cfg *C, const real *x, real *n, int T, int64_t N) {
+    for (int64_t i = 0; i < N; ++i) normalise_one(C, x + i * T, n + i * T, T);
+}
+
+static inline real sigmoidr(real v) { return R(1) / (R(1) + r_exp(-v)); }
+
+/* y[o] = act(sum_i x[i] W[i][o] + b[o]) ; W is [nin][nout] (Keras kernel orientation). */
+static void dense(const real *x, const real *W, const real *b, real *y, int nin, int nout,
+                  int relu) {
+    for (int o = 0; o < nout; ++o) {
+        real acc = 0;
+        for (int i = 0; i < nin; ++i) acc += x[i] * W[(int64_t)i * nout + o];
+        acc += b[o];
+        y[o] = relu ? (acc > 0 ? acc : 0) : acc;
+    }
+}
+
+void qbo_encoder_fwd(const qbo_weights *W, const qbo_loss_cfg *C, const real *x, real *out1,
+                     real *out2, real *sigma, int64_t N) {
+    const int T = W->T, U = W->U, L = W->L;
+    const int G = W->channelwise_gating ? U : 1;
+    const real goff = R(W->gate_offset);
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < N; ++v) {
+        real n[QBO_MAX_T];
+        real *a = (real *)malloc(sizeof(real) * U * 7);
+        real *b = a + U, *skip = b + U, *r = skip + U, *t1 = r + U, *gt = t1 + U, *tmp = gt + U;
+        normalise_one(C, x + v * T, n, T);  /* model.py:178 */
+        dense(n, W->W0, W->b0, a, T, U, 1); /* model.py:181 */
+        memcpy(b, a, sizeof(real) * U);     /* model.py:185: net2 = net1 */
+        for (int l = 0; l < L; ++l) {       /* create_block, model.py:142-174 */
+            const real *Wc = W->Wc + (int64_t)l * U * U, *bc = W->bc + l * U;
+            dense(a, Wc, bc, tmp, U, U, 1); /* stream 1, model.py:145 */
+            memcpy(a, tmp, sizeof(real) * U);
+            dense(b, Wc, bc, skip, U, U, 1); /* shared conv as skip, model.py:148 */
+            for (int i = 0; i < U; ++i) tmp[i] = b[i] > 0 ? b[i] : 0; /* model.py:151 */
+            dense(tmp, W->Wr1 + (int64_t)l * U * U, W->br1 + l * U, t1, U, U, 1); /* :152,155 */
+            dense(t1, W->Wr2 + (int64_t)l * U * U, W->br2 + l * U, r, U, U, 0);   /* :156 */
+            dense(r, W->Wg + (int64_t)l * U * G, W->bg + l * G, gt, U, G, 0);     /* :164 */
+            for (int i = 0; i < U; ++i) { /* gate_convs, model.py:167-170 */
+                real gate = sigmoidr(gt[G == 1 ? 0 : i] + goff);
+                b[i] = skip[i] * (R(1.0) - gate) + r[i] * gate;
+            }
+        }
+        real o[5];
+        if (out1) {
+            dense(a, W->Wf, W->bf, o, U, 5, 0); /* model.py:199 */
+            memcpy(out1 + v * 5, o, sizeof(o));
+        }
+        if (out2) {
+            dense(b, W->Wf, W->bf, o, U, 5, 0); /* model.py:208 */
+            memcpy(out2 + v * 5, o, sizeof(o));
+        }
+        if (sigma) {
+            real s[QBO_MAX_T];
+            dense(b, W->Ws, W->bs, s, U, T, 0); /* model.py:211-214,220 */
+            for (int t = 0; t < T; ++t) sigma[v * T + t] = r_exp(s[t]);
+        }
+        free(a);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Logit-Normal pieces -- model.py:288-316 = logit_mvn.py:72-100, :376-447 = logit_mvn.py:20-70.
+ * ---------------------------------------------------------------------------------------- */
+static inline real transform_std(real p) { return (r_tanh(p) * R(3.0)) - R(1.0); } /* :288-290 */
+static inline real transform_offdiag(real p) { return r_tanh(p) * R(exp(-2.0)); }  /* :292-294 */
+
+#define OEF_RANGE R(0.8)
+#define MIN_OEF R(0.04)
+#define DBV_RANGE R(0.2)
+#define MIN_DBV R(0.001)
+
+static inline void reparam_one(const real *q, real z0, real z1, real *oef, real *dbv) {
+    /* model.py:25-31 */
+    real a = q[0] + z0 * r_exp(transform_std(q[1]));
+    real b = q[2] + z0 * transform_offdiag(q[4]) + z1 * r_exp(transform_std(q[3]));
+    /* forward_transform, model.py:299-305 */
+    *oef = (sigmoidr(a) * OEF_RANGE) + MIN_OEF;
+    *dbv = (sigmoidr(b) * DBV_RANGE) + MIN_DBV;
+}
+
+void qbo_reparam(const real *q, const real *z, real *oef_dbv, int64_t N) {
+    for (int64_t i = 0; i < N; ++i)
+        reparam_one(q + 5 * i, z[2 * i], z[2 * i + 1], oef_dbv + 2 * i, oef_dbv + 2 * i + 1);
+}
+
+static inline real nlogp_one(real oef, real dbv, const real *p) {
+    real oef_mean = p[0], dbv_mean = p[2];
+    real s_o = transform_std(p[1]), s_d = transform_std(p[3]); /* model.py:381,383 */
+    real cov = transform_offdiag(p[4]);                        /* model.py:397 */
+    /* backwards_transform(include_logit=False), model.py:307-311 */
+    real x0 = (oef - MIN_OEF) / OEF_RANGE;
+    real x1 = (dbv - MIN_DBV) / DBV_RANGE;
+    const real eps = R(1e-6);
+    x0 = clipr(x0, eps, R(1.0) - eps); /* model.py:395 */
+    x1 = clipr(x1, eps, R(1.0) - eps);
+    real l0 = r_log(x0 / (R(1.0) - x0)); /* logit, model.py:10-12 */
+    real l1 = r_log(x1 / (R(1.0) - x1));
+    /* squared_whitened_residual, model.py:423-441 */
+    real inv_tl = r_exp(s_o * R(-1.0));
+    real inv_br = r_exp(s_d * R(-1.0));
+    real inv_bl = r_exp(s_o * R(-1.0) + s_d * R(-1.0)) * cov * R(-1.0);
+    real r0 = l0 - oef_mean, r1 = l1 - dbv_mean;
+    real w0 = r0 * inv_tl;
+    real w1 = r1 * inv_br + r0 * inv_bl;
+    real swr = w0 * w0 + w1 * w1;
+    real log_det = R(2.0) * (s_o + s_d); /* model.py:443-447 */
+    /* gaussian_nll_chol, model.py:385-390 */
+    real loss = -(-r_log(R(2.0 * M_PI)) - R(0.5) * log_det - R(0.5) * swr);
+    /* Jacobian, model.py:398 */
+    loss = loss + ((r_log(x0) + r_log(R(1.0) - x0)) + (r_log(x1) + r_log(R(1.0) - x1)));
+    return loss;
+}
+
+void qbo_logit_mvn_nlogp(const real *y, const real *p, real *out, int64_t N) {
+    for (int64_t i = 0; i < N; ++i) out[i] = nlogp_one(y[2 * i], y[2 * i + 1], p + 5 * i);
+}
+
+/* synthetic_data_loss, use_mvg, use_r2p_loss=False, inv_gamma off -- model.py:449-471,514 */
+double qbo_synthetic_data_loss(const real *y_true, const real *q, int64_t N) {
+    double acc = 0;
+    for (int64_t i = 0; i < N; ++i) acc += nlogp_one(y_true[3 * i], y_true[3 * i + 1], q + 5 * i);
+    return acc / (double)N;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * NLL -- fine_tune_loss_fn, model.py:527-568 (per voxel, before the mask multiply :564).
+ * ---------------------------------------------------------------------------------------- */
+static inline real nll_one(const qbo_loss_cfg *C, const real *x, real mask, const real *pred,
+                           const real *sigma, int T, real t_const) {
+    real nt, np_;
+    const int se = C->se_idx;
+    if (C->multi_image_normalisation) { /* model.py:541-542 */
+        nt = (x[se - 1] + x[se] + x[se + 1]) / R(3) + R(1e-3);
+        np_ = (pred[se - 1] + pred[se] + pred[se + 1]) / R(3) + R(1e-3);
+    } else { /* model.py:544-545 */
+        nt = x[se] + R(1e-3);
+        np_ = pred[se] + R(1e-3);
+    }
+    real acc = 0;
+    for (int t = 0; t < T; ++t) {
+        real yt = x[t] / nt, yp = pred[t] / np_;
+        if (C->predict_log_data) { /* model.py:547-549 */
+            yt = mask > 0 ? r_log(yt) : 0;
+            yp = mask > 0 ? r_log(yp) : 0;
+        }
+        real res = yt - yp; /* model.py:552 */
+        real s = sigma[t];
+        real nll;
+        if (C->use_student_t) { /* tfp StudentT(df,0,s).log_prob, model.py:557-559 */
+            real df = R(C->student_t_df);
+            real yy = res / s;
+            nll = -(t_const - r_log(s) - R(0.5) * (df + R(1)) * r_log1p(yy * yy / df));
+        } else { /* model.py:561 */
+            real rs = res / s;
+            nll = -(-r_log(s) - R(log(sqrt(2.0 * M_PI))) - R(0.5) * (rs * rs));
+        }
+        acc += nll; /* model.py:563 */
+    }
+    return acc;
+}
+
+static real student_t_const(const qbo_loss_cfg *C) {
+    if (!C->use_student_t) return 0;
+    double df = C->student_t_df;
+    return R(lgamma(0.5 * (df + 1.0)) - lgamma(0.5 * df) - 0.5 * log(df) - 0.5 * log(M_PI));
+}
+
+void qbo_nll(const qbo_loss_cfg *C, const real *x, const real *mask, const real *pred,
+             const real *sigma, real *nll, int T, int64_t N) {
+    real tc = student_t_const(C);
+    for (int64_t i = 0; i < N; ++i)
+        nll[i] = nll_one(C, x + i * T, mask ? mask[i] : R(1), pred + i * T, sigma + i * T, T, tc);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * KL -- mvg_kl_samples model.py:592-610, closed form mvg_kl model.py:612-652.
+ * ---------------------------------------------------------------------------------------- */
+static inline real kl_samples_one(const real *q, const real *prior, const real *z, int K) {
+    real acc = 0;
+    for (int k = 0; k < K; ++k) {
+        real oef, dbv;
+        reparam_one(q, z[2 * k], z[2 * k + 1], &oef, &dbv); /* create_samples, model.py:318-324 */
+        real log_q = -nlogp_one(oef, dbv, q);               /* model.py:596 */
+        real log_p = -nlogp_one(oef, dbv, prior);           /* model.py:597 */
+        acc += log_q - log_p;                               /* model.py:603 */
+    }
+    return acc / R(K); /* model.py:609 */
+}
+
+void qbo_kl_samples(const real *q, const real *prior, const real *z, int K, real *kl, int64_t N) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i)
+        kl[i] = kl_samples_one(q + 5 * i, prior + 5 * i, z + (int64_t)i * K * 2, K);
+}
+
+void qbo_kl_closed(const real *q, const real *prior, real *kl, int64_t N) {
+    for (int64_t i = 0; i < N; ++i) {
+        const real *qq = q + 5 * i, *pp = prior + 5 * i;
+        real q_cov = transform_offdiag(qq[4]), p_cov = transform_offdiag(pp[4]); /* :622-623 */
+        real q_so = transform_std(qq[1]), q_sd = transform_std(qq[3]);
+        real p_so = transform_std(pp[1]), p_sd = transform_std(pp[3]);
+        real det_q = R(2.0) * (q_so + q_sd), det_p = R(2.0) * (p_so + p_sd); /* :628-629 */
+        /* squared_whitened_residual(p_mu, q_mu, p_log_stds, p_cov) :633 */
+        real inv_tl = r_exp(-p_so), inv_br = r_exp(-p_sd);
+        real inv_bl = r_exp(-p_so - p_sd) * p_cov * R(-1.0);
+        real r0 = pp[0] - qq[0], r1 = pp[2] - qq[2];
+        real w0 = r0 * inv_tl, w1 = r1 * inv_br + r0 * inv_bl;
+        real sq = w0 * w0 + w1 * w1;
+        real det_term = det_p - det_q; /* :635 */
+        real inv_p_tl = R(1.0) / r_exp(p_so), inv_p_br = R(1.0) / r_exp(p_sd); /* :637-638 */
+        real inv_p_od = inv_p_tl * p_cov * inv_p_br * R(-1.0);
+        real inv_pcov_tl = inv_p_tl * inv_p_tl;
+        real inv_pcov_br = inv_p_od * inv_p_od + inv_p_br * inv_p_br;
+        real inv_pcov_od = inv_p_tl * inv_p_od;
+        real q_tl = r_exp(q_so) * r_exp(q_so);
+        real q_br = r_exp(q_sd) * r_exp(q_sd) + q_cov * q_cov;
+        real q_od = q_cov * r_exp(q_so);
+        real trace = inv_pcov_tl * q_tl + inv_pcov_od * q_od + inv_pcov_od * q_od +
+                     q_br * inv_pcov_br; /* :648 */
+        kl[i] = R(0.5) * (trace + sq + det_term - R(2.0)); /* :651 */
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Posterior moments -- calculate_means(include_r2p=True, return_stds=True), model.py:326-343.
+ * ---------------------------------------------------------------------------------------- */
+void qbo_moments(const qbo_phys *P, const real *q, const real *z, int n, real *means, real *vars,
+                 int64_t N) {
+    real dw_coef = R((4.0 / 3.0) * M_PI * P->gamma * P->b0 * P->dchi * P->hct);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+        real *so = (real *)malloc(sizeof(real) * 3 * n);
+        real *sd = so + n, *sr = sd + n;
+        real mo = 0, md = 0, mr = 0;
+        for (int k = 0; k < n; ++k) {
+            const real *zz = z + ((int64_t)i * n + k) * 2;
+            reparam_one(q + 5 * i, zz[0], zz[1], &so[k], &sd[k]);
+            sr[k] = (dw_coef * so[k]) * sd[k]; /* calculate_r2p, model.py:524-525 */
+            mo += so[k];
+            md += sd[k];
+            mr += sr[k];
+        }
+        mo /= R(n);
+        md /= R(n);
+        mr /= R(n);
+        real vo = 0, vd = 0, vr = 0;
+        for (int k = 0; k < n; ++k) { /* biased variance, model.py:331,337 */
+            vo += (so[k] - mo) * (so[k] - mo);
+            vd += (sd[k] - md) * (sd[k] - md);
+            vr += (sr[k] - mr) * (sr[k] - mr);
+        }
+        means[3 * i] = mo;
+        means[3 * i + 1] = md;
+        means[3 * i + 2] = mr;
+        if (vars) {
+            vars[3 * i] = vo / R(n);
+            vars[3 * i + 1] = vd / R(n);
+            vars[3 * i + 2] = vr / R(n);
+        }
+        free(so);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * One voxel-ELBO evaluation: S reparam samples -> forward model -> NLL,
+ * K-sample MC KL, masked sums.  build_fine_tuner model.py:239-286 (S copies :245-246),
+ * fine_tune_loss_fn :527-568 (tile :529), kl_loss :654-665, ELBO = nll + kl train.py:351.
+ * ---------------------------------------------------------------------------------------- */
+void qbo_elbo(const qbo_phys *P, const qbo_loss_cfg *C, const real *x, const real *mask,
+              const real *q, const real *prior, const real *sigma, const real *zs, int S,
+              const real *zk, int K, real *nll_v, real *kl_v, double *sums, int64_t N) {
+    fwd_consts c;
+    make_consts(P, &c);
+    init_nodes();
+    const int T = c.T;
+    real tc = student_t_const(C);
+    double s_nll = 0, s_kl = 0, s_m = 0;
+#pragma omp parallel for schedule(static) reduction(+ : s_nll, s_kl, s_m)
+    for (int64_t v = 0; v < N; ++v) {
+        real m = mask ? mask[v] : R(1);
+        real acc = 0;
+        real pred[QBO_MAX_T];
+        for (int s = 0; s < S; ++s) {
+            real oef, dbv;
+            const real *zz = zs + ((int64_t)v * S + s) * 2;
+            reparam_one(q + 5 * v, zz[0], zz[1], &oef, &dbv);
+            signal_one(P, &c, oef, dbv, pred);
+            acc += nll_one(C, x + v * T, m, pred, sigma + v * T, T, tc);
+        }
+        real nll = acc / R(S);
+        real kl = K > 0 ? kl_samples_one(q + 5 * v, prior + 5 * v, zk + (int64_t)v * K * 2, K) : 0;
+        if (nll_v) nll_v[v] = nll;
+        if (kl_v) kl_v[v] = kl;
+        s_nll += (double)(nll * m);        /* model.py:564 */
+        s_kl += (double)(m > 0 ? kl : 0);  /* model.py:661 */
+        s_m += (double)m;
+    }
+    sums[0] = s_nll;
+    sums[1] = s_kl;
+    sums[2] = s_m;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Random123 Philox4x32-10 (Salmon et al., SC'11) and the normal stream shared with the kernels.
+ * ---------------------------------------------------------------------------------------- */
+void qbo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static inline void box_muller(uint32_t a, uint32_t b, real *z0, real *z1) {
+    /* u in (0,1): top 24 bits + half an ulp.  Evaluated in double, rounded once. */
+    double u1 = ((double)(a >> 8) + 0.5) * (1.0 / 16777216.0);
+    double u2 = ((double)(b >> 8) + 0.5) * (1.0 / 16777216.0);
+    double rr = sqrt(-2.0 * log(u1));
+    *z0 = R(rr * cos(2.0 * M_PI * u2));
+    *z1 = R(rr * sin(2.0 * M_PI * u2));
+}
+
+void qbo_philox_normals(uint64_t seed, uint32_t stream, int64_t voxel0, int64_t N, int n,
+                        real *z) {
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+        uint64_t vox = (uint64_t)(voxel0 + i);
+        for (int j = 0; 2 * j < n; ++j) {
+            uint32_t ctr[4] = {(uint32_t)vox, (uint32_t)(vox >> 32), (uint32_t)j, stream};
+            uint32_t o[4];
+            qbo_philox4x32_10(ctr, key, o);
+            real *zz = z + ((int64_t)i * n + 2 * j) * 2;
+            box_muller(o[0], o[1], &zz[0], &zz[1]);
+            if (2 * j + 1 < n) box_muller(o[2], o[3], &zz[2], &zz[3]);
+        }
+    }
+}
