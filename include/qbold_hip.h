@@ -1,0 +1,169 @@
+/*
+ * qbold_hip.h -- C ABI of libqbold_hip.so: the MI355X (gfx950) implementation of the qBOLD-VI
+ * voxel-wise amortised-VI hot path.
+ *
+ * The reference (wearepal/qBOLD-VI) has no FFI/plugin interface: the path sits behind Python
+ * classes used as Keras layers / loss callables.  Each entry point below names the reference
+ * interface (file:line, relative to the reference repository root) whose arithmetic it replaces;
+ * the Python host mirror in qbold_vi_amd/ keeps the reference's class and method names and calls
+ * these functions through ctypes (see INTEGRATION.md for the binding a maintainer would add).
+ *
+ * Conventions
+ *   - every buffer is a caller-owned DEVICE pointer (float32, row-major, channel-last) unless
+ *     a parameter is documented as host; nothing is allocated per call;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is
+ *     asynchronous on that stream, and the library never synchronises the device;
+ *   - return value: 0 on success, a negative qbold_status otherwise; functions never throw;
+ *   - a context is bound to one device, immutable after creation and re-entrant.
+ *
+ * Tensor conventions (as the reference): posterior/prior parameters are
+ * [mu_oef, raw_s_oef, mu_dbv, raw_s_dbv, raw_c] (model.py:26-31,380-383); (OEF,DBV) pairs are
+ * interleaved [V][2] (signals.py:75-77); signals are [V][T] with T = number of taus.
+ */
+#ifndef QBOLD_HIP_H
+#define QBOLD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QBOLD_MAX_T 64
+#define QBOLD_ABI_VERSION 1
+
+typedef enum {
+    QBOLD_OK = 0,
+    QBOLD_ERR_INVALID = -1,     /* bad argument (null pointer, size, unsupported shape) */
+    QBOLD_ERR_HIP = -2,         /* a HIP runtime call failed; see qbold_last_error() */
+    QBOLD_ERR_UNSUPPORTED = -3, /* configuration outside what the kernels were built for */
+    QBOLD_ERR_NO_DEVICE = -4
+} qbold_status;
+
+/* System constants: INI `config` [DEFAULT] (config:1-38) as parsed by
+ * SignalGenerationLayer.__init__ (signals.py:18-53). */
+typedef struct {
+    double gamma, b0, dchi, te, r2t, tr, ti, t1b, hct;
+    double tau_start, tau_end, tau_step; /* tf.range(...) grid, signals.py:34-35 */
+    int32_t full_model;                  /* signals.py:192: Simpson/Bessel tissue model or log-linear */
+    int32_t include_blood;               /* signals.py:100 */
+} qbold_consts;
+
+/* Likelihood / normalisation switches of EncoderTrainer.__init__ (model.py:54-95). */
+typedef struct {
+    int32_t multi_image_normalisation; /* model.py:102-106, 540-545 */
+    int32_t predict_log_data;          /* model.py:547-549 */
+    int32_t use_student_t;             /* model.py:557: student_t_df is not None and < 50 */
+    double student_t_df;
+} qbold_loss_cfg;
+
+/* How the tissue integral F(x) of signals.py:159-185 is evaluated. */
+typedef enum {
+    QBOLD_TISSUE_TABLE = 0,   /* cubic-Hermite table of the reference's float32 Simpson-129 sum */
+    QBOLD_TISSUE_LITERAL = 1  /* the 129-node Simpson sum with Cephes j0f, per (voxel, tau) */
+} qbold_tissue_mode;
+
+/* Voxel-wise encoder geometry (model.py:122-223; 3x3x1 convolutions act through their centre
+ * tap on (N,1,1,1,T) voxel batches). */
+typedef struct {
+    int32_t T;                  /* no_ip_images */
+    int32_t U;                  /* no_units */
+    int32_t L;                  /* no_intermediate_layers */
+    int32_t channelwise_gating; /* model.py:160-162 */
+    float gate_offset;          /* model.py:169 */
+} qbold_encoder_shape;
+
+typedef struct qbold_ctx qbold_ctx;
+
+int qbold_abi_version(void);
+const char* qbold_last_error(void);
+
+/* ---- context ----------------------------------------------------------------------------- */
+/* Replaces SignalGenerationLayer.__init__ (signals.py:18-53) + EncoderTrainer.__init__'s
+ * se_idx (model.py:95).  Builds the tau grid, the folded float32 constants and the F(x) table
+ * and uploads them to `device`. */
+int qbold_ctx_create(const qbold_consts* consts, const qbold_loss_cfg* loss, int device,
+                     qbold_ctx** out);
+void qbold_ctx_destroy(qbold_ctx* ctx);
+int qbold_ctx_num_taus(const qbold_ctx* ctx);
+int qbold_ctx_se_idx(const qbold_ctx* ctx);
+/* host_out: HOST float[T] */
+int qbold_ctx_taus(const qbold_ctx* ctx, float* host_out);
+int qbold_ctx_set_tissue_mode(qbold_ctx* ctx, int mode);
+int qbold_ctx_tissue_mode(const qbold_ctx* ctx);
+/* Host-side evaluation of the uploaded table (for tests): F(x) and dF/dx, HOST arrays. */
+int qbold_ctx_table_eval(const qbold_ctx* ctx, const float* host_x, float* host_F, float* host_dF,
+                         int64_t n);
+
+/* ---- forward signal model ------------------------------------------------------------------ */
+/* SignalGenerationLayer.call without noise/misalignment (signals.py:55-114,137-138):
+ * oef_dbv [V][2] -> signal [V][T]. */
+int qbold_signal_fwd(const qbold_ctx* ctx, const float* oef_dbv, float* signal, int64_t V,
+                     void* stream);
+/* Vector-Jacobian product of the above: grad_signal [V][T] -> grad_oef_dbv [V][2]
+ * (what tf.GradientTape yields through signals.py:55-114). */
+int qbold_signal_bwd(const qbold_ctx* ctx, const float* oef_dbv, const float* grad_signal,
+                     float* grad_oef_dbv, int64_t V, void* stream);
+
+/* ---- encoder ------------------------------------------------------------------------------- */
+/* Number of floats of the canonical (Keras-orientation, [in][out]) weight blob:
+ * W0[T][U] b0[U] { Wc[U][U] bc[U] Wr1[U][U] br1[U] Wr2[U][U] br2[U] Wg[U][G] bg[G] } x L
+ * Wf[U][5] bf[5] Ws[U][T] bs[T]   (model.py:181,144,152,156,164,196,211-214). */
+int64_t qbold_encoder_num_params(const qbold_encoder_shape* shape);
+/* Size in floats of the device workspace holding the MFMA-ordered copy of the weights. */
+int64_t qbold_encoder_packed_floats(const qbold_encoder_shape* shape);
+/* Re-order the canonical blob into the LDS image the kernels stage (call after every update). */
+int qbold_encoder_pack(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
+                       const float* weights, float* packed, void* stream);
+/* create_encoder forward, voxel-wise (model.py:97-113 normalise_data, :122-223):
+ * x [N][T] -> out1 [N][5] (stream 1), out2 [N][5] (stream 2), sigma [N][T]; any may be NULL. */
+int qbold_encoder_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* packed,
+                      const float* x, float* out1, float* out2, float* sigma, int64_t N,
+                      void* stream);
+
+/* ---- logit-Normal pieces -------------------------------------------------------------------- */
+/* ReparamTrickLayer.call + forward_transform (model.py:15-50, 299-305): q [N][5], z [N][2] ->
+ * oef_dbv [N][2]. */
+int qbold_reparam(const qbold_ctx* ctx, const float* q, const float* z, float* oef_dbv, int64_t N,
+                  void* stream);
+/* logit_gaussian_mvg_log_prob (model.py:376-400 = logit_mvn.py:46-70): NEGATIVE log-density of
+ * y [N][2] under params [N][5] -> out [N]. */
+int qbold_logit_mvn_nlogp(const qbold_ctx* ctx, const float* y, const float* params, float* out,
+                          int64_t N, void* stream);
+/* calculate_means(include_r2p=True, return_stds=True) (model.py:318-343): q [N][5] ->
+ * means [N][3], vars [N][3] over n_samples reparameterised draws.  z = explicit normals
+ * [N][n_samples][2] or NULL for the in-kernel Philox stream (seed, global voxel = voxel0+i). */
+int qbold_posterior_moments(const qbold_ctx* ctx, const float* q, const float* z, int n_samples,
+                            uint64_t seed, int64_t voxel0, float* means, float* vars, int64_t N,
+                            void* stream);
+
+/* ---- ELBO ----------------------------------------------------------------------------------- */
+/* Size in bytes of the scratch the ELBO / fused kernels need for their per-workgroup partials. */
+int64_t qbold_elbo_workspace_bytes(const qbold_ctx* ctx);
+
+/* One voxel-ELBO evaluation given the encoder outputs: build_fine_tuner's sampling + forward
+ * model (model.py:245-248,273), fine_tune_loss_fn (model.py:527-568), kl_loss -> mvg_kl_samples
+ * (model.py:654-665, 592-610), masked sums as train.py:351.
+ *   x [N][T], mask [N] (NULL = ones), q / prior [N][5], sigma [N][T]
+ *   zs [N][S][2], zk [N][K][2] explicit normals, or NULL for the in-kernel Philox4x32-10 stream
+ *   keyed (seed; global voxel voxel0+i; draw) -- identical for any sharding of the voxels
+ *   nll_kl [N][2] per-voxel (nll averaged over S, kl) or NULL
+ *   sums: DEVICE double[3] = (sum_v m*nll, sum_v [m>0] kl, sum_v m), overwritten
+ *   workspace: qbold_elbo_workspace_bytes() bytes */
+int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float* mask, const float* q,
+                   const float* prior, const float* sigma, const float* zs, const float* zk, int S,
+                   int K, uint64_t seed, int64_t voxel0, float* nll_kl, double* sums,
+                   void* workspace, int64_t N, void* stream);
+
+/* The whole hot path in one launch: encoder stream 2 (model.py:122-223) -> S reparameterised
+ * samples -> forward model -> NLL, K-sample KL against `prior`, masked sums.  q_out [N][5]
+ * receives the posterior parameters (NULL to skip); other arguments as qbold_elbo_fwd. */
+int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* packed,
+                 const float* x, const float* mask, const float* prior, int S, int K, uint64_t seed,
+                 int64_t voxel0, float* q_out, float* nll_kl, double* sums, void* workspace,
+                 int64_t N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

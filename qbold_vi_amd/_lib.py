@@ -1,0 +1,95 @@
+"""ctypes binding of libqbold_hip.so (the C ABI declared in include/qbold_hip.h).
+
+The library is the product: if it is missing or fails to load this module raises -- there is no
+CPU or PyTorch fallback for any arithmetic on the hot path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqbold_hip.so")
+
+QBOLD_OK = 0
+QBOLD_TISSUE_TABLE = 0
+QBOLD_TISSUE_LITERAL = 1
+
+
+class QboldError(RuntimeError):
+    pass
+
+
+class Consts(C.Structure):
+    """qbold_consts -- INI `config` [DEFAULT] as parsed at signals.py:18-53 of the reference."""
+    _fields_ = [(n, C.c_double) for n in
+                ("gamma", "b0", "dchi", "te", "r2t", "tr", "ti", "t1b", "hct",
+                 "tau_start", "tau_end", "tau_step")] + \
+               [("full_model", C.c_int32), ("include_blood", C.c_int32)]
+
+
+class LossCfg(C.Structure):
+    _fields_ = [("multi_image_normalisation", C.c_int32), ("predict_log_data", C.c_int32),
+                ("use_student_t", C.c_int32), ("student_t_df", C.c_double)]
+
+
+class EncoderShape(C.Structure):
+    _fields_ = [("T", C.c_int32), ("U", C.c_int32), ("L", C.c_int32),
+                ("channelwise_gating", C.c_int32), ("gate_offset", C.c_float)]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_U64 = C.c_uint64
+
+# name -> (restype, argtypes); the single source of truth used by tests to check the export list
+SIGNATURES = {
+    "qbold_abi_version": (C.c_int, []),
+    "qbold_last_error": (C.c_char_p, []),
+    "qbold_ctx_create": (C.c_int, [C.POINTER(Consts), C.POINTER(LossCfg), C.c_int, C.POINTER(_P)]),
+    "qbold_ctx_destroy": (None, [_P]),
+    "qbold_ctx_num_taus": (C.c_int, [_P]),
+    "qbold_ctx_se_idx": (C.c_int, [_P]),
+    "qbold_ctx_taus": (C.c_int, [_P, _P]),
+    "qbold_ctx_set_tissue_mode": (C.c_int, [_P, C.c_int]),
+    "qbold_ctx_tissue_mode": (C.c_int, [_P]),
+    "qbold_ctx_table_eval": (C.c_int, [_P, _P, _P, _P, _I64]),
+    "qbold_signal_fwd": (C.c_int, [_P, _P, _P, _I64, _P]),
+    "qbold_signal_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _P]),
+    "qbold_encoder_num_params": (_I64, [C.POINTER(EncoderShape)]),
+    "qbold_encoder_packed_floats": (_I64, [C.POINTER(EncoderShape)]),
+    "qbold_encoder_pack": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, _P]),
+    "qbold_encoder_fwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, _P, _P, _P, _I64, _P]),
+    "qbold_reparam": (C.c_int, [_P, _P, _P, _P, _I64, _P]),
+    "qbold_logit_mvn_nlogp": (C.c_int, [_P, _P, _P, _P, _I64, _P]),
+    "qbold_posterior_moments": (C.c_int, [_P, _P, _P, C.c_int, _U64, _I64, _P, _P, _I64, _P]),
+    "qbold_elbo_workspace_bytes": (_I64, [_P]),
+    "qbold_elbo_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _U64, _I64,
+                                 _P, _P, _P, _I64, _P]),
+    "qbold_vi_fwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, _P, _P, C.c_int, C.c_int,
+                               _U64, _I64, _P, _P, _P, _P, _I64, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise QboldError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QboldError(
+            f"{LIB_PATH} not found: build it with `python -m qbold_vi_amd.build` "
+            "(or __graft_entry__.build()); there is no fallback path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != QBOLD_OK:
+        msg = load().qbold_last_error()
+        raise QboldError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,239 @@
+// ctx.hip -- context creation for libqbold_hip.so: folds the INI constants the way
+// SignalGenerationLayer.__init__ / calc_blood do (signals.py:18-53, 233-247), builds the tau grid
+// (signals.py:34-35) and the cubic-Hermite table of the tissue integral (signals.py:159-185).
+#include <math.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "qbold_ctx.h"
+
+namespace qb {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return QBOLD_ERR_HIP;
+}
+}  // namespace qb
+
+extern "C" int qbold_abi_version(void) { return QBOLD_ABI_VERSION; }
+extern "C" const char* qbold_last_error(void) { return qb::g_err.c_str(); }
+
+namespace {
+
+// The reference's float32 Simpson-129 sum, evaluated in double except for the one place where
+// float32 rounding changes the value at leading order: node 0 (u = 1e-5) takes Cephes j0f's
+// small-argument branch 1 - z/4, which rounds to exactly 1.0f for every x the table covers, so
+// that node contributes 0.  The node abscissae are the float32 linspace.
+struct Simpson {
+    double u[QB_NNODE], w[QB_NNODE], pre[QB_NNODE];
+    double h3;
+    Simpson() {
+        const float a = 1e-5f, b = 1.0f;
+        const float delta = (b - a) / 128.0f;
+        for (int i = 0; i < QB_NNODE; ++i) {
+            float uf = (i == QB_NNODE - 1) ? b : a + (float)i * delta;
+            u[i] = (double)uf;
+            pre[i] = (2.0 + u[i]) * sqrt(1.0 - u[i]) / (3.0 * u[i] * u[i]);
+            w[i] = (i == 0 || i == QB_NNODE - 1) ? 1.0 : ((i & 1) ? 4.0 : 2.0);
+        }
+        h3 = ((u[2] - u[0]) / 2.0) / 3.0;
+    }
+    static double node0(double x, double u0) {
+        float arg = (float)(1.5 * x * u0);
+        float z = arg * arg;
+        float one_minus = 1.0f - (1.0f - 0.25f * z);  // j0f small branch in float32
+        return (double)one_minus;
+    }
+    double F(double x) const {
+        double acc = w[0] * pre[0] * node0(x, u[0]);
+        for (int i = 1; i < QB_NNODE; ++i) acc += w[i] * pre[i] * (1.0 - j0(1.5 * x * u[i]));
+        return acc * h3;
+    }
+    // slope of node 0's J1 term: w0 pre0 (1.5 u0) J1(1.5 x u0) h3 with J1(z) = z/2 for z ~ 1e-4
+    double node0_slope() const { return w[0] * pre[0] * (1.5 * u[0]) * (0.75 * u[0]) * h3; }
+    double dF(double x) const {
+        double acc = 0.0;  // derivative of the float32 forward value: node 0 is flat
+        for (int i = 1; i < QB_NNODE; ++i) acc += w[i] * pre[i] * (1.5 * u[i] * j1(1.5 * x * u[i]));
+        return acc * h3;
+    }
+};
+
+}  // namespace
+
+extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* loss, int device,
+                                qbold_ctx** out) {
+    QB_REQUIRE(P && out, "qbold_ctx_create: null argument");
+    // device < 0: host-only context (constants + table, no kernels) for CPU-side checks.
+    if (device >= 0) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+            qb::set_error("qbold_ctx_create: no HIP device visible");
+            return QBOLD_ERR_NO_DEVICE;
+        }
+        QB_REQUIRE(device < ndev, "qbold_ctx_create: device index out of range");
+    }
+    QB_REQUIRE(P->tau_step != 0.0, "qbold_ctx_create: tau_step == 0");
+
+    qbold_ctx* ctx = new qbold_ctx();
+    ctx->device = device;
+    ctx->consts = *P;
+    if (loss) ctx->loss = *loss;
+    QbDev& d = ctx->dev;
+    memset(&d, 0, sizeof(d));
+
+    // tf.range(start, end, step, float32): size = ceil(|end-start|/|step|), value start + i*step.
+    const float ts = (float)P->tau_start, te_ = (float)P->tau_end, tstep = (float)P->tau_step;
+    int T = (int)ceil(fabs((double)te_ - (double)ts) / fabs((double)tstep));
+    if (T < 1 || T > QBOLD_MAX_T) {
+        delete ctx;
+        qb::set_error("qbold_ctx_create: number of taus outside [1, 64]");
+        return QBOLD_ERR_UNSUPPORTED;
+    }
+    d.T = T;
+    for (int i = 0; i < T; ++i) d.taus[i] = ts + (float)i * tstep;
+    d.se_idx = (int)fabs(P->tau_start / P->tau_step);  // model.py:95
+    if (d.se_idx >= T) {
+        delete ctx;
+        qb::set_error("qbold_ctx_create: spin-echo index beyond the tau grid");
+        return QBOLD_ERR_INVALID;
+    }
+    d.full_model = P->full_model ? 1 : 0;
+    d.include_blood = P->include_blood ? 1 : 0;
+    d.multi_norm = ctx->loss.multi_image_normalisation ? 1 : 0;
+    d.predict_log = ctx->loss.predict_log_data ? 1 : 0;
+    d.use_student_t = ctx->loss.use_student_t ? 1 : 0;
+    if (d.multi_norm && (d.se_idx < 1 || d.se_idx + 1 >= T)) {
+        delete ctx;
+        qb::set_error("qbold_ctx_create: multi_image_normalisation needs se_idx-1..se_idx+1");
+        return QBOLD_ERR_INVALID;
+    }
+    d.tissue_mode = QBOLD_TISSUE_TABLE;
+
+    d.dw_coef = (float)((4.0 / 3.0) * M_PI * P->gamma * P->b0 * P->dchi * P->hct);
+    d.e_te_r2t = expf((float)(-P->te * P->r2t));
+    d.r2t_te = (float)(-P->r2t * P->te);
+    {
+        float e1 = expf((float)(-(P->tr - P->ti) / P->t1b));
+        float e2 = expf((float)(-P->ti / P->t1b));
+        float m_bld = 1.0f - (2.0f - e1) * e2;  // signals.py:105
+        d.m_bld_nb = m_bld * 0.775f;             // nb, signals.py:102
+    }
+    d.g0_c1 = (float)((4.0 / 45.0) * P->hct * (1.0 - P->hct));
+    d.g0_c2 = (float)(4.0 * M_PI * P->b0 * P->dchi);
+    d.half_g2 = (float)(0.5 * (P->gamma * P->gamma));
+    const double r2b = 1.0 / 0.189;                     // signals.py:235
+    const double td = (pow(2.6, 2.0) / 2.0) * 1e-3;     // signals.py:236-238
+    d.td2 = (float)(td * td);
+    d.e_r2b_te = expf((float)(-r2b * P->te));
+    {
+        const float tef = (float)P->te, tdf = (float)td;
+        const float te_td = (float)(P->te / td);
+        const float s0 = sqrtf((float)(0.25 + P->te / td));
+        for (int t = 0; t < T; ++t) {
+            float a = sqrtf(0.25f + ((tef + d.taus[t]) / tdf));
+            float b = sqrtf(0.25f + ((tef - d.taus[t]) / tdf));
+            d.blood_B[t] = te_td + s0 + 1.5f - (2.0f * a) - (2.0f * b);
+        }
+    }
+    if (d.use_student_t) {
+        const double df = ctx->loss.student_t_df;
+        d.st_df = (float)df;
+        d.st_const = (float)(lgamma(0.5 * (df + 1.0)) - lgamma(0.5 * df) - 0.5 * log(df) -
+                             0.5 * log(M_PI));
+    }
+
+    // F(x) table over |x| <= max|tau| * dw(OEF = 1): OEF is a fraction, and forward_transform
+    // (model.py:299-305) never exceeds 0.84.
+    float max_tau = 0.0f;
+    for (int t = 0; t < T; ++t) max_tau = fmaxf(max_tau, fabsf(d.taus[t]));
+    double xmax = (double)max_tau * fabs((double)d.dw_coef) * 1.0;
+    if (xmax < 1e-3) xmax = 1e-3;
+    const double h = xmax / QB_TAB_SEG;
+    d.tab_inv_h = (float)(1.0 / h);
+    d.tab_xmax = (float)(xmax * (1.0 - 1e-6));
+    static const Simpson simpson;
+    d.dF_node0 = (float)simpson.node0_slope();
+    std::vector<double> f(QB_TAB_SEG + 1), g(QB_TAB_SEG + 1);
+    for (int i = 0; i <= QB_TAB_SEG; ++i) {
+        f[i] = simpson.F(i * h);
+        g[i] = simpson.dF(i * h) * h;
+    }
+    ctx->h_tab.resize(4 * QB_TAB_SEG);
+    for (int i = 0; i < QB_TAB_SEG; ++i) {
+        ctx->h_tab[4 * i + 0] = (float)f[i];
+        ctx->h_tab[4 * i + 1] = (float)g[i];
+        ctx->h_tab[4 * i + 2] = (float)(3.0 * (f[i + 1] - f[i]) - 2.0 * g[i] - g[i + 1]);
+        ctx->h_tab[4 * i + 3] = (float)(2.0 * (f[i] - f[i + 1]) + g[i] + g[i + 1]);
+    }
+
+    if (device < 0) {
+        *out = ctx;
+        return QBOLD_OK;
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_tab, sizeof(float) * 4 * QB_TAB_SEG);
+    if (e == hipSuccess)
+        e = hipMemcpy(ctx->d_tab, ctx->h_tab.data(), sizeof(float) * 4 * QB_TAB_SEG,
+                      hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->num_cus = prop.multiProcessorCount;
+    }
+    if (e != hipSuccess) {
+        if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+        delete ctx;
+        return qb::hip_fail(e, "qbold_ctx_create: device setup");
+    }
+    *out = ctx;
+    return QBOLD_OK;
+}
+
+extern "C" void qbold_ctx_destroy(qbold_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+    delete ctx;
+}
+
+extern "C" int qbold_ctx_num_taus(const qbold_ctx* ctx) { return ctx ? ctx->dev.T : QBOLD_ERR_INVALID; }
+extern "C" int qbold_ctx_se_idx(const qbold_ctx* ctx) { return ctx ? ctx->dev.se_idx : QBOLD_ERR_INVALID; }
+
+extern "C" int qbold_ctx_taus(const qbold_ctx* ctx, float* host_out) {
+    QB_REQUIRE(ctx && host_out, "qbold_ctx_taus: null argument");
+    memcpy(host_out, ctx->dev.taus, sizeof(float) * ctx->dev.T);
+    return QBOLD_OK;
+}
+
+extern "C" int qbold_ctx_set_tissue_mode(qbold_ctx* ctx, int mode) {
+    QB_REQUIRE(ctx, "qbold_ctx_set_tissue_mode: null ctx");
+    QB_REQUIRE(mode == QBOLD_TISSUE_TABLE || mode == QBOLD_TISSUE_LITERAL,
+               "qbold_ctx_set_tissue_mode: unknown mode");
+    ctx->dev.tissue_mode = mode;
+    return QBOLD_OK;
+}
+extern "C" int qbold_ctx_tissue_mode(const qbold_ctx* ctx) {
+    return ctx ? ctx->dev.tissue_mode : QBOLD_ERR_INVALID;
+}
+
+extern "C" int qbold_ctx_table_eval(const qbold_ctx* ctx, const float* hx, float* hF, float* hdF,
+                                    int64_t n) {
+    QB_REQUIRE(ctx && hx && hF, "qbold_ctx_table_eval: null argument");
+    const QbDev& c = ctx->dev;
+    for (int64_t k = 0; k < n; ++k) {
+        float ax = fabsf(hx[k]);
+        if (ax > c.tab_xmax) ax = c.tab_xmax;
+        float u = ax * c.tab_inv_h;
+        int i = (int)u;
+        if (i > QB_TAB_SEG - 1) i = QB_TAB_SEG - 1;
+        float f = u - (float)i;
+        const float* q = &ctx->h_tab[4 * i];
+        hF[k] = fmaf(fmaf(fmaf(q[3], f, q[2]), f, q[1]), f, q[0]);
+        if (hdF) {
+            float dd = fmaf(fmaf(3.0f * q[3], f, 2.0f * q[2]), f, q[1]) * c.tab_inv_h + c.dF_node0 * ax;
+            hdF[k] = hx[k] < 0 ? -dd : dd;
+        }
+    }
+    return QBOLD_OK;
+}

@@ -1,0 +1,192 @@
+// elbo_core.h -- per-voxel Monte-Carlo ELBO terms, shared by the stand-alone ELBO kernel
+// (elbo_kernels.hip) and the fused encoder+ELBO kernel (vi_kernels.hip).
+//
+// A wave owns 32 voxels; lanes l and l+32 share voxel (l & 31) and split its Monte-Carlo draws by
+// Philox pair index (pair j -> draws 2j, 2j+1; pair j belongs to half j & 1).  Everything a lane
+// needs per voxel lives in registers: T normalised data points, T inverse sigmas, the transformed
+// posterior / prior parameters.
+#pragma once
+
+#include "qbold_dev.h"
+
+namespace qb {
+
+// Likelihood side of one voxel, prepared once -- fine_tune_loss_fn, model.py:527-568.
+template <int T>
+struct VoxelLik {
+    float yt[T];      // normalised (optionally log) data                model.py:541-549
+    float inv_s[T];   // 1/sigma
+    float log_s_sum;  // sum_t log sigma_t (+ T log sqrt(2 pi) for the Gaussian)
+    float mask;
+};
+
+template <int T>
+__device__ __forceinline__ void prepare_lik(const QbDev& c, const float (&x)[T],
+                                            const float (&sigma)[T], float mask, VoxelLik<T>& k) {
+    const int se = c.se_idx;
+    float nt;
+    if (c.multi_norm) {
+        float a = 0.0f, b = 0.0f, d = 0.0f;  // runtime se_idx without dynamic register indexing
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            a = (t == se - 1) ? x[t] : a;
+            b = (t == se) ? x[t] : b;
+            d = (t == se + 1) ? x[t] : d;
+        }
+        nt = (a + b + d) / 3.0f + 1e-3f;  // model.py:541
+    } else {
+        float b = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) b = (t == se) ? x[t] : b;
+        nt = b + 1e-3f;  // model.py:544
+    }
+    float ls = 0.0f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        float y = x[t] / nt;
+        if (c.predict_log) y = mask > 0.0f ? __logf(y) : 0.0f;  // model.py:548
+        k.yt[t] = y;
+        k.inv_s[t] = 1.0f / sigma[t];
+        ls += __logf(sigma[t]);
+    }
+    k.log_s_sum = c.use_student_t ? ls : ls + (float)T * 0.9189385332046727f;  // log sqrt(2 pi)
+    k.mask = mask;
+}
+
+// NLL of one reparameterised draw: forward model over the T taus, normalise, score.
+template <int T, bool LITERAL>
+__device__ __forceinline__ float sample_nll(const FwdLds* L, const QbDev& c, const VoxelLik<T>& k,
+                                            float oef, float dbv) {
+    const FwdVox fv = fwd_vox(c, oef, dbv);
+    float s[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) s[t] = fwd_signal<LITERAL>(L, c, fv, t);
+    const int se = c.se_idx;
+    float np_;
+    if (c.multi_norm) {
+        float a = 0.0f, b = 0.0f, d = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            a = (t == se - 1) ? s[t] : a;
+            b = (t == se) ? s[t] : b;
+            d = (t == se + 1) ? s[t] : d;
+        }
+        np_ = (a + b + d) / 3.0f + 1e-3f;  // model.py:542
+    } else {
+        float b = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) b = (t == se) ? s[t] : b;
+        np_ = b + 1e-3f;  // model.py:545
+    }
+    const float inv_np = 1.0f / np_;
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        float yp = s[t] * inv_np;
+        if (c.predict_log) yp = k.mask > 0.0f ? __logf(yp) : 0.0f;  // model.py:549
+        float r = (k.yt[t] - yp) * k.inv_s[t];                      // model.py:552, 561
+        if (c.use_student_t)  // -StudentT(df, 0, sigma).log_prob(res), model.py:558-559
+            acc += 0.5f * (c.st_df + 1.0f) * log1pf(r * r / c.st_df) - c.st_const;
+        else
+            acc = fmaf(0.5f * r, r, acc);
+    }
+    return acc + k.log_s_sum;  // model.py:563
+}
+
+// The two Monte-Carlo sums of one voxel restricted to this lane's share of the draws.
+//   nll_sum = sum over this half's likelihood draws of the per-draw NLL
+//   kl_sum  = sum over this half's KL draws of log q(y) - log p(y)          model.py:596-603
+// zs / zk: explicit normals of this voxel ([S][2] / [K][2]) or nullptr for the Philox stream.
+template <int T, bool LITERAL>
+__device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
+                                              const VoxelLik<T>& lik, const LogitMvn& q,
+                                              const LogitMvn& prior, int S, int K,
+                                              const float* __restrict__ zs,
+                                              const float* __restrict__ zk, uint64_t seed,
+                                              uint64_t vox, int half, float& nll_sum,
+                                              float& kl_sum) {
+    nll_sum = 0.0f;
+    kl_sum = 0.0f;
+    for (int j = half; 2 * j < S; j += 2) {
+        float z[4];
+        const bool two = 2 * j + 1 < S;
+        if (zs) {
+            z[0] = zs[4 * j];
+            z[1] = zs[4 * j + 1];
+            z[2] = two ? zs[4 * j + 2] : 0.0f;
+            z[3] = two ? zs[4 * j + 3] : 0.0f;
+        } else {
+            normals4(seed, vox, (uint32_t)j, STREAM_LIK, z);
+        }
+        float a, b, oef, dbv;
+        reparam_logits(q, z[0], z[1], a, b);
+        forward_transform(a, b, oef, dbv);
+        nll_sum += sample_nll<T, LITERAL>(L, c, lik, oef, dbv);
+        if (two) {
+            reparam_logits(q, z[2], z[3], a, b);
+            forward_transform(a, b, oef, dbv);
+            nll_sum += sample_nll<T, LITERAL>(L, c, lik, oef, dbv);
+        }
+    }
+    for (int j = half; 2 * j < K; j += 2) {
+        float z[4];
+        const bool two = 2 * j + 1 < K;
+        if (zk) {
+            z[0] = zk[4 * j];
+            z[1] = zk[4 * j + 1];
+            z[2] = two ? zk[4 * j + 2] : 0.0f;
+            z[3] = two ? zk[4 * j + 3] : 0.0f;
+        } else {
+            normals4(seed, vox, (uint32_t)j, STREAM_KL, z);
+        }
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            if (d == 1 && !two) break;
+            float a, b, oef, dbv;
+            reparam_logits(q, z[2 * d], z[2 * d + 1], a, b);  // create_samples, model.py:318-324
+            forward_transform(a, b, oef, dbv);
+            const LogitObs o = make_obs(oef, dbv);
+            // log_q - log_p with log = -nlogp                 model.py:596-597, 603
+            kl_sum += nlogp(o, prior) - nlogp(o, q);
+        }
+    }
+}
+
+// Block-level reduction of the three masked sums into one double3 partial per workgroup.
+// red: LDS scratch of 3 * (blockDim.x / 64) doubles.
+__device__ __forceinline__ void block_partials(double* red, float s_nll, float s_kl, float s_m,
+                                               double* __restrict__ partials) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    s_nll = wave_sum(s_nll);
+    s_kl = wave_sum(s_kl);
+    s_m = wave_sum(s_m);
+    if (lane == 0) {
+        red[3 * wave + 0] = (double)s_nll;
+        red[3 * wave + 1] = (double)s_kl;
+        red[3 * wave + 2] = (double)s_m;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double a = 0.0;
+        for (int w = 0; w < nw; ++w) a += red[3 * w + threadIdx.x];
+        partials[3 * blockIdx.x + threadIdx.x] = a;
+    }
+}
+
+// Final deterministic pass: sums[k] = sum_b partials[b][k].  One block of 192 threads.
+static __global__ void reduce_partials_kernel(const double* __restrict__ partials, int nblocks,
+                                       double* __restrict__ sums) {
+    __shared__ double sh[192];
+    const int k = threadIdx.x / 64, lane = threadIdx.x & 63;
+    double a = 0.0;
+    for (int b = lane; b < nblocks; b += 64) a += partials[3 * b + k];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    if (lane == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 64; ++i) t += sh[64 * k + i];
+        sums[k] = t;
+    }
+}
+
+}  // namespace qb

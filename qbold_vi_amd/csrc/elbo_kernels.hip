@@ -1,0 +1,250 @@
+// elbo_kernels.hip -- stand-alone ELBO kernel (given encoder outputs) and the small logit-Normal
+// utilities of the reference's API surface (reparameterised sampling, log-density, posterior
+// moments).  The per-voxel arithmetic is in elbo_core.h / qbold_dev.h.
+//
+// Roofline (qbold_elbo_fwd, T=11): reads 4T+4+20+20+4T = 132 B per voxel, writes 8 B; work is
+// S forward-model evaluations + K log-density pairs + (S+K)/2 Philox calls per voxel
+// (~25 kFLOP-equivalent at S=32, K=70) -> f32 VALU-bound by two orders of magnitude.
+#include "elbo_core.h"
+#include "qbold_ctx.h"
+
+namespace {
+
+constexpr int kBlock = 256;              // 4 waves
+constexpr int kVoxPerBlock = kBlock / 2; // 32 voxels per wave, 2 lanes per voxel
+
+template <int T, bool LITERAL>
+__global__ __launch_bounds__(kBlock) void elbo_fwd_kernel(
+    QbDev c, const float4* __restrict__ g_tab, const float* __restrict__ x,
+    const float* __restrict__ mask, const float* __restrict__ q, const float* __restrict__ prior,
+    const float* __restrict__ sigma, const float* __restrict__ zs, const float* __restrict__ zk,
+    int S, int K, uint64_t seed, int64_t voxel0, float2* __restrict__ nll_kl,
+    double* __restrict__ partials, int64_t N) {
+    __shared__ qb::FwdLds L;
+    __shared__ double red[3 * (kBlock / 64)];
+    qb::fwd_lds_fill(&L, g_tab, true);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5;
+    float s_nll = 0.0f, s_kl = 0.0f, s_m = 0.0f;
+    const int64_t ntile = (N + kVoxPerBlock - 1) / kVoxPerBlock;
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int64_t v = tile * kVoxPerBlock + wave * 32 + (lane & 31);
+        if (v < N) {
+            float xv[T], sv[T], qv[5], pv[5];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                xv[t] = x[v * T + t];
+                sv[t] = sigma[v * T + t];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                qv[i] = q[v * 5 + i];
+                pv[i] = prior[v * 5 + i];
+            }
+            const float m = mask ? mask[v] : 1.0f;
+            qb::VoxelLik<T> lik;
+            qb::prepare_lik<T>(c, xv, sv, m, lik);
+            const qb::LogitMvn qm = qb::make_mvn(qv), pm = qb::make_mvn(pv);
+            float nll_part, kl_part;
+            qb::voxel_mc_sums<T, LITERAL>(&L, c, lik, qm, pm, S, K, zs ? zs + v * S * 2 : nullptr,
+                                          zk ? zk + v * K * 2 : nullptr, seed,
+                                          (uint64_t)(voxel0 + v), half, nll_part, kl_part);
+            // partner lane (same voxel, other half of the draws); both lanes of a voxel are
+            // active together because v depends on lane & 31 only
+            const float nll = (nll_part + __shfl_xor(nll_part, 32, 64)) / (float)S;
+            const float kl = K > 0 ? (kl_part + __shfl_xor(kl_part, 32, 64)) / (float)K : 0.0f;
+            if (half == 0) {
+                if (nll_kl) nll_kl[v] = make_float2(nll, kl);
+                s_nll += nll * m;               // model.py:564
+                s_kl += m > 0.0f ? kl : 0.0f;   // model.py:661
+                s_m += m;
+            }
+        }
+    }
+    qb::block_partials(red, s_nll, s_kl, s_m, partials);
+}
+
+__global__ void reparam_kernel(const float* __restrict__ q, const float2* __restrict__ z,
+                               float2* __restrict__ out, int64_t N) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float p[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) p[k] = q[i * 5 + k];
+        const qb::LogitMvn m = qb::make_mvn(p);
+        const float2 zz = z[i];
+        float a, b, oef, dbv;
+        qb::reparam_logits(m, zz.x, zz.y, a, b);
+        qb::forward_transform(a, b, oef, dbv);
+        out[i] = make_float2(oef, dbv);
+    }
+}
+
+__global__ void nlogp_kernel(const float2* __restrict__ y, const float* __restrict__ params,
+                             float* __restrict__ out, int64_t N) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float p[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) p[k] = params[i * 5 + k];
+        const qb::LogitMvn m = qb::make_mvn(p);
+        const float2 yy = y[i];
+        out[i] = qb::nlogp(qb::make_obs(yy.x, yy.y), m);
+    }
+}
+
+// calculate_means(include_r2p=True, return_stds=True) -- model.py:318-343.  Two passes over the
+// same counter-generated draws (mean, then biased variance about it), as the reference does.
+__global__ void moments_kernel(QbDev c, const float* __restrict__ q, const float* __restrict__ z,
+                               int n, uint64_t seed, int64_t voxel0, float* __restrict__ means,
+                               float* __restrict__ vars, int64_t N) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float p[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) p[k] = q[i * 5 + k];
+        const qb::LogitMvn m = qb::make_mvn(p);
+        const float* zi = z ? z + i * n * 2 : nullptr;
+        float mo = 0.0f, md = 0.0f, mr = 0.0f, vo = 0.0f, vd = 0.0f, vr = 0.0f;
+        for (int pass = 0; pass < 2; ++pass) {
+            float ao = 0.0f, ad = 0.0f, ar = 0.0f;
+            for (int j = 0; 2 * j < n; ++j) {
+                float zz[4];
+                const bool two = 2 * j + 1 < n;
+                if (zi) {
+                    zz[0] = zi[4 * j];
+                    zz[1] = zi[4 * j + 1];
+                    zz[2] = two ? zi[4 * j + 2] : 0.0f;
+                    zz[3] = two ? zi[4 * j + 3] : 0.0f;
+                } else {
+                    qb::normals4(seed, (uint64_t)(voxel0 + i), (uint32_t)j, qb::STREAM_MOMENTS, zz);
+                }
+                for (int d = 0; d < (two ? 2 : 1); ++d) {
+                    float a, b, oef, dbv;
+                    qb::reparam_logits(m, zz[2 * d], zz[2 * d + 1], a, b);
+                    qb::forward_transform(a, b, oef, dbv);
+                    const float r2p = (c.dw_coef * oef) * dbv;  // calculate_r2p, model.py:524-525
+                    if (pass == 0) {
+                        ao += oef;
+                        ad += dbv;
+                        ar += r2p;
+                    } else {
+                        ao += (oef - mo) * (oef - mo);
+                        ad += (dbv - md) * (dbv - md);
+                        ar += (r2p - mr) * (r2p - mr);
+                    }
+                }
+            }
+            const float inv = 1.0f / (float)n;
+            if (pass == 0) {
+                mo = ao * inv;
+                md = ad * inv;
+                mr = ar * inv;
+                if (!vars) break;
+            } else {
+                vo = ao * inv;
+                vd = ad * inv;
+                vr = ar * inv;
+            }
+        }
+        means[3 * i] = mo;
+        means[3 * i + 1] = md;
+        means[3 * i + 2] = mr;
+        if (vars) {
+            vars[3 * i] = vo;
+            vars[3 * i + 1] = vd;
+            vars[3 * i + 2] = vr;
+        }
+    }
+}
+
+int ew_grid(const qbold_ctx* ctx, int64_t N, int block) {
+    int64_t nb = (N + block - 1) / block;
+    int64_t cap = (int64_t)ctx->num_cus * 8;
+    return (int)(nb < cap ? (nb > 0 ? nb : 1) : cap);
+}
+
+}  // namespace
+
+namespace qb {
+int elbo_grid(const qbold_ctx* ctx) { return ctx->num_cus * 4; }
+}
+
+extern "C" int64_t qbold_elbo_workspace_bytes(const qbold_ctx* ctx) {
+    if (!ctx) return QBOLD_ERR_INVALID;
+    return (int64_t)sizeof(double) * 3 * (int64_t)qb::elbo_grid(ctx);
+}
+
+extern "C" int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float* mask, const float* q,
+                              const float* prior, const float* sigma, const float* zs,
+                              const float* zk, int S, int K, uint64_t seed, int64_t voxel0,
+                              float* nll_kl, double* sums, void* workspace, int64_t N, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    QB_REQUIRE(N >= 0 && S >= 1 && K >= 0, "qbold_elbo_fwd: need N >= 0, S >= 1, K >= 0");
+    QB_REQUIRE(sums && workspace, "qbold_elbo_fwd: null sums/workspace");
+    QB_REQUIRE(N == 0 || (x && q && prior && sigma), "qbold_elbo_fwd: null input buffer");
+    hipStream_t s = (hipStream_t)stream;
+    double* partials = reinterpret_cast<double*>(workspace);
+    const int64_t ntile = (N + kVoxPerBlock - 1) / kVoxPerBlock;
+    int grid = (int)(ntile < qb::elbo_grid(ctx) ? (ntile > 0 ? ntile : 1) : qb::elbo_grid(ctx));
+    const bool lit = ctx->dev.tissue_mode == QBOLD_TISSUE_LITERAL;
+    float2* out = reinterpret_cast<float2*>(nll_kl);
+#define QB_LAUNCH_ELBO(TT)                                                                       \
+    do {                                                                                         \
+        if (lit)                                                                                 \
+            hipLaunchKernelGGL((elbo_fwd_kernel<TT, true>), dim3(grid), dim3(kBlock), 0, s,      \
+                               ctx->dev, ctx->d_tab, x, mask, q, prior, sigma, zs, zk, S, K,     \
+                               seed, voxel0, out, partials, N);                                  \
+        else                                                                                     \
+            hipLaunchKernelGGL((elbo_fwd_kernel<TT, false>), dim3(grid), dim3(kBlock), 0, s,     \
+                               ctx->dev, ctx->d_tab, x, mask, q, prior, sigma, zs, zk, S, K,     \
+                               seed, voxel0, out, partials, N);                                  \
+    } while (0)
+    switch (ctx->dev.T) {
+        case 11: QB_LAUNCH_ELBO(11); break;
+        default:
+            qb::set_error("qbold_elbo_fwd: kernels are built for T = 11 taus");
+            return QBOLD_ERR_UNSUPPORTED;
+    }
+#undef QB_LAUNCH_ELBO
+    QB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(qb::reduce_partials_kernel, dim3(1), dim3(192), 0, s, partials, grid, sums);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
+extern "C" int qbold_reparam(const qbold_ctx* ctx, const float* q, const float* z, float* oef_dbv,
+                             int64_t N, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    if (N == 0) return QBOLD_OK;
+    QB_REQUIRE(N > 0 && q && z && oef_dbv, "qbold_reparam: bad argument");
+    hipLaunchKernelGGL(reparam_kernel, dim3(ew_grid(ctx, N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       q, reinterpret_cast<const float2*>(z), reinterpret_cast<float2*>(oef_dbv), N);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
+extern "C" int qbold_logit_mvn_nlogp(const qbold_ctx* ctx, const float* y, const float* params,
+                                     float* out, int64_t N, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    if (N == 0) return QBOLD_OK;
+    QB_REQUIRE(N > 0 && y && params && out, "qbold_logit_mvn_nlogp: bad argument");
+    hipLaunchKernelGGL(nlogp_kernel, dim3(ew_grid(ctx, N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float2*>(y), params, out, N);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
+extern "C" int qbold_posterior_moments(const qbold_ctx* ctx, const float* q, const float* z,
+                                       int n_samples, uint64_t seed, int64_t voxel0, float* means,
+                                       float* vars, int64_t N, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    if (N == 0) return QBOLD_OK;
+    QB_REQUIRE(N > 0 && q && means && n_samples >= 1, "qbold_posterior_moments: bad argument");
+    hipLaunchKernelGGL(moments_kernel, dim3(ew_grid(ctx, N, 128)), dim3(128), 0, (hipStream_t)stream,
+                       ctx->dev, q, z, n_samples, seed, voxel0, means, vars, N);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}

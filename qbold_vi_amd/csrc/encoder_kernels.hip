@@ -1,0 +1,227 @@
+// encoder_kernels.hip -- weight packing and the stand-alone encoder forward kernel.
+//
+// qbold_encoder_fwd replaces the Keras encoder model built by EncoderTrainer.create_encoder
+// (model.py:122-223) for voxel batches: x [N][T] -> stream-1 parameters out1 [N][5] (the
+// pre-training / prior output, model.py:199), stream-2 parameters out2 [N][5] (model.py:208) and
+// the heteroscedastic sigma [N][T] (model.py:211-220).
+//
+// Roofline: 2 * 30,420 MAC = 60.8 kFLOP per voxel (U=60, L=2, T=11, stream 2) against 44 B read
+// + 64 B written -> ~560 flop/B: bound by the f32 matrix pipe (v_mfma_f32_32x32x2_f32,
+// 157.3 TFLOP/s peak), not by HBM.
+#include "encoder_core.h"
+#include "qbold_ctx.h"
+
+namespace qb {
+
+// Canonical blob offsets (floats); see qbold_encoder_num_params in include/qbold_hip.h.
+struct CanonLayout {
+    int T, U, L, G;
+    int W0, b0, blk0, blk_stride, Wf, bf, Ws, bs, total;
+    // inside a block
+    int Wc, bc, Wr1, br1, Wr2, br2, Wg, bg;
+};
+__host__ __device__ inline CanonLayout make_canon(int T, int U, int L, int cw) {
+    CanonLayout c;
+    c.T = T; c.U = U; c.L = L; c.G = cw ? U : 1;
+    c.W0 = 0;
+    c.b0 = T * U;
+    c.blk0 = c.b0 + U;
+    c.Wc = 0;
+    c.bc = U * U;
+    c.Wr1 = c.bc + U;
+    c.br1 = c.Wr1 + U * U;
+    c.Wr2 = c.br1 + U;
+    c.br2 = c.Wr2 + U * U;
+    c.Wg = c.br2 + U;
+    c.bg = c.Wg + U * c.G;
+    c.blk_stride = c.bg + c.G;
+    c.Wf = c.blk0 + L * c.blk_stride;
+    c.bf = c.Wf + U * 5;
+    c.Ws = c.bf + 5;
+    c.bs = c.Ws + U * T;
+    c.total = c.bs + T;
+    return c;
+}
+
+}  // namespace qb
+
+namespace {
+
+using qb::EncLayout;
+using qb::f32x16;
+
+// value of W[in][out] of a canonical [nin][nout] matrix, zero outside
+__device__ __forceinline__ float wval(const float* W, int nin, int nout, int in, int out) {
+    return (in < nin && out < nout) ? W[in * nout + out] : 0.0f;
+}
+
+__global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset,
+                            const float* __restrict__ w, float* __restrict__ packed) {
+    const int U = c.U, T = c.T, G = c.G;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < e.total; p += gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        if (p < e.first_b) {  // first-layer A: [s][h][i][m]
+            const int m = p & 1, i = (p >> 1) & 31, h = (p >> 6) & 1, s = p >> 7;
+            v = wval(w + c.W0, T, U, 2 * s + h, 32 * m + i);
+        } else if (p < e.blk0) {  // first-layer bias [m][h][r]
+            const int q = p - e.first_b, r = q & 15, h = (q >> 4) & 1, m = q >> 5;
+            const int u = qb::acc_unit(m, r, h);
+            v = u < U ? w[c.b0 + u] : 0.0f;
+        } else if (p < e.head_A) {
+            const int q = p - e.blk0, l = q / qb::BLK_FLOATS, o = q % qb::BLK_FLOATS;
+            const float* wb = w + c.blk0 + l * c.blk_stride;
+            const int piece = o / 4160, oo = o % 4160;  // 4 x (4096 A + 64 bias)
+            const int Aoff = piece == 0 ? c.Wc : piece == 1 ? c.Wr1 : piece == 2 ? c.Wr2 : c.Wg;
+            const int boff = piece == 0 ? c.bc : piece == 1 ? c.br1 : piece == 2 ? c.br2 : c.bg;
+            const int nout = piece == 3 ? G : U;
+            if (oo < 4096) {  // A: [kstep = m_in*16 + r][h][i][m_out]
+                const int m = oo & 1, i = (oo >> 1) & 31, h = (oo >> 6) & 1, ks = oo >> 7;
+                const int in = qb::acc_unit(ks >> 4, ks & 15, h);
+                int out = 32 * m + i;
+                if (piece == 3 && G == 1) out = out < U ? 0 : U;  // shared gate broadcast to all units
+                v = wval(wb + Aoff, U, nout, in, out);
+            } else {
+                const int qq = oo - 4096, r = qq & 15, h = (qq >> 4) & 1, m = qq >> 5;
+                const int u = qb::acc_unit(m, r, h);
+                if (u < U) {
+                    v = wb[boff + ((piece == 3 && G == 1) ? 0 : u)];
+                    if (piece == 3) v += gate_offset;
+                }
+            }
+        } else if (p < e.head_b) {  // head A: [kstep][h][i], rows: 0-4 = Wf, 5.. = Ws
+            const int q = p - e.head_A, i = q & 31, h = (q >> 5) & 1, ks = q >> 6;
+            const int in = qb::acc_unit(ks >> 4, ks & 15, h);
+            if (i < 5) v = wval(w + c.Wf, U, 5, in, i);
+            else if (i < 5 + T) v = wval(w + c.Ws, U, T, in, i - 5);
+        } else if (p < e.head_b + 32) {  // head bias [h][r]
+            const int q = p - e.head_b, r = q & 15, h = q >> 4;
+            const int row = qb::acc_unit(0, r, h);
+            if (row < 5) v = w[c.bf + row];
+            else if (row < 5 + T) v = w[c.bs + row - 5];
+        }
+        packed[p] = v;
+    }
+}
+
+constexpr int kEncBlock = 512;
+
+template <int T>
+__global__ __launch_bounds__(kEncBlock, 2) void encoder_fwd_kernel(
+    QbDev c, EncLayout e, const float* __restrict__ packed, const float* __restrict__ x,
+    float* __restrict__ out1, float* __restrict__ out2, float* __restrict__ sigma, int64_t N) {
+    extern __shared__ __align__(16) float lds_w[];
+    for (int p = threadIdx.x; p < e.total / 4; p += kEncBlock)
+        reinterpret_cast<float4*>(lds_w)[p] = reinterpret_cast<const float4*>(packed)[p];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, i = lane & 31;
+    constexpr int NW = kEncBlock / 64;
+    const int64_t ntile = (N + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntile; tile += (int64_t)gridDim.x * NW) {
+        const int64_t v = tile * 32 + i;
+        const int64_t vc = v < N ? v : N - 1;  // clamp: every lane takes part in the MFMAs
+        float xv[T], nv[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) xv[t] = x[vc * T + t];
+        qb::normalise<T>(c, xv, nv);
+        f32x16 a[2];
+        qb::dense_first<T>(lds_w + e.first_A, lds_w + e.first_b, nv, a, h, i);
+        if (out2 || sigma) {
+            f32x16 b[2] = {a[0], a[1]};  // net2 = net1, model.py:185
+            for (int l = 0; l < e.L; ++l) qb::block_stream2(lds_w + e.blk0 + l * e.blk_stride, b, h, i);
+            const f32x16 hd = qb::dense_head(lds_w + e.head_A, lds_w + e.head_b, b, h, i);
+            float o[5 + T];
+            qb::gather_head<5 + T>(hd, o);
+            if (v < N) {
+                if (out2 && h == 0) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) out2[v * 5 + k] = o[k];
+                }
+                if (sigma && h == 1) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) sigma[v * T + t] = __expf(o[5 + t]);  // model.py:214
+                }
+            }
+        }
+        if (out1) {
+            for (int l = 0; l < e.L; ++l) qb::block_stream1(lds_w + e.blk0 + l * e.blk_stride, a, h, i);
+            const f32x16 hd = qb::dense_head(lds_w + e.head_A, lds_w + e.head_b, a, h, i);
+            float o[5];
+            qb::gather_head<5>(hd, o);
+            if (v < N && h == 0) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) out1[v * 5 + k] = o[k];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+namespace qb {
+int check_encoder_shape(const qbold_ctx* ctx, const qbold_encoder_shape* s) {
+    if (!s) { set_error("encoder shape is null"); return QBOLD_ERR_INVALID; }
+    if (s->T != ctx->dev.T) { set_error("encoder shape T differs from the context's tau grid"); return QBOLD_ERR_INVALID; }
+    if (s->U < 1 || s->U > 64 || s->L < 1 || s->L > 2 || s->T > 27) {
+        set_error("encoder kernels are built for U <= 64, L <= 2, T <= 27 (LDS-resident weights)");
+        return QBOLD_ERR_UNSUPPORTED;
+    }
+    return QBOLD_OK;
+}
+}  // namespace qb
+
+extern "C" int64_t qbold_encoder_num_params(const qbold_encoder_shape* s) {
+    if (!s) return QBOLD_ERR_INVALID;
+    return qb::make_canon(s->T, s->U, s->L, s->channelwise_gating).total;
+}
+
+extern "C" int64_t qbold_encoder_packed_floats(const qbold_encoder_shape* s) {
+    if (!s) return QBOLD_ERR_INVALID;
+    return qb::make_enc_layout(s->T, s->U, s->L).total;
+}
+
+extern "C" int qbold_encoder_pack(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
+                                  const float* weights, float* packed, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    int rc = qb::check_encoder_shape(ctx, shape);
+    if (rc) return rc;
+    QB_REQUIRE(weights && packed, "qbold_encoder_pack: null buffer");
+    const EncLayout e = qb::make_enc_layout(shape->T, shape->U, shape->L);
+    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating);
+    hipLaunchKernelGGL(pack_kernel, dim3((e.total + 255) / 256), dim3(256), 0, (hipStream_t)stream, e,
+                       c, shape->gate_offset, weights, packed);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
+extern "C" int qbold_encoder_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
+                                 const float* packed, const float* x, float* out1, float* out2,
+                                 float* sigma, int64_t N, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    int rc = qb::check_encoder_shape(ctx, shape);
+    if (rc) return rc;
+    QB_REQUIRE(N >= 0, "qbold_encoder_fwd: negative N");
+    if (N == 0) return QBOLD_OK;
+    QB_REQUIRE(packed && x, "qbold_encoder_fwd: null buffer");
+    const EncLayout e = qb::make_enc_layout(shape->T, shape->U, shape->L);
+    const size_t smem = sizeof(float) * e.total;
+    const int64_t ntile = (N + 31) / 32;
+    const int64_t nblk = (ntile + kEncBlock / 64 - 1) / (kEncBlock / 64);
+    const int grid = (int)(nblk < ctx->num_cus ? nblk : ctx->num_cus);
+    switch (shape->T) {
+        case 11: {
+            auto k = encoder_fwd_kernel<11>;
+            QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(k, dim3(grid), dim3(kEncBlock), smem, (hipStream_t)stream, ctx->dev, e,
+                               packed, x, out1, out2, sigma, N);
+            break;
+        }
+        default:
+            qb::set_error("qbold_encoder_fwd: kernels are built for T = 11 taus");
+            return QBOLD_ERR_UNSUPPORTED;
+    }
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}

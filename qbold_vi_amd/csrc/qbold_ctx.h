@@ -1,0 +1,48 @@
+// qbold_ctx.h -- host-side context of libqbold_hip.so (private; the public face is
+// include/qbold_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/qbold_hip.h"
+#include "qbold_dev.h"
+
+struct qbold_ctx {
+    int device = 0;
+    qbold_consts consts{};
+    qbold_loss_cfg loss{};
+    QbDev dev{};                    // folded constants, passed by value to kernels
+    float4* d_tab = nullptr;        // device copy of the F(x) cubic table
+    std::vector<float> h_tab;       // host copy (4 floats per segment)
+    int num_cus = 256;
+};
+
+namespace qb {
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+}  // namespace qb
+
+#define QB_HIP(call)                                              \
+    do {                                                          \
+        hipError_t _e = (call);                                   \
+        if (_e != hipSuccess) return qb::hip_fail(_e, #call);     \
+    } while (0)
+
+#define QB_NEED_DEVICE(ctx)                                                   \
+    do {                                                                      \
+        if (!(ctx) || (ctx)->device < 0) {                                    \
+            qb::set_error("context has no device (host-only or null)");       \
+            return QBOLD_ERR_NO_DEVICE;                                       \
+        }                                                                     \
+    } while (0)
+
+#define QB_REQUIRE(cond, msg)              \
+    do {                                   \
+        if (!(cond)) {                     \
+            qb::set_error(msg);            \
+            return QBOLD_ERR_INVALID;      \
+        }                                  \
+    } while (0)

@@ -1,0 +1,372 @@
+// qbold_dev.h -- device-side building blocks shared by the gfx950 kernels of libqbold_hip.so.
+//
+// Everything here is per-voxel (or per voxel-sample) float32 arithmetic restating the reference's
+// Python (file:line cited per function, relative to the reference repository root).  The kernels
+// that use these pieces live in signal_kernels.hip / elbo_kernels.hip / encoder_kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define QB_MAX_T 64
+#define QB_TAB_SEG 256        // cubic-Hermite segments of the F(x) table (4 KiB in LDS)
+#define QB_NNODE 129          // Simpson nodes of signals.py:168
+#define QB_WAVE 64
+
+// Folded float32 constants of one context; passed BY VALUE as a kernel argument so every field is
+// read with scalar loads and lives in SGPRs (wave-uniform).
+struct QbDev {
+    int T, se_idx, full_model, include_blood;
+    int multi_norm, predict_log, use_student_t, tissue_mode;
+    float dw_coef;   // (4/3) pi gamma b0 dchi hct                      signals.py:144
+    float e_te_r2t;  // exp(-te*r2t)                                    signals.py:172
+    float r2t_te;    // -r2t*te                                         signals.py:204
+    float m_bld_nb;  // m_bld * nb                                      signals.py:102-107
+    float g0_c1;     // (4/45) hct (1-hct)                              signals.py:239
+    float g0_c2;     // 4 pi b0 dchi                                    signals.py:239
+    float half_g2;   // 0.5 gamma^2                                     signals.py:241
+    float td2;       // td^2                                            signals.py:241
+    float e_r2b_te;  // exp(-r2b*te)                                    signals.py:241
+    float tab_inv_h; // segments per unit x
+    float tab_xmax;  // table covers |x| <= tab_xmax
+    float dF_node0;  // slope of Simpson node 0 in dF/dx (see tissue_F)
+    float st_df, st_const;  // Student-t df and log-normaliser          model.py:558
+    float taus[QB_MAX_T];
+    float blood_B[QB_MAX_T];  // bracket of signals.py:242-247 per tau
+};
+
+namespace qb {
+
+// ---------------------------------------------------------------------------------------------
+// small math
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float clampf_(float v, float lo, float hi) {
+    return fminf(fmaxf(v, lo), hi);
+}
+// tanh through one exp: tanh(p) = 1 - 2/(exp(2p)+1); |error| ~ 1e-7 abs, monotone, saturates.
+__device__ __forceinline__ float tanhf_(float p) {
+    float e = __expf(2.0f * p);
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+// transform_std / transform_offdiag -- model.py:288-294 = logit_mvn.py:91-97
+__device__ __forceinline__ float transform_std(float p) { return tanhf_(p) * 3.0f - 1.0f; }
+__device__ __forceinline__ float transform_offdiag(float p) {
+    return tanhf_(p) * 0.1353352832366127f;  // exp(-2)
+}
+
+#define QB_OEF_RANGE 0.8f
+#define QB_MIN_OEF 0.04f
+#define QB_DBV_RANGE 0.2f
+#define QB_MIN_DBV 0.001f
+
+// Posterior parameters of one voxel with the transforms applied once.
+struct LogitMvn {
+    float mu_o, mu_d;  // logit-space means
+    float s_o, s_d;    // log std (transformed)
+    float c;           // off-diagonal Cholesky term (transformed)
+    float e_so, e_sd;  // exp(s)
+    float i_so, i_sd;  // exp(-s)
+    float i_bl;        // -exp(-s_o-s_d)*c                               model.py:434
+};
+
+__device__ __forceinline__ LogitMvn make_mvn(const float p[5]) {
+    LogitMvn m;
+    m.mu_o = p[0];
+    m.mu_d = p[2];
+    m.s_o = transform_std(p[1]);
+    m.s_d = transform_std(p[3]);
+    m.c = transform_offdiag(p[4]);
+    m.e_so = __expf(m.s_o);
+    m.e_sd = __expf(m.s_d);
+    m.i_so = __expf(-m.s_o);
+    m.i_sd = __expf(-m.s_d);
+    m.i_bl = __expf(-m.s_o - m.s_d) * m.c * -1.0f;
+    return m;
+}
+
+// ReparamTrickLayer.call -- model.py:25-31: logit-space sample (a, b) from normals (z0, z1).
+__device__ __forceinline__ void reparam_logits(const LogitMvn& m, float z0, float z1, float& a,
+                                               float& b) {
+    a = m.mu_o + z0 * m.e_so;
+    b = m.mu_d + z0 * m.c + z1 * m.e_sd;
+}
+// forward_transform -- model.py:299-305
+__device__ __forceinline__ void forward_transform(float a, float b, float& oef, float& dbv) {
+    oef = sigmoidf_(a) * QB_OEF_RANGE + QB_MIN_OEF;
+    dbv = sigmoidf_(b) * QB_DBV_RANGE + QB_MIN_DBV;
+}
+
+// Observation-side quantities of logit_gaussian_mvg_log_prob that do not depend on the
+// distribution parameters (model.py:393-398): clipped unit-interval values' logits and Jacobian.
+struct LogitObs {
+    float l0, l1;  // logit(x)
+    float jac;     // sum log x + log(1-x)
+};
+__device__ __forceinline__ LogitObs make_obs(float oef, float dbv) {
+    float x0 = (oef - QB_MIN_OEF) / QB_OEF_RANGE;  // backwards_transform, model.py:307-311
+    float x1 = (dbv - QB_MIN_DBV) / QB_DBV_RANGE;
+    x0 = clampf_(x0, 1e-6f, 1.0f - 1e-6f);         // model.py:394-395
+    x1 = clampf_(x1, 1e-6f, 1.0f - 1e-6f);
+    float lx0 = __logf(x0), l1x0 = __logf(1.0f - x0);
+    float lx1 = __logf(x1), l1x1 = __logf(1.0f - x1);
+    LogitObs o;
+    o.l0 = lx0 - l1x0;  // logit, model.py:10-12
+    o.l1 = lx1 - l1x1;
+    o.jac = (lx0 + l1x0) + (lx1 + l1x1);  // model.py:398
+    return o;
+}
+// Negative log-density -- gaussian_nll_chol + Jacobian, model.py:385-398, :423-447.
+__device__ __forceinline__ float nlogp(const LogitObs& o, const LogitMvn& m) {
+    float r0 = o.l0 - m.mu_o, r1 = o.l1 - m.mu_d;
+    float w0 = r0 * m.i_so;
+    float w1 = r1 * m.i_sd + r0 * m.i_bl;
+    float swr = w0 * w0 + w1 * w1;
+    return 1.8378770664093453f + (m.s_o + m.s_d) + 0.5f * swr + o.jac;  // log(2 pi) + ...
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Random123) and the normal stream: ctr = (voxel_lo, voxel_hi, pair index,
+// stream id), key = (seed_lo, seed_hi).  One call yields the (z0, z1) normals of two draws.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+    float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float r = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincospif(2.0f * u2, &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+enum { STREAM_LIK = 0, STREAM_KL = 1, STREAM_MOMENTS = 2 };
+
+// normals of draws (2*pair, 2*pair+1) of `stream` for global voxel `vox`
+__device__ __forceinline__ void normals4(uint64_t seed, uint64_t vox, uint32_t pair,
+                                         uint32_t stream, float z[4]) {
+    uint4 o = philox4x32_10(make_uint4((uint32_t)vox, (uint32_t)(vox >> 32), pair, stream),
+                            make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    box_muller(o.x, o.y, z[0], z[1]);
+    box_muller(o.z, o.w, z[2], z[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tissue integral F(x) -- signals.py:159-185.
+// ---------------------------------------------------------------------------------------------
+// Cephes j0f (= Eigen generic_j0<float> behind tf.math.special.bessel_j0, signals.py:170).
+__device__ __forceinline__ float j0f_(float xx) {
+    float x = fabsf(xx);
+    float z = x * x;
+    float p = -6.068350350393235E-008f;
+    p = p * z + 6.388945720783375E-006f;
+    p = p * z + -3.969646342510940E-004f;
+    p = p * z + 1.332913422519003E-002f;
+    p = p * z + -1.729150680240724E-001f;
+    float small = (x < 1.0e-3f) ? (1.0f - 0.25f * z) : (z - 5.78318596294678452118f) * p;
+    if (x <= 2.0f) return small;
+    float q = 1.0f / x;
+    float w = rsqrtf(x);
+    float m = -6.838999669318810E-002f;
+    m = m * q + 1.864949361379502E-001f;
+    m = m * q + -2.145007480346739E-001f;
+    m = m * q + 1.197549369473540E-001f;
+    m = m * q + -3.560281861530129E-003f;
+    m = m * q + -4.969382655296620E-002f;
+    m = m * q + -3.355424622293709E-006f;
+    m = m * q + 7.978845717621440E-001f;
+    float w2 = q * q;
+    float h = 3.242077816988247E+001f;
+    h = h * w2 + -3.630592630518434E+001f;
+    h = h * w2 + 1.756221482109099E+001f;
+    h = h * w2 + -4.974978466280903E+000f;
+    h = h * w2 + 1.001973420681837E+000f;
+    h = h * w2 + -1.939906941791308E-001f;
+    h = h * w2 + 6.490598792654666E-002f;
+    h = h * w2 + -1.249992184872738E-001f;
+    float xn = q * h - 0.7853981633974483096f;
+    return (w * m) * cosf(xn + x);
+}
+// Cephes j1f (the derivative TF registers for bessel_j0 is -bessel_j1).
+__device__ __forceinline__ float j1f_(float xx) {
+    float x = fabsf(xx);
+    float r;
+    if (x <= 2.0f) {
+        float z = x * x;
+        float p = -4.878788132172128E-009f;
+        p = p * z + 6.009061827883699E-007f;
+        p = p * z + -4.541343896997497E-005f;
+        p = p * z + 1.937383947804541E-003f;
+        p = p * z + -3.405537384615824E-002f;
+        r = (z - 1.46819706421238932572E1f) * x * p;
+    } else {
+        float q = 1.0f / x;
+        float w = sqrtf(q);
+        float m = 6.913942741265801E-002f;
+        m = m * q + -2.284801500053359E-001f;
+        m = m * q + 3.138238455499697E-001f;
+        m = m * q + -2.102302420403875E-001f;
+        m = m * q + 5.435364690523026E-003f;
+        m = m * q + 1.493389585089498E-001f;
+        m = m * q + 4.976029650847191E-006f;
+        m = m * q + 7.978845453073848E-001f;
+        float w2 = q * q;
+        float h = -4.497014141919556E+001f;
+        h = h * w2 + 5.073465654089319E+001f;
+        h = h * w2 + -2.485774108720340E+001f;
+        h = h * w2 + 7.222973196770240E+000f;
+        h = h * w2 + -1.544842782180211E+000f;
+        h = h * w2 + 3.503787691653334E-001f;
+        h = h * w2 + -1.637986776941202E-001f;
+        h = h * w2 + 3.749989509080821E-001f;
+        float xn = q * h - 2.35619449019234492885f;
+        r = (w * m) * cosf(xn + x);
+    }
+    return xx < 0 ? -r : r;
+}
+
+// LDS image shared by every kernel that evaluates the forward model:
+//   tab[QB_TAB_SEG] float4 cubic coefficients, then the Simpson node tables (literal mode).
+struct FwdLds {
+    float4 tab[QB_TAB_SEG];
+    float u[QB_NNODE + 3];
+    float pre[QB_NNODE + 3];  // (2+u)*sqrt(1-u)
+    float den[QB_NNODE + 3];  // 3*u^2
+};
+
+__device__ __forceinline__ void fwd_lds_fill(FwdLds* L, const float4* __restrict__ g_tab,
+                                             bool literal) {
+    for (int i = threadIdx.x; i < QB_TAB_SEG; i += blockDim.x) L->tab[i] = g_tab[i];
+    if (literal) {
+        // tf.linspace(1e-5, 1, 129) in float32 -- signals.py:166-168
+        const float a = 1e-5f, b = 1.0f;
+        const float delta = (b - a) / 128.0f;
+        for (int i = threadIdx.x; i < QB_NNODE; i += blockDim.x) {
+            float u = (i == QB_NNODE - 1) ? b : a + (float)i * delta;
+            L->u[i] = u;
+            L->pre[i] = (2.0f + u) * sqrtf(1.0f - u);
+            L->den[i] = 3.0f * (u * u);
+        }
+    }
+}
+
+// 129-node Simpson sum in float32, the reference's operation order -- signals.py:169-185.
+__device__ __noinline__ float tissue_F_literal(const FwdLds* L, float x) {
+    const float h3 = ((L->u[2] - L->u[0]) / 2.0f) / 3.0f;
+    const float x15 = 1.5f * x;
+    float acc = 0.0f;
+    float ya = L->pre[0] * (1.0f - j0f_(x15 * L->u[0])) / L->den[0];
+    for (int m = 0; m < (QB_NNODE - 1) / 2; ++m) {
+        float ym = L->pre[2 * m + 1] * (1.0f - j0f_(x15 * L->u[2 * m + 1])) / L->den[2 * m + 1];
+        float yb = L->pre[2 * m + 2] * (1.0f - j0f_(x15 * L->u[2 * m + 2])) / L->den[2 * m + 2];
+        acc += (ya + yb + 4.0f * ym) * h3;
+        ya = yb;
+    }
+    return acc;
+}
+__device__ __noinline__ float tissue_dF_literal(const FwdLds* L, float x) {
+    const float h3 = ((L->u[2] - L->u[0]) / 2.0f) / 3.0f;
+    const float x15 = 1.5f * x;
+    float acc = 0.0f;
+    float ya = L->pre[0] * (1.5f * L->u[0] * j1f_(x15 * L->u[0])) / L->den[0];
+    for (int m = 0; m < (QB_NNODE - 1) / 2; ++m) {
+        int i1 = 2 * m + 1, i2 = 2 * m + 2;
+        float ym = L->pre[i1] * (1.5f * L->u[i1] * j1f_(x15 * L->u[i1])) / L->den[i1];
+        float yb = L->pre[i2] * (1.5f * L->u[i2] * j1f_(x15 * L->u[i2])) / L->den[i2];
+        acc += (ya + yb + 4.0f * ym) * h3;
+        ya = yb;
+    }
+    return acc;
+}
+
+// Table evaluation: F and (optionally) dF/dx.  |x| beyond the table (OEF > 1, never produced by
+// forward_transform) takes the literal sum.  The derivative is the one TensorFlow's autodiff
+// yields through bessel_j0 (its registered gradient is -J1): the J1-kernel Simpson sum over ALL
+// 129 nodes.  Node 0 (u = 1e-5) contributes 0 to the float32 forward value (1 - J0 rounds to 0)
+// but a slope of dF_node0 * x to that gradient (J1(z) ~ z/2 is representable), so it is added to
+// the derivative of the forward cubic.
+template <bool LITERAL, bool WITH_D>
+__device__ __forceinline__ float tissue_F(const FwdLds* L, const QbDev& c, float x, float* dF) {
+    float ax = fabsf(x);
+    if (LITERAL || ax > c.tab_xmax) {
+        if (WITH_D) {
+            float d = tissue_dF_literal(L, ax);
+            *dF = x < 0 ? -d : d;
+        }
+        return tissue_F_literal(L, ax);
+    }
+    float u = ax * c.tab_inv_h;
+    int i = min((int)u, QB_TAB_SEG - 1);
+    float f = u - (float)i;
+    float4 k = L->tab[i];
+    if (WITH_D) {
+        float d = fmaf(fmaf(3.0f * k.w, f, 2.0f * k.z), f, k.y) * c.tab_inv_h + c.dF_node0 * ax;
+        *dF = x < 0 ? -d : d;
+    }
+    return fmaf(fmaf(fmaf(k.w, f, k.z), f, k.y), f, k.x);
+}
+
+// Per-voxel-sample part of the forward model that does not depend on tau.
+struct FwdVox {
+    float dw;     // calculate_dw, signals.py:142-147
+    float dbv;
+    float bw;     // blood weight, signals.py:107 / :110
+    float tw;     // tissue weight, signals.py:112
+    float g;      // 0.5 gamma^2 g0 td^2, signals.py:239-241
+};
+__device__ __forceinline__ FwdVox fwd_vox(const QbDev& c, float oef, float dbv) {
+    FwdVox v;
+    v.dw = c.dw_coef * oef;
+    v.dbv = dbv;
+    if (c.include_blood) {
+        v.bw = c.m_bld_nb * dbv;
+        float t = c.g0_c2 * oef;
+        v.g = (c.half_g2 * (c.g0_c1 * (t * t))) * c.td2;
+    } else {
+        v.bw = dbv;
+        v.g = 0.0f;
+    }
+    v.tw = 1.0f - v.bw;
+    return v;
+}
+// signal at one tau -- signals.py:98-114 with calc_tissue :152-209 and calc_blood :233-247.
+template <bool LITERAL>
+__device__ __forceinline__ float fwd_signal(const FwdLds* L, const QbDev& c, const FwdVox& v,
+                                            int t) {
+    const float tau = c.taus[t];
+    float tissue;
+    if (c.full_model) {
+        float F = tissue_F<LITERAL, false>(L, c, tau * v.dw, nullptr);
+        tissue = __expf(-v.dbv * F) * c.e_te_r2t;
+    } else {  // log-linear two-regime model, signals.py:194-207
+        float tc = 1.0f / v.dw;
+        float rt = (v.dw * v.dbv) * tau;
+        float e = __expf(c.r2t_te);
+        tissue = (fabsf(tau) < tc) ? e * __expf(-(0.3f * (rt * rt)) / v.dbv)
+                                   : e * __expf(v.dbv - rt);
+    }
+    float blood = c.include_blood ? c.e_r2b_te * __expf(-v.g * c.blood_B[t]) : 0.0f;
+    return v.tw * tissue + v.bw * blood;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave / block reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace qb

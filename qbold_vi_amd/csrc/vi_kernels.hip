@@ -1,0 +1,146 @@
+// vi_kernels.hip -- the whole voxel-ELBO hot path in one launch (qbold_vi_fwd).
+//
+// Per 32-voxel wave tile: load x -> normalise -> encoder stream 2 on the f32 matrix cores
+// (encoder_core.h) -> posterior parameters + sigma stay in registers -> S reparameterised draws
+// through the forward model + K-draw Monte-Carlo KL on the VALU (elbo_core.h) -> per-voxel
+// (nll, kl), posterior parameters and the three masked sums.  This is the reference's
+// full_model([data, mask]) + fine_tune_loss_fn + kl_loss (model.py:239-286, 527-568, 654-665)
+// evaluated for (N,1,1,1,T) voxel batches, with ELBO = nll + kl as train.py:351.
+//
+// HBM traffic per voxel (T=11): read x 44 + mask 4 + prior 20, write q 20 + (nll,kl) 8 = 96 B;
+// weights (145 KB), the F(x) table (4 KB) and constants are LDS/SGPR resident.  Work per voxel:
+// 60.8 kFLOP of MFMA + ~25 kFLOP-equivalent of VALU/transcendental at S=32, K=70: compute-bound
+// (arithmetic intensity ~900 flop/B against a machine balance of ~20 flop/B).
+//
+// One 512-thread workgroup per CU (the weight image takes ~145 KB of the 160 KB LDS); the two
+// waves per SIMD run the same program, so while one is in its VALU sampling phase the other can
+// own the SIMD's matrix pipe.
+#include "elbo_core.h"
+#include "encoder_core.h"
+#include "qbold_ctx.h"
+
+namespace qb {
+int check_encoder_shape(const qbold_ctx* ctx, const qbold_encoder_shape* s);
+}
+
+namespace {
+
+using qb::EncLayout;
+using qb::f32x16;
+
+constexpr int kBlock = 512;
+constexpr int kWaves = kBlock / 64;
+
+template <int T, bool LITERAL>
+__global__ __launch_bounds__(kBlock, 2) void vi_fwd_kernel(
+    QbDev c, EncLayout e, const float4* __restrict__ g_tab, const float* __restrict__ packed,
+    const float* __restrict__ x, const float* __restrict__ mask, const float* __restrict__ prior,
+    int S, int K, uint64_t seed, int64_t voxel0, float* __restrict__ q_out,
+    float2* __restrict__ nll_kl, double* __restrict__ partials, int64_t N) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* lds_w = reinterpret_cast<float*>(smem);
+    qb::FwdLds* L = reinterpret_cast<qb::FwdLds*>(smem + sizeof(float) * e.total);
+    double* red = reinterpret_cast<double*>(smem + sizeof(float) * e.total + sizeof(qb::FwdLds));
+    for (int p = threadIdx.x; p < e.total / 4; p += kBlock)
+        reinterpret_cast<float4*>(lds_w)[p] = reinterpret_cast<const float4*>(packed)[p];
+    qb::fwd_lds_fill(L, g_tab, true);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, i = lane & 31;
+    float s_nll = 0.0f, s_kl = 0.0f, s_m = 0.0f;
+    const int64_t ntile = (N + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntile;
+         tile += (int64_t)gridDim.x * kWaves) {
+        const int64_t v = tile * 32 + i;
+        const int64_t vc = v < N ? v : N - 1;
+        float xv[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) xv[t] = x[vc * T + t];
+        float o[5 + T];
+        {
+            float nv[T];
+            qb::normalise<T>(c, xv, nv);
+            f32x16 b[2];
+            qb::dense_first<T>(lds_w + e.first_A, lds_w + e.first_b, nv, b, h, i);
+            for (int l = 0; l < e.L; ++l) qb::block_stream2(lds_w + e.blk0 + l * e.blk_stride, b, h, i);
+            const f32x16 hd = qb::dense_head(lds_w + e.head_A, lds_w + e.head_b, b, h, i);
+            qb::gather_head<5 + T>(hd, o);
+        }
+        if (v < N) {
+            float sv[T], qv[5], pv[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                qv[k] = o[k];
+                pv[k] = prior[v * 5 + k];
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) sv[t] = __expf(o[5 + t]);  // model.py:214
+            const float m = mask ? mask[v] : 1.0f;
+            qb::VoxelLik<T> lik;
+            qb::prepare_lik<T>(c, xv, sv, m, lik);
+            const qb::LogitMvn qm = qb::make_mvn(qv), pm = qb::make_mvn(pv);
+            float nll_part, kl_part;
+            qb::voxel_mc_sums<T, LITERAL>(L, c, lik, qm, pm, S, K, nullptr, nullptr, seed,
+                                          (uint64_t)(voxel0 + v), h, nll_part, kl_part);
+            const float nll = (nll_part + __shfl_xor(nll_part, 32, 64)) / (float)S;
+            const float kl = K > 0 ? (kl_part + __shfl_xor(kl_part, 32, 64)) / (float)K : 0.0f;
+            if (h == 0) {
+                if (nll_kl) nll_kl[v] = make_float2(nll, kl);
+                s_nll += nll * m;              // model.py:564
+                s_kl += m > 0.0f ? kl : 0.0f;  // model.py:661
+                s_m += m;
+            } else if (q_out) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) q_out[v * 5 + k] = qv[k];
+            }
+        }
+    }
+    qb::block_partials(red, s_nll, s_kl, s_m, partials);
+}
+
+}  // namespace
+
+extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
+                            const float* packed, const float* x, const float* mask,
+                            const float* prior, int S, int K, uint64_t seed, int64_t voxel0,
+                            float* q_out, float* nll_kl, double* sums, void* workspace, int64_t N,
+                            void* stream) {
+    QB_NEED_DEVICE(ctx);
+    int rc = qb::check_encoder_shape(ctx, shape);
+    if (rc) return rc;
+    QB_REQUIRE(N >= 0 && S >= 1 && K >= 0, "qbold_vi_fwd: need N >= 0, S >= 1, K >= 0");
+    QB_REQUIRE(sums && workspace, "qbold_vi_fwd: null sums/workspace");
+    QB_REQUIRE(N == 0 || (packed && x && prior), "qbold_vi_fwd: null input buffer");
+    const EncLayout e = qb::make_enc_layout(shape->T, shape->U, shape->L);
+    const size_t smem = sizeof(float) * e.total + sizeof(qb::FwdLds) + sizeof(double) * 3 * kWaves;
+    hipStream_t s = (hipStream_t)stream;
+    double* partials = reinterpret_cast<double*>(workspace);
+    const int64_t ntile = (N + 31) / 32;
+    const int64_t nblk = (ntile + kWaves - 1) / kWaves;
+    const int grid = (int)(nblk < ctx->num_cus ? (nblk > 0 ? nblk : 1) : ctx->num_cus);
+    const bool lit = ctx->dev.tissue_mode == QBOLD_TISSUE_LITERAL;
+    float2* out = reinterpret_cast<float2*>(nll_kl);
+#define QB_LAUNCH_VI(TT, LIT)                                                                     \
+    do {                                                                                          \
+        auto k = vi_fwd_kernel<TT, LIT>;                                                          \
+        QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                              \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));       \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), smem, s, ctx->dev, e, ctx->d_tab, packed, \
+                           x, mask, prior, S, K, seed, voxel0, q_out, out, partials, N);          \
+    } while (0)
+    switch (shape->T) {
+        case 11:
+            if (lit) QB_LAUNCH_VI(11, true);
+            else QB_LAUNCH_VI(11, false);
+            break;
+        default:
+            qb::set_error("qbold_vi_fwd: kernels are built for T = 11 taus");
+            return QBOLD_ERR_UNSUPPORTED;
+    }
+#undef QB_LAUNCH_VI
+    QB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(qb::reduce_partials_kernel, dim3(1), dim3(192), 0, s, partials, grid, sums);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}

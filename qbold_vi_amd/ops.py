@@ -1,0 +1,277 @@
+"""Torch-tensor front-end of the C ABI: device buffers in, device buffers out.
+
+PyTorch owns the memory and the stream; every number is produced by libqbold_hip.so.  Inputs must
+be float32 CUDA (HIP) tensors -- CPU tensors are rejected, there is no host fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Consts, EncoderShape, LossCfg, QboldError
+
+PARAM_KEYS = ("gamma", "b0", "dchi", "te", "r2t", "tr", "ti", "t1b", "hct",
+              "tau_start", "tau_end", "tau_step")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, name, shape_last=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise QboldError(f"{name}: tensor is on {t.device}; the HIP kernels need a cuda (ROCm) tensor "
+                         "and there is no CPU fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    t = t.contiguous()
+    if shape_last is not None and t.shape[-1] != shape_last:
+        raise ValueError(f"{name}: last dimension is {t.shape[-1]}, expected {shape_last}")
+    return t
+
+
+class EncoderWeights:
+    """The canonical (Keras-orientation) weight blob of the voxel-wise encoder plus its
+    MFMA-ordered device copy.  Layout: include/qbold_hip.h, qbold_encoder_num_params."""
+
+    NAMES = ("W0", "b0", "Wc", "bc", "Wr1", "br1", "Wr2", "br2", "Wg", "bg", "Wf", "bf", "Ws", "bs")
+
+    def __init__(self, ctx, T, U, L, channelwise_gating=True, gate_offset=0.0):
+        self.ctx = ctx
+        self.shape = EncoderShape(int(T), int(U), int(L), int(bool(channelwise_gating)),
+                                  float(gate_offset))
+        lib = _lib.load()
+        self.num_params = int(lib.qbold_encoder_num_params(C.byref(self.shape)))
+        self.flat = torch.zeros(self.num_params, dtype=torch.float32, device=ctx.device)
+        self.packed = torch.zeros(int(lib.qbold_encoder_packed_floats(C.byref(self.shape))),
+                                  dtype=torch.float32, device=ctx.device)
+        self._dirty = True
+
+    # canonical blob views -------------------------------------------------------------------
+    def _slices(self):
+        T, U, L = self.shape.T, self.shape.U, self.shape.L
+        G = U if self.shape.channelwise_gating else 1
+        out, off = {}, 0
+
+        def take(name, *shape):
+            nonlocal off
+            n = int(np.prod(shape))
+            out.setdefault(name, []).append((off, shape))
+            off += n
+        take("W0", T, U); take("b0", U)
+        for _ in range(L):
+            take("Wc", U, U); take("bc", U); take("Wr1", U, U); take("br1", U)
+            take("Wr2", U, U); take("br2", U); take("Wg", U, G); take("bg", G)
+        take("Wf", U, 5); take("bf", 5); take("Ws", U, T); take("bs", T)
+        assert off == self.num_params
+        return out
+
+    def set_from_arrays(self, w):
+        """w: dict name -> array; per-block tensors carry a leading [L] axis."""
+        sl = self._slices()
+        flat = torch.empty(self.num_params, dtype=torch.float32)
+        for name, pieces in sl.items():
+            arr = torch.as_tensor(np.asarray(w[name], dtype=np.float32))
+            for l, (off, shape) in enumerate(pieces):
+                src = arr[l] if len(pieces) > 1 or arr.dim() == len(shape) + 1 else arr
+                flat[off:off + int(np.prod(shape))] = src.reshape(-1)
+        self.flat.copy_(flat.to(self.flat.device))
+        self._dirty = True
+        return self
+
+    def to_arrays(self):
+        sl = self._slices()
+        flat = self.flat.detach().cpu().numpy()
+        out = {}
+        for name, pieces in sl.items():
+            arrs = [flat[off:off + int(np.prod(shape))].reshape(shape) for off, shape in pieces]
+            out[name] = np.stack(arrs) if name in ("Wc", "bc", "Wr1", "br1", "Wr2", "br2", "Wg", "bg") \
+                else arrs[0]
+        return out
+
+    def mark_dirty(self):
+        self._dirty = True
+
+    def packed_ptr(self):
+        if self._dirty:
+            _lib.check(_lib.load().qbold_encoder_pack(self.ctx.handle, C.byref(self.shape),
+                                                      _ptr(self.flat), _ptr(self.packed), _stream()),
+                       "qbold_encoder_pack")
+            self._dirty = False
+        return _ptr(self.packed)
+
+
+class Context:
+    """One qbold_ctx: folded constants + F(x) table on one device."""
+
+    def __init__(self, params, full_model=True, include_blood=True, multi_image_normalisation=False,
+                 predict_log_data=False, student_t_df=None, device=None, host_only=False):
+        lib = _lib.load()
+        consts = Consts(**{k: float(params[k]) for k in PARAM_KEYS},
+                        full_model=int(bool(full_model)), include_blood=int(bool(include_blood)))
+        use_t = student_t_df is not None and student_t_df < 50  # model.py:557
+        loss = LossCfg(int(bool(multi_image_normalisation)), int(bool(predict_log_data)), int(use_t),
+                       float(student_t_df) if use_t else 0.0)
+        if host_only:
+            dev_index = -1
+            self.device = torch.device("cpu")
+        else:
+            if not torch.cuda.is_available():
+                raise QboldError("no ROCm device visible to PyTorch; libqbold_hip.so needs an "
+                                 "MI355X (there is no CPU fallback)")
+            self.device = torch.device(device if device is not None else
+                                       f"cuda:{torch.cuda.current_device()}")
+            dev_index = self.device.index if self.device.index is not None else 0
+        h = C.c_void_p()
+        _lib.check(lib.qbold_ctx_create(C.byref(consts), C.byref(loss), dev_index, C.byref(h)),
+                   "qbold_ctx_create")
+        self.handle = h
+        self.lib = lib
+        self.T = lib.qbold_ctx_num_taus(h)
+        self.se_idx = lib.qbold_ctx_se_idx(h)
+        taus = np.zeros(self.T, np.float32)
+        _lib.check(lib.qbold_ctx_taus(h, taus.ctypes.data_as(C.c_void_p)), "qbold_ctx_taus")
+        self.taus = taus
+        self._ws = None
+        self._sums = None
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            self.lib.qbold_ctx_destroy(h)
+            self.handle = None
+
+    # -- configuration ---------------------------------------------------------------------
+    def set_tissue_mode(self, mode):
+        mode = {"table": 0, "literal": 1}.get(mode, mode)
+        _lib.check(self.lib.qbold_ctx_set_tissue_mode(self.handle, int(mode)), "set_tissue_mode")
+
+    def table_eval(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        F = np.empty_like(x)
+        dF = np.empty_like(x)
+        _lib.check(self.lib.qbold_ctx_table_eval(self.handle, x.ctypes.data_as(C.c_void_p),
+                                                 F.ctypes.data_as(C.c_void_p),
+                                                 dF.ctypes.data_as(C.c_void_p), x.size), "table_eval")
+        return F, dF
+
+    def _workspace(self):
+        if self._ws is None:
+            n = int(self.lib.qbold_elbo_workspace_bytes(self.handle))
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # -- forward model ---------------------------------------------------------------------
+    def signal_fwd(self, oef_dbv):
+        x = _f32(oef_dbv, "oef_dbv", 2)
+        V = x.numel() // 2
+        out = torch.empty(x.shape[:-1] + (self.T,), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.qbold_signal_fwd(self.handle, _ptr(x), _ptr(out), V, _stream()),
+                   "qbold_signal_fwd")
+        return out
+
+    def signal_bwd(self, oef_dbv, grad_signal):
+        x = _f32(oef_dbv, "oef_dbv", 2)
+        g = _f32(grad_signal, "grad_signal", self.T)
+        V = x.numel() // 2
+        if g.numel() != V * self.T:
+            raise ValueError("grad_signal does not match oef_dbv")
+        out = torch.empty_like(x)
+        _lib.check(self.lib.qbold_signal_bwd(self.handle, _ptr(x), _ptr(g), _ptr(out), V, _stream()),
+                   "qbold_signal_bwd")
+        return out
+
+    # -- encoder ---------------------------------------------------------------------------
+    def encoder_fwd(self, weights, x, want=("out1", "out2", "sigma")):
+        x = _f32(x, "x", self.T)
+        N = x.numel() // self.T
+        lead = x.shape[:-1]
+        mk = lambda c: torch.empty(lead + (c,), dtype=torch.float32, device=x.device)
+        o1 = mk(5) if "out1" in want else None
+        o2 = mk(5) if "out2" in want else None
+        sg = mk(self.T) if "sigma" in want else None
+        _lib.check(self.lib.qbold_encoder_fwd(self.handle, C.byref(weights.shape), weights.packed_ptr(),
+                                              _ptr(x), _ptr(o1), _ptr(o2), _ptr(sg), N, _stream()),
+                   "qbold_encoder_fwd")
+        return o1, o2, sg
+
+    # -- logit-normal ----------------------------------------------------------------------
+    def reparam(self, q, z):
+        q = _f32(q, "q", 5)
+        z = _f32(z, "z", 2)
+        N = q.numel() // 5
+        out = torch.empty(q.shape[:-1] + (2,), dtype=torch.float32, device=q.device)
+        _lib.check(self.lib.qbold_reparam(self.handle, _ptr(q), _ptr(z), _ptr(out), N, _stream()),
+                   "qbold_reparam")
+        return out
+
+    def logit_mvn_nlogp(self, y, params):
+        y = _f32(y, "y", 2)
+        p = _f32(params, "params", 5)
+        N = p.numel() // 5
+        out = torch.empty(p.shape[:-1], dtype=torch.float32, device=p.device)
+        _lib.check(self.lib.qbold_logit_mvn_nlogp(self.handle, _ptr(y), _ptr(p), _ptr(out), N,
+                                                  _stream()), "qbold_logit_mvn_nlogp")
+        return out
+
+    def posterior_moments(self, q, n_samples=20, z=None, seed=1, voxel0=0, want_vars=True):
+        q = _f32(q, "q", 5)
+        N = q.numel() // 5
+        if z is not None:
+            z = _f32(z, "z", 2)
+        means = torch.empty(q.shape[:-1] + (3,), dtype=torch.float32, device=q.device)
+        var = torch.empty_like(means) if want_vars else None
+        _lib.check(self.lib.qbold_posterior_moments(self.handle, _ptr(q), _ptr(z), int(n_samples),
+                                                    int(seed), int(voxel0), _ptr(means), _ptr(var),
+                                                    N, _stream()), "qbold_posterior_moments")
+        return means, var
+
+    # -- ELBO ------------------------------------------------------------------------------
+    def elbo_fwd(self, x, mask, q, prior, sigma, S=1, K=70, zs=None, zk=None, seed=1, voxel0=0,
+                 per_voxel=True):
+        """Returns (sums double[3] device tensor = (sum m*nll, sum [m>0] kl, sum m), nll_kl [N,2])."""
+        x = _f32(x, "x", self.T)
+        N = x.numel() // self.T
+        q = _f32(q, "q", 5)
+        prior = _f32(prior, "prior", 5)
+        sigma = _f32(sigma, "sigma", self.T)
+        mask = _f32(mask, "mask") if mask is not None else None
+        zs = _f32(zs, "zs", 2) if zs is not None else None
+        zk = _f32(zk, "zk", 2) if zk is not None else None
+        if zs is not None and zs.numel() != N * S * 2:
+            raise ValueError("zs must be [N, S, 2]")
+        if zk is not None and zk.numel() != N * K * 2:
+            raise ValueError("zk must be [N, K, 2]")
+        sums = torch.empty(3, dtype=torch.float64, device=x.device)
+        out = torch.empty((N, 2), dtype=torch.float32, device=x.device) if per_voxel else None
+        _lib.check(self.lib.qbold_elbo_fwd(self.handle, _ptr(x), _ptr(mask), _ptr(q), _ptr(prior),
+                                           _ptr(sigma), _ptr(zs), _ptr(zk), int(S), int(K), int(seed),
+                                           int(voxel0), _ptr(out), _ptr(sums),
+                                           _ptr(self._workspace()), N, _stream()), "qbold_elbo_fwd")
+        return sums, out
+
+    def vi_fwd(self, weights, x, mask, prior, S=1, K=70, seed=1, voxel0=0, want_q=True,
+               per_voxel=True, out=None):
+        """Fused encoder + ELBO.  Returns (sums, q [N,5] or None, nll_kl [N,2] or None)."""
+        x = _f32(x, "x", self.T)
+        N = x.numel() // self.T
+        prior = _f32(prior, "prior", 5)
+        mask = _f32(mask, "mask") if mask is not None else None
+        if out is None:
+            sums = torch.empty(3, dtype=torch.float64, device=x.device)
+            qo = torch.empty((N, 5), dtype=torch.float32, device=x.device) if want_q else None
+            nk = torch.empty((N, 2), dtype=torch.float32, device=x.device) if per_voxel else None
+        else:
+            sums, qo, nk = out
+        _lib.check(self.lib.qbold_vi_fwd(self.handle, C.byref(weights.shape), weights.packed_ptr(),
+                                         _ptr(x), _ptr(mask), _ptr(prior), int(S), int(K), int(seed),
+                                         int(voxel0), _ptr(qo), _ptr(nk), _ptr(sums),
+                                         _ptr(self._workspace()), N, _stream()), "qbold_vi_fwd")
+        return sums, qo, nk

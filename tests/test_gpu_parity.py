@@ -1,0 +1,292 @@
+"""GPU parity tests: HIP kernels (through the C ABI) against the CPU oracle on identical inputs.
+
+Tolerances follow SURVEY.md 8(d) "Parity gates" and BASELINE.json north_star:
+  per-voxel signal <= 1e-5 rel (same F policy), ELBO scalar <= 1e-4 rel,
+  posterior means <= 1e-5 abs, variances <= 1e-4 rel (+ tiny abs floor).
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(params):
+    from qbold_vi_amd.ops import Context
+    return Context(params, full_model=True, include_blood=True)
+
+
+@pytest.fixture(scope="module")
+def weights(ctx):
+    from oracle.oracle import init_weights
+    from qbold_vi_amd.ops import EncoderWeights
+    w = init_weights(T=11, U=60, L=2, seed=3)
+    # non-trivial biases so that every bias path is exercised
+    rng = np.random.default_rng(7)
+    for n in ("b0", "bc", "br1", "br2", "bg", "bf"):
+        w[n] = (rng.standard_normal(w[n].shape) * 0.1).astype(np.float32)
+    w["gate_offset"] = -3.0
+    ew = EncoderWeights(ctx, 11, 60, 2, True, -3.0).set_from_arrays(w)
+    return w, ew
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+
+
+def rel(a, b, floor=0.0):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + floor)))
+
+
+def grid_oef_dbv(n=4096, seed=0):
+    rng = np.random.default_rng(seed)
+    oef = rng.uniform(0.04, 0.84, n)
+    dbv = rng.uniform(0.001, 0.201, n)
+    y = np.stack([oef, dbv], -1).astype(np.float32)
+    y[:4] = [[0.4, 0.12], [0.4, 0.025], [0.04, 0.001], [0.84, 0.201]]
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+def test_signal_fwd_literal_matches_oracle(ctx, oracle32):
+    y = grid_oef_dbv(4096)
+    ctx.set_tissue_mode("literal")
+    try:
+        got = ctx.signal_fwd(dev(y)).cpu().numpy()
+    finally:
+        ctx.set_tissue_mode("table")
+    want = oracle32.signal_fwd(y)
+    # same algorithm, same float32 semantics: only libm-vs-OCML ulp differences remain
+    assert rel(got, want) < 2e-6
+
+
+def test_signal_fwd_table_matches_oracle(ctx, oracle32, oracle64):
+    y = grid_oef_dbv(20000, seed=1)
+    got = ctx.signal_fwd(dev(y)).cpu().numpy()
+    want = oracle32.signal_fwd(y)
+    assert rel(got, want) < 1e-5
+    # reported, not gated: distance of both from the float64 evaluation
+    truth = oracle64.signal_fwd(y)
+    print("table vs f64 truth", rel(got, truth), "oracle32 vs f64 truth", rel(want, truth))
+
+
+def test_signal_fwd_shapes_and_edges(ctx, oracle32):
+    # arbitrary leading dims, V not a multiple of the block, empty input
+    y = grid_oef_dbv(3 * 5 * 7 + 1)[:105].reshape(3, 5, 7, 2)
+    got = ctx.signal_fwd(dev(y))
+    assert got.shape == (3, 5, 7, 11)
+    assert rel(got.cpu().numpy(), oracle32.signal_fwd(y)) < 1e-5
+    empty = ctx.signal_fwd(torch.empty((0, 2), device="cuda"))
+    assert empty.shape == (0, 11)
+    one = ctx.signal_fwd(dev(np.array([[0.4, 0.12]], np.float32))).cpu().numpy()
+    assert rel(one, oracle32.signal_fwd([[0.4, 0.12]])) < 1e-5
+    with pytest.raises(Exception):
+        ctx.signal_fwd(torch.zeros((4, 2)))  # CPU tensor: no fallback
+
+
+def test_signal_loglinear_and_no_blood(params, oracle32):
+    from oracle.oracle import Oracle
+    from qbold_vi_amd.ops import Context
+    y = grid_oef_dbv(2048, seed=2)
+    for full, blood in ((False, True), (True, False), (False, False)):
+        c = Context(params, full_model=full, include_blood=blood)
+        o = Oracle("f32", params, full_model=full, include_blood=blood)
+        assert rel(c.signal_fwd(dev(y)).cpu().numpy(), o.signal_fwd(y)) < 1e-5
+
+
+def test_signal_bwd_matches_oracle_jacobian(ctx, oracle32):
+    y = grid_oef_dbv(4096, seed=3)
+    rng = np.random.default_rng(5)
+    g = rng.standard_normal((y.shape[0], 11)).astype(np.float32)
+    jac = oracle32.signal_jac(y)  # [V, T, 2], J1-kernel derivative = TF's gradient of bessel_j0
+    want = np.einsum("vt,vtk->vk", g.astype(np.float64), jac)
+    got = ctx.signal_bwd(dev(y), dev(g)).cpu().numpy()
+    scale = np.abs(np.einsum("vt,vtk->vk", np.abs(g).astype(np.float64), np.abs(jac))) + 1e-6
+    assert float(np.max(np.abs(got - want) / scale)) < 2e-4
+    ctx.set_tissue_mode("literal")
+    try:
+        got_l = ctx.signal_bwd(dev(y), dev(g)).cpu().numpy()
+    finally:
+        ctx.set_tissue_mode("table")
+    assert float(np.max(np.abs(got_l - want) / scale)) < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------
+def test_encoder_fwd_matches_oracle(ctx, weights, oracle32):
+    from oracle.oracle import synth_inputs
+    w, ew = weights
+    x, _ = synth_inputs(4096 + 17, seed=1, oracle=oracle32)
+    o1, o2, sg = ctx.encoder_fwd(ew, dev(x))
+    w1, w2, wsg = oracle32.encoder_fwd(w, x)
+    assert np.max(np.abs(o1.cpu().numpy() - w1)) < 2e-5
+    assert np.max(np.abs(o2.cpu().numpy() - w2)) < 2e-5
+    assert rel(sg.cpu().numpy(), wsg) < 2e-5
+    # each output on its own (NULL pointers for the others)
+    only1, _, _ = ctx.encoder_fwd(ew, dev(x), want=("out1",))
+    assert torch.equal(only1, o1)
+    _, only2, _ = ctx.encoder_fwd(ew, dev(x), want=("out2",))
+    assert torch.equal(only2, o2)
+
+
+def test_encoder_small_shapes(ctx, oracle32):
+    from oracle.oracle import init_weights, synth_inputs
+    from qbold_vi_amd.ops import EncoderWeights
+    x, _ = synth_inputs(333, seed=4, oracle=oracle32)
+    for U, L, cw in ((30, 1, True), (10, 1, False), (64, 2, True), (33, 2, False)):
+        w = init_weights(T=11, U=U, L=L, channelwise_gating=cw, seed=U)
+        w["gate_offset"] = 0.5
+        ew = EncoderWeights(ctx, 11, U, L, cw, 0.5).set_from_arrays(w)
+        o1, o2, sg = ctx.encoder_fwd(ew, dev(x))
+        w1, w2, wsg = oracle32.encoder_fwd(w, x)
+        assert np.max(np.abs(o1.cpu().numpy() - w1)) < 2e-5, (U, L, cw)
+        assert np.max(np.abs(o2.cpu().numpy() - w2)) < 2e-5, (U, L, cw)
+        assert rel(sg.cpu().numpy(), wsg) < 2e-5, (U, L, cw)
+
+
+# ---------------------------------------------------------------------------------------------
+def make_q(n, seed=0):
+    rng = np.random.default_rng(seed)
+    q = np.empty((n, 5), np.float32)
+    q[:, 0] = rng.normal(-0.2, 0.8, n)
+    q[:, 1] = rng.normal(0.0, 0.7, n)
+    q[:, 2] = rng.normal(-1.5, 0.8, n)
+    q[:, 3] = rng.normal(0.0, 0.7, n)
+    q[:, 4] = rng.normal(0.0, 1.0, n)
+    return q
+
+
+def test_reparam_and_nlogp(ctx, oracle32):
+    n = 10000
+    q, z = make_q(n, 1), np.random.default_rng(2).standard_normal((n, 2)).astype(np.float32)
+    z[:8] *= 6.0  # drive some samples into the clip of model.py:395
+    y = ctx.reparam(dev(q), dev(z)).cpu().numpy()
+    want = oracle32.reparam(q, z)
+    assert np.max(np.abs(y - want)) < 2e-6
+    p = make_q(n, 3)
+    got = ctx.logit_mvn_nlogp(dev(want), dev(p)).cpu().numpy()
+    ref = oracle32.logit_mvn_nlogp(want, p)
+    # terms of order 1e2..1e3 cancel inside nlogp: float32 leaves ~1e-7 of the largest term
+    assert np.max(np.abs(got - ref) / (np.abs(ref) + 1.0)) < 1e-4
+
+
+def test_posterior_moments(ctx, oracle32):
+    n, ns = 5000, 200
+    q = make_q(n, 4)
+    z = np.random.default_rng(5).standard_normal((n, ns, 2)).astype(np.float32)
+    m, v = ctx.posterior_moments(dev(q), ns, z=dev(z))
+    wm, wv = oracle32.moments(q, z)
+    assert np.max(np.abs(m.cpu().numpy()[:, :2] - wm[:, :2])) < 1e-5
+    assert rel(m.cpu().numpy()[:, 2], wm[:, 2], 1e-3) < 1e-4
+    assert rel(v.cpu().numpy(), wv, 1e-7) < 1e-3
+    # Philox stream: integer part bit-identical to the oracle's, normals to a few ulp
+    m2, v2 = ctx.posterior_moments(dev(q), 20, seed=11, voxel0=123)
+    zp = oracle32.philox_normals(11, 2, 123, n, 20)
+    wm2, wv2 = oracle32.moments(q, zp)
+    assert np.max(np.abs(m2.cpu().numpy()[:, :2] - wm2[:, :2])) < 1e-5
+    assert rel(v2.cpu().numpy(), wv2, 1e-7) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------
+def elbo_inputs(oracle32, w, n, seed):
+    from oracle.oracle import synth_inputs
+    x, _ = synth_inputs(n, seed=seed, oracle=oracle32)
+    prior, q, sigma = oracle32.encoder_fwd(w, x)
+    rng = np.random.default_rng(seed + 100)
+    mask = (rng.uniform(size=n) > 0.2).astype(np.float32)
+    return x, mask, q, prior, sigma
+
+
+@pytest.mark.parametrize("S,K", [(1, 70), (32, 70), (3, 5)])
+def test_elbo_explicit_eps(ctx, weights, oracle32, S, K):
+    w, _ = weights
+    n = 2048 + 5
+    x, mask, q, prior, sigma = elbo_inputs(oracle32, w, n, 1)
+    rng = np.random.default_rng(9)
+    zs = rng.standard_normal((n, S, 2)).astype(np.float32)
+    zk = rng.standard_normal((n, K, 2)).astype(np.float32)
+    want = oracle32.elbo(x, mask, q, prior, sigma, zs, zk)
+    sums, nk = ctx.elbo_fwd(dev(x), dev(mask), dev(q), dev(prior), dev(sigma), S, K, dev(zs), dev(zk))
+    sums = sums.cpu().numpy()
+    nk = nk.cpu().numpy()
+    assert rel(nk[:, 0], want["nll_v"], 1.0) < 1e-4
+    assert np.max(np.abs(nk[:, 1] - want["kl_v"]) / (np.abs(want["kl_v"]) + 1.0)) < 1e-4
+    assert sums[2] == want["sums"][2]
+    elbo = sums[0] / sums[2] + sums[1] / sums[2]
+    assert abs(elbo - want["elbo"]) / abs(want["elbo"]) < 1e-4
+
+
+def test_elbo_philox_matches_oracle_stream(ctx, weights, oracle32):
+    w, _ = weights
+    n, S, K, seed, v0 = 1500, 32, 70, 1234, 1000003
+    x, mask, q, prior, sigma = elbo_inputs(oracle32, w, n, 2)
+    zs = oracle32.philox_normals(seed, 0, v0, n, S)
+    zk = oracle32.philox_normals(seed, 1, v0, n, K)
+    want = oracle32.elbo(x, mask, q, prior, sigma, zs, zk)
+    sums, nk = ctx.elbo_fwd(dev(x), dev(mask), dev(q), dev(prior), dev(sigma), S, K, seed=seed,
+                            voxel0=v0)
+    sums = sums.cpu().numpy()
+    elbo = (sums[0] + sums[1]) / sums[2]
+    assert abs(elbo - want["elbo"]) / abs(want["elbo"]) < 1e-4
+    assert rel(nk.cpu().numpy()[:, 0], want["nll_v"], 1.0) < 2e-4
+
+
+def test_elbo_literal_mode(ctx, weights, oracle32):
+    w, _ = weights
+    n, S, K = 512, 2, 4
+    x, mask, q, prior, sigma = elbo_inputs(oracle32, w, n, 3)
+    rng = np.random.default_rng(1)
+    zs = rng.standard_normal((n, S, 2)).astype(np.float32)
+    zk = rng.standard_normal((n, K, 2)).astype(np.float32)
+    want = oracle32.elbo(x, mask, q, prior, sigma, zs, zk)
+    ctx.set_tissue_mode("literal")
+    try:
+        sums, nk = ctx.elbo_fwd(dev(x), dev(mask), dev(q), dev(prior), dev(sigma), S, K, dev(zs), dev(zk))
+    finally:
+        ctx.set_tissue_mode("table")
+    assert rel(nk.cpu().numpy()[:, 0], want["nll_v"], 1.0) < 5e-5
+
+
+def test_vi_fwd_fused_matches_oracle(ctx, weights, oracle32):
+    """BASELINE config 1: optimal.yaml, 4k synthetic voxels x 11 tau (S=1 and S=32, K=70)."""
+    from oracle.oracle import synth_inputs
+    w, ew = weights
+    n, K, seed = 4096, 70, 1
+    x, _ = synth_inputs(n, seed=1, oracle=oracle32)
+    prior, q_want, sigma = oracle32.encoder_fwd(w, x)
+    mask = np.ones(n, np.float32)
+    for S in (1, 32):
+        zs = oracle32.philox_normals(seed, 0, 0, n, S)
+        zk = oracle32.philox_normals(seed, 1, 0, n, K)
+        want = oracle32.elbo(x, mask, q_want, prior, sigma, zs, zk)
+        sums, q, nk = ctx.vi_fwd(ew, dev(x), dev(mask), dev(prior), S, K, seed=seed)
+        sums = sums.cpu().numpy()
+        assert np.max(np.abs(q.cpu().numpy() - q_want)) < 2e-5
+        elbo = (sums[0] + sums[1]) / sums[2]
+        print("S", S, "elbo gpu", elbo, "oracle", want["elbo"])
+        assert abs(elbo - want["elbo"]) / abs(want["elbo"]) < 1e-4
+        assert rel(nk.cpu().numpy()[:, 0], want["nll_v"], 1.0) < 5e-4
+        # fused == unfused on the same encoder outputs and the same Philox stream
+        s2, nk2 = ctx.elbo_fwd(dev(x), dev(mask), q, dev(prior),
+                               ctx.encoder_fwd(ew, dev(x), want=("sigma",))[2], S, K, seed=seed)
+        assert torch.allclose(nk, nk2, rtol=1e-5, atol=1e-5)
+
+
+def test_vi_fwd_sharding_invariance(ctx, weights, oracle32):
+    """Philox counters are keyed by the global voxel index: two half-shards == one full batch."""
+    from oracle.oracle import synth_inputs
+    w, ew = weights
+    n = 3000
+    x, _ = synth_inputs(n, seed=5, oracle=oracle32)
+    prior = dev(oracle32.encoder_fwd(w, x)[0])
+    xd = dev(x)
+    full, qf, nkf = ctx.vi_fwd(ew, xd, None, prior, 4, 10, seed=3, voxel0=0)
+    h = 1472
+    a, qa, nka = ctx.vi_fwd(ew, xd[:h], None, prior[:h], 4, 10, seed=3, voxel0=0)
+    b, qb, nkb = ctx.vi_fwd(ew, xd[h:], None, prior[h:], 4, 10, seed=3, voxel0=h)
+    assert torch.equal(torch.cat([nka, nkb]), nkf)
+    assert torch.equal(torch.cat([qa, qb]), qf)
+    assert torch.allclose(a + b, full, rtol=1e-12)
