@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- voxel-ELBO evaluations per second on MI355X (BASELINE.json metric).
+
+A step = one pass of the whole hot path (qbold_vi_fwd: encoder stream 2 -> S reparameterised
+draws -> forward model over T taus -> NLL + K-draw MC KL -> masked sums) over one batch of
+synthetic voxels already resident in HBM.  Workload at N=1: BASELINE.json configs[1]
+(1 M voxels x 11 tau, S=32, K=70, fp32, configurations/optimal.yaml encoder).  With N>1 ranks
+(one process per GPU, torchrun) every rank owns its own 1 M-voxel shard (weak scaling) and the three
+masked sums are all-reduced over RCCL every step.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel vi_fwd_kernel, timed
+with HIP events on the launch stream) and "cpu_baseline" (the oracle's literal-Simpson restatement
+on the host cores, bounded sample).
+"""
+import argparse
+import configparser
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_voxel(T):
+    # read signal 4T + mask 4 + prior 20; write q 20 + (nll, kl) 8
+    return 4 * T + 4 + 20 + 20 + 8
+
+
+def encoder_macs_per_voxel(T, U, L):
+    # stream 2 only: first layer, L x (skip + 2 residual + gate), q head, sigma head
+    return T * U + L * 4 * U * U + U * 5 + U * T
+
+
+def make_inputs(n, params, seed, device):
+    """SURVEY 8(d) synthetic voxels, generated ON the GPU by the library's own forward model
+    (the oracle is not involved): OEF = clip(N(0.4,0.2),.05,.8), DBV = TruncNormal(0.025,0.02;
+    [.003,.195]) by rejection, reference noise model for T=11 (signals.py:116-128)."""
+    import torch
+    from qbold_vi_amd.ops import Context
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    oef = (torch.randn(n, generator=g, device=device) * 0.2 + 0.4).clamp_(0.05, 0.8)
+    dbv = torch.randn(n, generator=g, device=device) * 0.02 + 0.025
+    for _ in range(64):
+        bad = (dbv < 0.003) | (dbv > 0.195)
+        if not bool(bad.any()):
+            break
+        dbv = torch.where(bad, torch.randn(n, generator=g, device=device) * 0.02 + 0.025, dbv)
+    dbv.clamp_(0.003, 0.195)
+    ctx = Context(params, True, True, device=device)
+    sig = ctx.signal_fwd(torch.stack([oef, dbv], -1))
+    norm_snr = torch.tensor([0.985, 1.00, 1.01, 1., 0.97, 0.95, 0.93, 0.90, 0.86, 0.83, 0.79],
+                            device=device)
+    snr = (torch.rand(n, 1, generator=g, device=device) * 70 + 50) * norm_snr[None]
+    std = sig.mean(0, keepdim=True) / snr
+    sig = sig + torch.randn(sig.shape, generator=g, device=device) * std
+    return ctx, sig.contiguous()
+
+
+def cpu_baseline(params, weights_np, S, K, budget_s=15.0):
+    """Times the oracle (reference algorithm: literal 129-node Simpson + Bessel J0 per
+    (voxel, sample, tau), encoder, logit-Normal KL) on the host cores, on a bounded sample."""
+    from oracle.oracle import Oracle, synth_inputs
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    orc = Oracle("f32", params, threads=cores)
+
+    weights_np = dict(weights_np, gate_offset=-3.0,
+                      meta=dict(T=11, U=60, L=2, channelwise_gating=True))
+
+    def run(n):
+        x, _ = synth_inputs(n, params, seed=2, oracle=orc)
+        t0 = time.perf_counter()
+        prior, q, sigma = orc.encoder_fwd(weights_np, x)
+        zs = orc.philox_normals(1, 0, 0, n, S)
+        zk = orc.philox_normals(1, 1, 0, n, K)
+        orc.elbo(x, np.ones(n, np.float32), q, prior, sigma, zs, zk)
+        return time.perf_counter() - t0
+
+    n0 = 256 * cores
+    t_probe = run(n0)
+    n = int(min(max(n0, n0 * budget_s / max(t_probe, 1e-3)), 1 << 20))
+    n = max(1024, (n // 1024) * 1024)
+    t = run(n)
+    return {"value": n / t, "unit": "voxel-ELBO evals/s", "cores": cores, "kind": "port",
+            "sample": f"{n} voxels x 11 tau, S={S}, K={K}, C oracle (OpenMP), literal Simpson-129 "
+                      f"+ Cephes j0f as the reference computes it; {t:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--voxels", type=int, default=1 << 20, help="voxels per GPU")
+    ap.add_argument("--mc_samples", type=int, default=32)
+    ap.add_argument("--kl_samples", type=int, default=70)
+    ap.add_argument("--tissue", choices=["table", "literal"], default="table")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_budget_s", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from qbold_vi_amd.init import init_encoder_weights
+    from qbold_vi_amd.ops import EncoderWeights
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(ROOT, "config"))
+    params = dict(cfg["DEFAULT"])
+    T, U, L = 11, 60, 2  # configurations/optimal.yaml
+    S, K, n = args.mc_samples, args.kl_samples, args.voxels
+
+    ctx, x = make_inputs(n, params, seed=1 + rank, device=device)
+    ctx.set_tissue_mode(args.tissue)
+    w = init_encoder_weights(T=T, U=U, L=L, channelwise_gating=True, resid_init_std=0.05,
+                             im_loss_sigma=0.05, seed=1)
+    ew = EncoderWeights(ctx, T, U, L, True, -3.0).set_from_arrays(w)
+    mask = torch.ones(n, device=device)
+    prior, _, _ = ctx.encoder_fwd(ew, x, want=("out1",))  # prior = stream-1 output (train.py:26-31)
+    out = (torch.empty(3, dtype=torch.float64, device=device),
+           torch.empty((n, 5), device=device), torch.empty((n, 2), device=device))
+    voxel0 = rank * n
+
+    def step():
+        sums, _, _ = ctx.vi_fwd(ew, x, mask, prior, S, K, seed=1, voxel0=voxel0, out=out)
+        if world > 1:
+            dist.all_reduce(sums)  # RCCL over xGMI: sum m*nll, sum kl, sum m
+        return sums
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    # per-launch duration of the dominant kernel: HIP events on the launch stream
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        sums = ctx.vi_fwd(ew, x, mask, prior, S, K, seed=1, voxel0=voxel0, out=out)[0]
+        b.record()
+        if world > 1:
+            dist.all_reduce(sums)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    s = sums.cpu().numpy()
+    neg_elbo = float((s[0] + s[1]) / s[2])
+    if not np.isfinite(neg_elbo):
+        raise SystemExit("non-finite ELBO")  # the reference's TerminateOnNaN (train.py:375)
+
+    if rank == 0:
+        total_vox = n * world
+        value = total_vox * args.steps / elapsed
+        flops = 2.0 * encoder_macs_per_voxel(T, U, L) * n
+        byts = algorithmic_bytes_per_voxel(T) * n
+        ach_tf = flops / (kernel_ms * 1e-3) / 1e12
+        ach_gbs = byts / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_vi_fwd_pmc.json")
+        if os.path.exists(pmc) and args.tissue == "table" and n == 1 << 20:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "voxel-ELBO evals/sec", "value": value, "unit": "voxel-ELBO evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n} synthetic voxels/GPU x {T} tau, S={S} likelihood draws, "
+                                   f"K={K} KL draws, optimal.yaml encoder (U={U}, L={L}), fused "
+                                   f"qbold_vi_fwd, tissue integral: {args.tissue}",
+                       "global_voxels": total_vox, "parallelism": f"voxel-shard x{world}",
+                       "collective": "all_reduce(3 x f64)/step" if world > 1 else "none"},
+            "neg_elbo": neg_elbo,
+            "roofline": {"kernel": "vi_fwd_kernel<11>", "bound": "mfma", "achieved": ach_tf,
+                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach_tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel_ms": kernel_ms,
+                         "algorithmic_flops_per_voxel": 2 * encoder_macs_per_voxel(T, U, L),
+                         "hbm": {"algorithmic_bytes_per_voxel": algorithmic_bytes_per_voxel(T),
+                                 "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": ach_gbs / HBM_PEAK_GBS}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(params, w, S, K, args.cpu_budget_s)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

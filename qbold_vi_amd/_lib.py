@@ -80,6 +80,10 @@ def load():
         raise QboldError(
             f"{LIB_PATH} not found: build it with `python -m qbold_vi_amd.build` "
             "(or __graft_entry__.build()); there is no fallback path")
+    # PyTorch ships its own HIP runtime (SONAME libamdhip64.so.7).  It must be the one already
+    # loaded when libqbold_hip.so's NEEDED entry is resolved, so that torch's streams and device
+    # pointers belong to the runtime the kernels are launched through.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
