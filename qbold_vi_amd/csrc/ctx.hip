@@ -153,6 +153,14 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
     const double h = xmax / QB_TAB_SEG;
     d.tab_inv_h = (float)(1.0 / h);
     d.tab_xmax = (float)(xmax * (1.0 - 1e-6));
+    d.tauh0 = ts * d.tab_inv_h;
+    d.tauh_step = tstep * d.tab_inv_h;
+    {
+        const double c2 = 4.0 * M_PI * P->b0 * P->dchi;
+        const double gk = 0.5 * P->gamma * P->gamma * (4.0 / 45.0) * P->hct * (1.0 - P->hct) * c2 * c2 *
+                          td * td;
+        d.ngk_l2e = (float)(-gk * 1.4426950408889634);
+    }
     static const Simpson simpson;
     d.dF_node0 = (float)simpson.node0_slope();
     std::vector<double> f(QB_TAB_SEG + 1), g(QB_TAB_SEG + 1);

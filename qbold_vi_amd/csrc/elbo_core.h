@@ -20,65 +20,54 @@ struct VoxelLik {
     float mask;
 };
 
-template <int T>
+// Normaliser of model.py:541-545: v[se] (or the mean of v[se-1..se+1]) + 1e-3.  SE >= 0 is a
+// compile-time spin-echo index; SE < 0 reads c.se_idx without dynamic register indexing.
+template <int T, int SE>
+__device__ __forceinline__ float se_norm(const QbDev& c, const float (&v)[T]) {
+    if (SE >= 0 && !c.multi_norm) return v[SE >= 0 ? SE : 0] + 1e-3f;
+    const int se = SE >= 0 ? SE : c.se_idx;
+    float a = 0.0f, b = 0.0f, d = 0.0f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        a = (t == se - 1) ? v[t] : a;
+        b = (t == se) ? v[t] : b;
+        d = (t == se + 1) ? v[t] : d;
+    }
+    return c.multi_norm ? (a + b + d) / 3.0f + 1e-3f : b + 1e-3f;
+}
+
+// LOGSIG: `sigma` holds log sigma (the encoder's pre-activation, model.py:211-214) instead of sigma.
+template <int T, int SE, bool LOGSIG>
 __device__ __forceinline__ void prepare_lik(const QbDev& c, const float (&x)[T],
                                             const float (&sigma)[T], float mask, VoxelLik<T>& k) {
-    const int se = c.se_idx;
-    float nt;
-    if (c.multi_norm) {
-        float a = 0.0f, b = 0.0f, d = 0.0f;  // runtime se_idx without dynamic register indexing
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            a = (t == se - 1) ? x[t] : a;
-            b = (t == se) ? x[t] : b;
-            d = (t == se + 1) ? x[t] : d;
-        }
-        nt = (a + b + d) / 3.0f + 1e-3f;  // model.py:541
-    } else {
-        float b = 0.0f;
-#pragma unroll
-        for (int t = 0; t < T; ++t) b = (t == se) ? x[t] : b;
-        nt = b + 1e-3f;  // model.py:544
-    }
+    const float inv_nt = rcpf_(se_norm<T, SE>(c, x));
     float ls = 0.0f;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        float y = x[t] / nt;
+        float y = x[t] * inv_nt;
         if (c.predict_log) y = mask > 0.0f ? __logf(y) : 0.0f;  // model.py:548
         k.yt[t] = y;
-        k.inv_s[t] = 1.0f / sigma[t];
-        ls += __logf(sigma[t]);
+        if (LOGSIG) {
+            k.inv_s[t] = exp2f_(-QB_LOG2E * sigma[t]);
+            ls += sigma[t];
+        } else {
+            k.inv_s[t] = rcpf_(sigma[t]);
+            ls += QB_LN2 * log2f_(sigma[t]);
+        }
     }
     k.log_s_sum = c.use_student_t ? ls : ls + (float)T * 0.9189385332046727f;  // log sqrt(2 pi)
     k.mask = mask;
 }
 
 // NLL of one reparameterised draw: forward model over the T taus, normalise, score.
-template <int T, bool LITERAL>
+template <int T, int SE, bool LITERAL>
 __device__ __forceinline__ float sample_nll(const FwdLds* L, const QbDev& c, const VoxelLik<T>& k,
                                             float oef, float dbv) {
     const FwdVox fv = fwd_vox(c, oef, dbv);
     float s[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) s[t] = fwd_signal<LITERAL>(L, c, fv, t);
-    const int se = c.se_idx;
-    float np_;
-    if (c.multi_norm) {
-        float a = 0.0f, b = 0.0f, d = 0.0f;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            a = (t == se - 1) ? s[t] : a;
-            b = (t == se) ? s[t] : b;
-            d = (t == se + 1) ? s[t] : d;
-        }
-        np_ = (a + b + d) / 3.0f + 1e-3f;  // model.py:542
-    } else {
-        float b = 0.0f;
-#pragma unroll
-        for (int t = 0; t < T; ++t) b = (t == se) ? s[t] : b;
-        np_ = b + 1e-3f;  // model.py:545
-    }
-    const float inv_np = 1.0f / np_;
+    const float inv_np = 1.0f / se_norm<T, SE>(c, s);  // model.py:542 / :545
     float acc = 0.0f;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -93,11 +82,50 @@ __device__ __forceinline__ float sample_nll(const FwdLds* L, const QbDev& c, con
     return acc + k.log_s_sum;  // model.py:563
 }
 
+// Fast path (full model, table mode, Gaussian likelihood on linear data): same arithmetic with the
+// per-draw constants folded (FwdFast) and the residual scored as sum r^2 (0.5 applied once).
+template <int T, int SE>
+__device__ __forceinline__ float sample_sq_fast(const FwdLds* L, const QbDev& c,
+                                                const VoxelLik<T>& k, float oef, float dbv) {
+    const FwdFast fv = fwd_fast(c, oef, dbv);
+    float s[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) s[t] = fwd_signal_fast(L, c, fv, t);
+    const float inv_np = rcpf_(se_norm<T, SE>(c, s));
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const float r = fmaf(-s[t], inv_np, k.yt[t]) * k.inv_s[t];
+        acc = fmaf(r, r, acc);
+    }
+    return acc;
+}
+
+// swr_p - swr_q of one draw: the only draw-dependent part of log q - log p (the Jacobian and the
+// log-determinants cancel or are constant per voxel).  Logits come from the clipped unit-interval
+// value exactly as logit_gaussian_mvg_log_prob forms them (model.py:393-396).
+__device__ __forceinline__ float kl_swr_diff(const LogitMvn& q, const LogitMvn& p, float z0,
+                                             float z1) {
+    float a, b, oef, dbv;
+    reparam_logits(q, z0, z1, a, b);
+    forward_transform(a, b, oef, dbv);
+    float x0 = clampf_((oef - QB_MIN_OEF) * 1.25f, 1e-6f, 1.0f - 1e-6f);
+    float x1 = clampf_((dbv - QB_MIN_DBV) * 5.0f, 1e-6f, 1.0f - 1e-6f);
+    const float l0 = QB_LN2 * log2f_(x0 * rcpf_(1.0f - x0));  // logit, model.py:10-12
+    const float l1 = QB_LN2 * log2f_(x1 * rcpf_(1.0f - x1));
+    const float rq0 = l0 - q.mu_o, rq1 = l1 - q.mu_d;
+    const float rp0 = l0 - p.mu_o, rp1 = l1 - p.mu_d;
+    const float wq0 = rq0 * q.i_so, wq1 = fmaf(rq1, q.i_sd, rq0 * q.i_bl);
+    const float wp0 = rp0 * p.i_so, wp1 = fmaf(rp1, p.i_sd, rp0 * p.i_bl);
+    return fmaf(wp0, wp0, wp1 * wp1) - fmaf(wq0, wq0, wq1 * wq1);
+}
+
 // The two Monte-Carlo sums of one voxel restricted to this lane's share of the draws.
 //   nll_sum = sum over this half's likelihood draws of the per-draw NLL
 //   kl_sum  = sum over this half's KL draws of log q(y) - log p(y)          model.py:596-603
 // zs / zk: explicit normals of this voxel ([S][2] / [K][2]) or nullptr for the Philox stream.
-template <int T, bool LITERAL>
+// FAST: requires c.full_model, table mode, !predict_log, !use_student_t (checked on the host).
+template <int T, int SE, bool FAST, bool LITERAL>
 __device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
                                               const VoxelLik<T>& lik, const LogitMvn& q,
                                               const LogitMvn& prior, int S, int K,
@@ -107,9 +135,11 @@ __device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
                                               float& kl_sum) {
     nll_sum = 0.0f;
     kl_sum = 0.0f;
+    int n_lik = 0, n_kl = 0;  // draws taken by this lane
     for (int j = half; 2 * j < S; j += 2) {
         float z[4];
         const bool two = 2 * j + 1 < S;
+        n_lik += two ? 2 : 1;
         if (zs) {
             z[0] = zs[4 * j];
             z[1] = zs[4 * j + 1];
@@ -118,19 +148,23 @@ __device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
         } else {
             normals4(seed, vox, (uint32_t)j, STREAM_LIK, z);
         }
-        float a, b, oef, dbv;
-        reparam_logits(q, z[0], z[1], a, b);
-        forward_transform(a, b, oef, dbv);
-        nll_sum += sample_nll<T, LITERAL>(L, c, lik, oef, dbv);
-        if (two) {
-            reparam_logits(q, z[2], z[3], a, b);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            if (d == 1 && !two) break;
+            float a, b, oef, dbv;
+            reparam_logits(q, z[2 * d], z[2 * d + 1], a, b);
             forward_transform(a, b, oef, dbv);
-            nll_sum += sample_nll<T, LITERAL>(L, c, lik, oef, dbv);
+            if (FAST) nll_sum += sample_sq_fast<T, SE>(L, c, lik, oef, dbv);
+            else nll_sum += sample_nll<T, SE, LITERAL>(L, c, lik, oef, dbv);
         }
+    }
+    if (FAST) {  // sum_d [0.5 sum_t r^2 + sum_t log sigma + T log sqrt(2 pi)] over this lane's draws
+        nll_sum = fmaf(0.5f, nll_sum, (float)n_lik * lik.log_s_sum);
     }
     for (int j = half; 2 * j < K; j += 2) {
         float z[4];
         const bool two = 2 * j + 1 < K;
+        n_kl += two ? 2 : 1;
         if (zk) {
             z[0] = zk[4 * j];
             z[1] = zk[4 * j + 1];
@@ -142,13 +176,20 @@ __device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
             if (d == 1 && !two) break;
-            float a, b, oef, dbv;
-            reparam_logits(q, z[2 * d], z[2 * d + 1], a, b);  // create_samples, model.py:318-324
-            forward_transform(a, b, oef, dbv);
-            const LogitObs o = make_obs(oef, dbv);
-            // log_q - log_p with log = -nlogp                 model.py:596-597, 603
-            kl_sum += nlogp(o, prior) - nlogp(o, q);
+            if (FAST) {
+                kl_sum += kl_swr_diff(q, prior, z[2 * d], z[2 * d + 1]);
+            } else {
+                float a, b, oef, dbv;
+                reparam_logits(q, z[2 * d], z[2 * d + 1], a, b);  // create_samples, model.py:318-324
+                forward_transform(a, b, oef, dbv);
+                const LogitObs o = make_obs(oef, dbv);
+                // log_q - log_p with log = -nlogp                 model.py:596-597, 603
+                kl_sum += nlogp(o, prior) - nlogp(o, q);
+            }
         }
+    }
+    if (FAST) {  // log q - log p = 0.5 (swr_p - swr_q) + (s_o + s_d)_p - (s_o + s_d)_q per draw
+        kl_sum = fmaf(0.5f, kl_sum, (float)n_kl * ((prior.s_o + prior.s_d) - (q.s_o + q.s_d)));
     }
 }
 

@@ -13,7 +13,7 @@ namespace {
 constexpr int kBlock = 256;              // 4 waves
 constexpr int kVoxPerBlock = kBlock / 2; // 32 voxels per wave, 2 lanes per voxel
 
-template <int T, bool LITERAL>
+template <int T, int SE, bool FAST, bool LITERAL>
 __global__ __launch_bounds__(kBlock) void elbo_fwd_kernel(
     QbDev c, const float4* __restrict__ g_tab, const float* __restrict__ x,
     const float* __restrict__ mask, const float* __restrict__ q, const float* __restrict__ prior,
@@ -45,10 +45,10 @@ __global__ __launch_bounds__(kBlock) void elbo_fwd_kernel(
             }
             const float m = mask ? mask[v] : 1.0f;
             qb::VoxelLik<T> lik;
-            qb::prepare_lik<T>(c, xv, sv, m, lik);
+            qb::prepare_lik<T, SE, false>(c, xv, sv, m, lik);
             const qb::LogitMvn qm = qb::make_mvn(qv), pm = qb::make_mvn(pv);
             float nll_part, kl_part;
-            qb::voxel_mc_sums<T, LITERAL>(&L, c, lik, qm, pm, S, K, zs ? zs + v * S * 2 : nullptr,
+            qb::voxel_mc_sums<T, SE, FAST, LITERAL>(&L, c, lik, qm, pm, S, K, zs ? zs + v * S * 2 : nullptr,
                                           zk ? zk + v * K * 2 : nullptr, seed,
                                           (uint64_t)(voxel0 + v), half, nll_part, kl_part);
             // partner lane (same voxel, other half of the draws); both lanes of a voxel are
@@ -170,6 +170,12 @@ int ew_grid(const qbold_ctx* ctx, int64_t N, int block) {
 
 namespace qb {
 int elbo_grid(const qbold_ctx* ctx) { return ctx->num_cus * 4; }
+// the folded-constant kernels cover the optimal.yaml configuration: full model from the table,
+// Gaussian likelihood on linear (not log) data
+bool elbo_fast_path(const qbold_ctx* ctx) {
+    const QbDev& d = ctx->dev;
+    return d.full_model && d.tissue_mode == QBOLD_TISSUE_TABLE && !d.predict_log && !d.use_student_t;
+}
 }
 
 extern "C" int64_t qbold_elbo_workspace_bytes(const qbold_ctx* ctx) {
@@ -191,19 +197,18 @@ extern "C" int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float*
     int grid = (int)(ntile < qb::elbo_grid(ctx) ? (ntile > 0 ? ntile : 1) : qb::elbo_grid(ctx));
     const bool lit = ctx->dev.tissue_mode == QBOLD_TISSUE_LITERAL;
     float2* out = reinterpret_cast<float2*>(nll_kl);
-#define QB_LAUNCH_ELBO(TT)                                                                       \
-    do {                                                                                         \
-        if (lit)                                                                                 \
-            hipLaunchKernelGGL((elbo_fwd_kernel<TT, true>), dim3(grid), dim3(kBlock), 0, s,      \
-                               ctx->dev, ctx->d_tab, x, mask, q, prior, sigma, zs, zk, S, K,     \
-                               seed, voxel0, out, partials, N);                                  \
-        else                                                                                     \
-            hipLaunchKernelGGL((elbo_fwd_kernel<TT, false>), dim3(grid), dim3(kBlock), 0, s,     \
-                               ctx->dev, ctx->d_tab, x, mask, q, prior, sigma, zs, zk, S, K,     \
-                               seed, voxel0, out, partials, N);                                  \
-    } while (0)
+#define QB_LAUNCH_ELBO(TT, SE, FAST, LIT)                                                        \
+    hipLaunchKernelGGL((elbo_fwd_kernel<TT, SE, FAST, LIT>), dim3(grid), dim3(kBlock), 0, s,      \
+                       ctx->dev, ctx->d_tab, x, mask, q, prior, sigma, zs, zk, S, K, seed, voxel0, \
+                       out, partials, N)
+    const bool fast = qb::elbo_fast_path(ctx);
     switch (ctx->dev.T) {
-        case 11: QB_LAUNCH_ELBO(11); break;
+        case 11:
+            if (fast && ctx->dev.se_idx == 2) QB_LAUNCH_ELBO(11, 2, true, false);
+            else if (fast) QB_LAUNCH_ELBO(11, -1, true, false);
+            else if (lit) QB_LAUNCH_ELBO(11, -1, false, true);
+            else QB_LAUNCH_ELBO(11, -1, false, false);
+            break;
         default:
             qb::set_error("qbold_elbo_fwd: kernels are built for T = 11 taus");
             return QBOLD_ERR_UNSUPPORTED;

@@ -31,6 +31,9 @@ struct QbDev {
     float tab_xmax;  // table covers |x| <= tab_xmax
     float dF_node0;  // slope of Simpson node 0 in dF/dx (see tissue_F)
     float st_df, st_const;  // Student-t df and log-normaliser          model.py:558
+    // fast (table) path: u_t = |tauh0 + t*tauh_step| * dw is the table coordinate of tau_t
+    float tauh0, tauh_step;  // tau_start * tab_inv_h, tau_step * tab_inv_h
+    float ngk_l2e;           // -log2(e) * 0.5 gamma^2 (4/45) hct (1-hct) (4 pi b0 dchi)^2 td^2
     float taus[QB_MAX_T];
     float blood_B[QB_MAX_T];  // bracket of signals.py:242-247 per tau
 };
@@ -40,14 +43,19 @@ namespace qb {
 // ---------------------------------------------------------------------------------------------
 // small math
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+#define QB_LOG2E 1.4426950408889634f
+#define QB_LN2 0.6931471805599453f
+__device__ __forceinline__ float rcpf_(float v) { return __builtin_amdgcn_rcpf(v); }      // 1 ulp
+__device__ __forceinline__ float exp2f_(float v) { return __builtin_amdgcn_exp2f(v); }    // v_exp_f32
+__device__ __forceinline__ float log2f_(float v) { return __builtin_amdgcn_logf(v); }     // v_log_f32
+__device__ __forceinline__ float sigmoidf_(float v) { return rcpf_(1.0f + exp2f_(-QB_LOG2E * v)); }
 __device__ __forceinline__ float clampf_(float v, float lo, float hi) {
     return fminf(fmaxf(v, lo), hi);
 }
 // tanh through one exp: tanh(p) = 1 - 2/(exp(2p)+1); |error| ~ 1e-7 abs, monotone, saturates.
 __device__ __forceinline__ float tanhf_(float p) {
-    float e = __expf(2.0f * p);
-    return 1.0f - 2.0f / (e + 1.0f);
+    float e = exp2f_((2.0f * QB_LOG2E) * p);
+    return 1.0f - 2.0f * rcpf_(e + 1.0f);
 }
 // transform_std / transform_offdiag -- model.py:288-294 = logit_mvn.py:91-97
 __device__ __forceinline__ float transform_std(float p) { return tanhf_(p) * 3.0f - 1.0f; }
@@ -104,8 +112,9 @@ struct LogitObs {
     float jac;     // sum log x + log(1-x)
 };
 __device__ __forceinline__ LogitObs make_obs(float oef, float dbv) {
-    float x0 = (oef - QB_MIN_OEF) / QB_OEF_RANGE;  // backwards_transform, model.py:307-311
-    float x1 = (dbv - QB_MIN_DBV) / QB_DBV_RANGE;
+    // backwards_transform, model.py:307-311 (divisions by 0.8 / 0.2 as multiplies by 1.25 / 5)
+    float x0 = (oef - QB_MIN_OEF) * 1.25f;
+    float x1 = (dbv - QB_MIN_DBV) * 5.0f;
     x0 = clampf_(x0, 1e-6f, 1.0f - 1e-6f);         // model.py:394-395
     x1 = clampf_(x1, 1e-6f, 1.0f - 1e-6f);
     float lx0 = __logf(x0), l1x0 = __logf(1.0f - x0);
@@ -144,11 +153,10 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
     float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
     float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    float r = sqrtf(-2.0f * logf(u1));
-    float s, c;
-    sincospif(2.0f * u2, &s, &c);
-    z0 = r * c;
-    z1 = r * s;
+    // r = sqrt(-2 ln u1) via v_log_f32 (log2) and v_sqrt_f32; v_sin/v_cos take revolutions
+    float r = __builtin_amdgcn_sqrtf((-2.0f * QB_LN2) * log2f_(u1));
+    z0 = r * __builtin_amdgcn_cosf(u2);
+    z1 = r * __builtin_amdgcn_sinf(u2);
 }
 
 enum { STREAM_LIK = 0, STREAM_KL = 1, STREAM_MOMENTS = 2 };
@@ -358,6 +366,40 @@ __device__ __forceinline__ float fwd_signal(const FwdLds* L, const QbDev& c, con
     }
     float blood = c.include_blood ? c.e_r2b_te * __expf(-v.g * c.blood_B[t]) : 0.0f;
     return v.tw * tissue + v.bw * blood;
+}
+
+// Fast path of the same model (full model, table mode, inputs from forward_transform so that
+// 0.04 <= OEF <= 0.84 and 0.001 <= DBV <= 0.201): the table coordinate is a single FMA per tau,
+// constants are folded once per draw, exponentials go straight to v_exp_f32.
+struct FwdFast {
+    float ua, ub;   // u_t = |ua + t * ub|
+    float nd;       // -dbv * log2(e)
+    float tissue_w; // (1 - bw) * exp(-te r2t)
+    float blood_w;  // bw * exp(-r2b te)           (0 without blood)
+    float ng;       // -g * log2(e)
+};
+__device__ __forceinline__ FwdFast fwd_fast(const QbDev& c, float oef, float dbv) {
+    FwdFast v;
+    const float dw = c.dw_coef * oef;
+    v.ua = c.tauh0 * dw;
+    v.ub = c.tauh_step * dw;
+    v.nd = -QB_LOG2E * dbv;
+    const float bw = c.include_blood ? c.m_bld_nb * dbv : dbv;
+    v.tissue_w = (1.0f - bw) * c.e_te_r2t;
+    v.blood_w = c.include_blood ? bw * c.e_r2b_te : 0.0f;
+    v.ng = c.ngk_l2e * (oef * oef);
+    return v;
+}
+__device__ __forceinline__ float fwd_signal_fast(const FwdLds* L, const QbDev& c, const FwdFast& v,
+                                                 int t) {
+    const float u = fabsf(fmaf((float)t, v.ub, v.ua));
+    const int i = min((int)u, QB_TAB_SEG - 1);
+    const float f = u - (float)i;
+    const float4 k = L->tab[i];
+    const float F = fmaf(fmaf(fmaf(k.w, f, k.z), f, k.y), f, k.x);
+    const float e1 = exp2f_(v.nd * F);
+    const float e2 = exp2f_(v.ng * c.blood_B[t]);
+    return fmaf(v.tissue_w, e1, v.blood_w * e2);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -21,6 +21,7 @@
 
 namespace qb {
 int check_encoder_shape(const qbold_ctx* ctx, const qbold_encoder_shape* s);
+bool elbo_fast_path(const qbold_ctx* ctx);
 }
 
 namespace {
@@ -31,7 +32,7 @@ using qb::f32x16;
 constexpr int kBlock = 512;
 constexpr int kWaves = kBlock / 64;
 
-template <int T, bool LITERAL>
+template <int T, int SE, bool FAST, bool LITERAL>
 __global__ __launch_bounds__(kBlock, 2) void vi_fwd_kernel(
     QbDev c, EncLayout e, const float4* __restrict__ g_tab, const float* __restrict__ packed,
     const float* __restrict__ x, const float* __restrict__ mask, const float* __restrict__ prior,
@@ -75,13 +76,13 @@ __global__ __launch_bounds__(kBlock, 2) void vi_fwd_kernel(
                 pv[k] = prior[v * 5 + k];
             }
 #pragma unroll
-            for (int t = 0; t < T; ++t) sv[t] = __expf(o[5 + t]);  // model.py:214
+            for (int t = 0; t < T; ++t) sv[t] = o[5 + t];  // log sigma; sigma = exp(.), model.py:214
             const float m = mask ? mask[v] : 1.0f;
             qb::VoxelLik<T> lik;
-            qb::prepare_lik<T>(c, xv, sv, m, lik);
+            qb::prepare_lik<T, SE, true>(c, xv, sv, m, lik);
             const qb::LogitMvn qm = qb::make_mvn(qv), pm = qb::make_mvn(pv);
             float nll_part, kl_part;
-            qb::voxel_mc_sums<T, LITERAL>(L, c, lik, qm, pm, S, K, nullptr, nullptr, seed,
+            qb::voxel_mc_sums<T, SE, FAST, LITERAL>(L, c, lik, qm, pm, S, K, nullptr, nullptr, seed,
                                           (uint64_t)(voxel0 + v), h, nll_part, kl_part);
             const float nll = (nll_part + __shfl_xor(nll_part, 32, 64)) / (float)S;
             const float kl = K > 0 ? (kl_part + __shfl_xor(kl_part, 32, 64)) / (float)K : 0.0f;
@@ -121,18 +122,21 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     const int grid = (int)(nblk < ctx->num_cus ? (nblk > 0 ? nblk : 1) : ctx->num_cus);
     const bool lit = ctx->dev.tissue_mode == QBOLD_TISSUE_LITERAL;
     float2* out = reinterpret_cast<float2*>(nll_kl);
-#define QB_LAUNCH_VI(TT, LIT)                                                                     \
+#define QB_LAUNCH_VI(TT, SE, FAST, LIT)                                                           \
     do {                                                                                          \
-        auto k = vi_fwd_kernel<TT, LIT>;                                                          \
+        auto k = vi_fwd_kernel<TT, SE, FAST, LIT>;                                                \
         QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                              \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));       \
         hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), smem, s, ctx->dev, e, ctx->d_tab, packed, \
                            x, mask, prior, S, K, seed, voxel0, q_out, out, partials, N);          \
     } while (0)
+    const bool fast = qb::elbo_fast_path(ctx);
     switch (shape->T) {
         case 11:
-            if (lit) QB_LAUNCH_VI(11, true);
-            else QB_LAUNCH_VI(11, false);
+            if (fast && ctx->dev.se_idx == 2) QB_LAUNCH_VI(11, 2, true, false);
+            else if (fast) QB_LAUNCH_VI(11, -1, true, false);
+            else if (lit) QB_LAUNCH_VI(11, -1, false, true);
+            else QB_LAUNCH_VI(11, -1, false, false);
             break;
         default:
             qb::set_error("qbold_vi_fwd: kernels are built for T = 11 taus");
