@@ -2,6 +2,7 @@
 // SignalGenerationLayer.__init__ / calc_blood do (signals.py:18-53, 233-247), builds the tau grid
 // (signals.py:34-35) and the cubic-Hermite table of the tissue integral (signals.py:159-185).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -110,6 +111,7 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
         return QBOLD_ERR_INVALID;
     }
     d.tissue_mode = QBOLD_TISSUE_TABLE;
+    if (const char* dbg = getenv("QBOLD_DEBUG_SKIP")) d.debug_skip = atoi(dbg);
 
     d.dw_coef = (float)((4.0 / 3.0) * M_PI * P->gamma * P->b0 * P->dchi * P->hct);
     d.e_te_r2t = expf((float)(-P->te * P->r2t));

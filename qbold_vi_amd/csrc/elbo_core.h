@@ -1,15 +1,25 @@
 // elbo_core.h -- per-voxel Monte-Carlo ELBO terms, shared by the stand-alone ELBO kernel
 // (elbo_kernels.hip) and the fused encoder+ELBO kernel (vi_kernels.hip).
 //
-// A wave owns 32 voxels; lanes l and l+32 share voxel (l & 31) and split its Monte-Carlo draws by
-// Philox pair index (pair j -> draws 2j, 2j+1; pair j belongs to half j & 1).  Everything a lane
-// needs per voxel lives in registers: T normalised data points, T inverse sigmas, the transformed
-// posterior / prior parameters.
+// A wave owns 16 voxels; the four lanes l, l+16, l+32, l+48 share voxel (l & 15) and split its
+// Monte-Carlo draws by Philox pair index (pair j -> draws 2j, 2j+1; pair j belongs to lane group
+// j & 3).  Everything a lane needs per voxel lives in registers: T normalised data points, T
+// inverse sigmas, the transformed posterior / prior parameters.
 #pragma once
 
 #include "qbold_dev.h"
 
 namespace qb {
+
+#define QB_LANES_PER_VOXEL 4
+#define QB_VOX_PER_WAVE 16
+
+// sum over the four lanes of a voxel (lane groups 16 apart)
+__device__ __forceinline__ float voxel_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
 
 // Likelihood side of one voxel, prepared once -- fine_tune_loss_fn, model.py:527-568.
 template <int T>
@@ -88,11 +98,24 @@ template <int T, int SE>
 __device__ __forceinline__ float sample_sq_fast(const FwdLds* L, const QbDev& c,
                                                 const VoxelLik<T>& k, float oef, float dbv) {
     const FwdFast fv = fwd_fast(c, oef, dbv);
+    float acc = 0.0f;
+    if (SE >= 0 && !c.multi_norm) {
+        // spin-echo signal first, then each tau's residual as soon as its signal exists: no
+        // T-element signal array is kept live
+        const float s_se = fwd_signal_fast(L, c, fv, SE >= 0 ? SE : 0);
+        const float inv_np = rcpf_(s_se + 1e-3f);  // model.py:545
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float st = (t == SE) ? s_se : fwd_signal_fast(L, c, fv, t);
+            const float r = fmaf(-st, inv_np, k.yt[t]) * k.inv_s[t];
+            acc = fmaf(r, r, acc);
+        }
+        return acc;
+    }
     float s[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) s[t] = fwd_signal_fast(L, c, fv, t);
     const float inv_np = rcpf_(se_norm<T, SE>(c, s));
-    float acc = 0.0f;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const float r = fmaf(-s[t], inv_np, k.yt[t]) * k.inv_s[t];
@@ -131,12 +154,12 @@ __device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
                                               const LogitMvn& prior, int S, int K,
                                               const float* __restrict__ zs,
                                               const float* __restrict__ zk, uint64_t seed,
-                                              uint64_t vox, int half, float& nll_sum,
+                                              uint64_t vox, int part, float& nll_sum,
                                               float& kl_sum) {
     nll_sum = 0.0f;
     kl_sum = 0.0f;
     int n_lik = 0, n_kl = 0;  // draws taken by this lane
-    for (int j = half; 2 * j < S; j += 2) {
+    for (int j = part; 2 * j < S; j += QB_LANES_PER_VOXEL) {
         float z[4];
         const bool two = 2 * j + 1 < S;
         n_lik += two ? 2 : 1;
@@ -161,7 +184,7 @@ __device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
     if (FAST) {  // sum_d [0.5 sum_t r^2 + sum_t log sigma + T log sqrt(2 pi)] over this lane's draws
         nll_sum = fmaf(0.5f, nll_sum, (float)n_lik * lik.log_s_sum);
     }
-    for (int j = half; 2 * j < K; j += 2) {
+    for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
         float z[4];
         const bool two = 2 * j + 1 < K;
         n_kl += two ? 2 : 1;

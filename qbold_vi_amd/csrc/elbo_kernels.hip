@@ -11,7 +11,7 @@
 namespace {
 
 constexpr int kBlock = 256;              // 4 waves
-constexpr int kVoxPerBlock = kBlock / 2; // 32 voxels per wave, 2 lanes per voxel
+constexpr int kVoxPerBlock = kBlock / QB_LANES_PER_VOXEL;  // 16 voxels per wave, 4 lanes each
 
 template <int T, int SE, bool FAST, bool LITERAL>
 __global__ __launch_bounds__(kBlock) void elbo_fwd_kernel(
@@ -26,11 +26,11 @@ __global__ __launch_bounds__(kBlock) void elbo_fwd_kernel(
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = lane >> 5;
+    const int part = lane >> 4;
     float s_nll = 0.0f, s_kl = 0.0f, s_m = 0.0f;
     const int64_t ntile = (N + kVoxPerBlock - 1) / kVoxPerBlock;
     for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        const int64_t v = tile * kVoxPerBlock + wave * 32 + (lane & 31);
+        const int64_t v = tile * kVoxPerBlock + wave * QB_VOX_PER_WAVE + (lane & 15);
         if (v < N) {
             float xv[T], sv[T], qv[5], pv[5];
 #pragma unroll
@@ -50,12 +50,11 @@ __global__ __launch_bounds__(kBlock) void elbo_fwd_kernel(
             float nll_part, kl_part;
             qb::voxel_mc_sums<T, SE, FAST, LITERAL>(&L, c, lik, qm, pm, S, K, zs ? zs + v * S * 2 : nullptr,
                                           zk ? zk + v * K * 2 : nullptr, seed,
-                                          (uint64_t)(voxel0 + v), half, nll_part, kl_part);
-            // partner lane (same voxel, other half of the draws); both lanes of a voxel are
-            // active together because v depends on lane & 31 only
-            const float nll = (nll_part + __shfl_xor(nll_part, 32, 64)) / (float)S;
-            const float kl = K > 0 ? (kl_part + __shfl_xor(kl_part, 32, 64)) / (float)K : 0.0f;
-            if (half == 0) {
+                                          (uint64_t)(voxel0 + v), part, nll_part, kl_part);
+            // the four lanes of a voxel are active together (v depends on lane & 15 only)
+            const float nll = qb::voxel_sum(nll_part) / (float)S;
+            const float kl = K > 0 ? qb::voxel_sum(kl_part) / (float)K : 0.0f;
+            if (part == 0) {
                 if (nll_kl) nll_kl[v] = make_float2(nll, kl);
                 s_nll += nll * m;               // model.py:564
                 s_kl += m > 0.0f ? kl : 0.0f;   // model.py:661

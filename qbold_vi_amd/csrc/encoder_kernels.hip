@@ -48,7 +48,7 @@ __host__ __device__ inline CanonLayout make_canon(int T, int U, int L, int cw) {
 namespace {
 
 using qb::EncLayout;
-using qb::f32x16;
+using qb::f32x4;
 
 // value of W[in][out] of a canonical [nin][nout] matrix, zero outside
 __device__ __forceinline__ float wval(const float* W, int nin, int nout, int in, int out) {
@@ -60,12 +60,12 @@ __global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset,
     const int U = c.U, T = c.T, G = c.G;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < e.total; p += gridDim.x * blockDim.x) {
         float v = 0.0f;
-        if (p < e.first_b) {  // first-layer A: [s][h][i][m]
-            const int m = p & 1, i = (p >> 1) & 31, h = (p >> 6) & 1, s = p >> 7;
-            v = wval(w + c.W0, T, U, 2 * s + h, 32 * m + i);
-        } else if (p < e.blk0) {  // first-layer bias [m][h][r]
-            const int q = p - e.first_b, r = q & 15, h = (q >> 4) & 1, m = q >> 5;
-            const int u = qb::acc_unit(m, r, h);
+        if (p < e.first_b) {  // first-layer A: [s][g][i][m]
+            const int m = p & 3, i = (p >> 2) & 15, g = (p >> 6) & 3, s = p >> 8;
+            v = wval(w + c.W0, T, U, 4 * s + g, 16 * m + i);
+        } else if (p < e.blk0) {  // first-layer bias [m][g][r]
+            const int q = p - e.first_b, r = q & 3, g = (q >> 2) & 3, m = q >> 4;
+            const int u = qb::acc_unit(m, r, g);
             v = u < U ? w[c.b0 + u] : 0.0f;
         } else if (p < e.head_A) {
             const int q = p - e.blk0, l = q / qb::BLK_FLOATS, o = q % qb::BLK_FLOATS;
@@ -74,28 +74,30 @@ __global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset,
             const int Aoff = piece == 0 ? c.Wc : piece == 1 ? c.Wr1 : piece == 2 ? c.Wr2 : c.Wg;
             const int boff = piece == 0 ? c.bc : piece == 1 ? c.br1 : piece == 2 ? c.br2 : c.bg;
             const int nout = piece == 3 ? G : U;
-            if (oo < 4096) {  // A: [kstep = m_in*16 + r][h][i][m_out]
-                const int m = oo & 1, i = (oo >> 1) & 31, h = (oo >> 6) & 1, ks = oo >> 7;
-                const int in = qb::acc_unit(ks >> 4, ks & 15, h);
-                int out = 32 * m + i;
+            if (oo < 4096) {  // A: [kstep = m_in*4 + r][g][i][m_out]
+                const int m = oo & 3, i = (oo >> 2) & 15, g = (oo >> 6) & 3, ks = oo >> 8;
+                const int in = qb::acc_unit(ks >> 2, ks & 3, g);
+                int out = 16 * m + i;
                 if (piece == 3 && G == 1) out = out < U ? 0 : U;  // shared gate broadcast to all units
                 v = wval(wb + Aoff, U, nout, in, out);
             } else {
-                const int qq = oo - 4096, r = qq & 15, h = (qq >> 4) & 1, m = qq >> 5;
-                const int u = qb::acc_unit(m, r, h);
+                const int qq = oo - 4096, r = qq & 3, g = (qq >> 2) & 3, m = qq >> 4;
+                const int u = qb::acc_unit(m, r, g);
                 if (u < U) {
                     v = wb[boff + ((piece == 3 && G == 1) ? 0 : u)];
                     if (piece == 3) v += gate_offset;
                 }
             }
-        } else if (p < e.head_b) {  // head A: [kstep][h][i], rows: 0-4 = Wf, 5.. = Ws
-            const int q = p - e.head_A, i = q & 31, h = (q >> 5) & 1, ks = q >> 6;
-            const int in = qb::acc_unit(ks >> 4, ks & 15, h);
-            if (i < 5) v = wval(w + c.Wf, U, 5, in, i);
-            else if (i < 5 + T) v = wval(w + c.Ws, U, T, in, i - 5);
-        } else if (p < e.head_b + 32) {  // head bias [h][r]
-            const int q = p - e.head_b, r = q & 15, h = q >> 4;
-            const int row = qb::acc_unit(0, r, h);
+        } else if (p < e.head_b) {  // head A: [kstep][g][i][mh], rows: 0-4 = Wf, 5.. = Ws
+            const int q = p - e.head_A, HT = e.head_tiles;
+            const int mh = q % HT, qq = q / HT, i = qq & 15, g = (qq >> 4) & 3, ks = qq >> 6;
+            const int in = qb::acc_unit(ks >> 2, ks & 3, g);
+            const int row = 16 * mh + i;
+            if (row < 5) v = wval(w + c.Wf, U, 5, in, row);
+            else if (row < 5 + T) v = wval(w + c.Ws, U, T, in, row - 5);
+        } else if (p < e.head_b + 16 * e.head_tiles) {  // head bias [mh][g][r]
+            const int q = p - e.head_b, r = q & 3, g = (q >> 2) & 3, mh = q >> 4;
+            const int row = qb::acc_unit(mh, r, g);
             if (row < 5) v = w[c.bf + row];
             else if (row < 5 + T) v = w[c.bs + row - 5];
         }
@@ -103,10 +105,10 @@ __global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset,
     }
 }
 
-constexpr int kEncBlock = 512;
+constexpr int kEncBlock = 1024;
 
 template <int T>
-__global__ __launch_bounds__(kEncBlock, 2) void encoder_fwd_kernel(
+__global__ __launch_bounds__(kEncBlock) void encoder_fwd_kernel(
     QbDev c, EncLayout e, const float* __restrict__ packed, const float* __restrict__ x,
     float* __restrict__ out1, float* __restrict__ out2, float* __restrict__ sigma, int64_t N) {
     extern __shared__ __align__(16) float lds_w[];
@@ -114,42 +116,45 @@ __global__ __launch_bounds__(kEncBlock, 2) void encoder_fwd_kernel(
         reinterpret_cast<float4*>(lds_w)[p] = reinterpret_cast<const float4*>(packed)[p];
     __syncthreads();
 
+    constexpr int HT = (5 + T + 15) / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int h = lane >> 5, i = lane & 31;
+    const int g = lane >> 4, i = lane & 15;
     constexpr int NW = kEncBlock / 64;
-    const int64_t ntile = (N + 31) / 32;
+    const int64_t ntile = (N + 15) / 16;
     for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntile; tile += (int64_t)gridDim.x * NW) {
-        const int64_t v = tile * 32 + i;
+        const int64_t v = tile * 16 + i;
         const int64_t vc = v < N ? v : N - 1;  // clamp: every lane takes part in the MFMAs
         float xv[T], nv[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) xv[t] = x[vc * T + t];
         qb::normalise<T>(c, xv, nv);
-        f32x16 a[2];
-        qb::dense_first<T>(lds_w + e.first_A, lds_w + e.first_b, nv, a, h, i);
+        f32x4 a[4];
+        qb::dense_first<T>(lds_w + e.first_A, lds_w + e.first_b, nv, a, g, i);
         if (out2 || sigma) {
-            f32x16 b[2] = {a[0], a[1]};  // net2 = net1, model.py:185
-            for (int l = 0; l < e.L; ++l) qb::block_stream2(lds_w + e.blk0 + l * e.blk_stride, b, h, i);
-            const f32x16 hd = qb::dense_head(lds_w + e.head_A, lds_w + e.head_b, b, h, i);
+            f32x4 b[4] = {a[0], a[1], a[2], a[3]};  // net2 = net1, model.py:185
+            for (int l = 0; l < e.L; ++l) qb::block_stream2(lds_w + e.blk0 + l * e.blk_stride, b, g, i);
+            f32x4 hd[HT];
+            qb::dense_head<HT>(lds_w + e.head_A, lds_w + e.head_b, b, hd, g, i);
             float o[5 + T];
-            qb::gather_head<5 + T>(hd, o);
+            qb::gather_head<5 + T, HT>(hd, o);
             if (v < N) {
-                if (out2 && h == 0) {
+                if (out2 && g == 0) {
 #pragma unroll
                     for (int k = 0; k < 5; ++k) out2[v * 5 + k] = o[k];
                 }
-                if (sigma && h == 1) {
+                if (sigma && g == 1) {
 #pragma unroll
                     for (int t = 0; t < T; ++t) sigma[v * T + t] = __expf(o[5 + t]);  // model.py:214
                 }
             }
         }
         if (out1) {
-            for (int l = 0; l < e.L; ++l) qb::block_stream1(lds_w + e.blk0 + l * e.blk_stride, a, h, i);
-            const f32x16 hd = qb::dense_head(lds_w + e.head_A, lds_w + e.head_b, a, h, i);
+            for (int l = 0; l < e.L; ++l) qb::block_stream1(lds_w + e.blk0 + l * e.blk_stride, a, g, i);
+            f32x4 hd[HT];
+            qb::dense_head<HT>(lds_w + e.head_A, lds_w + e.head_b, a, hd, g, i);
             float o[5];
-            qb::gather_head<5>(hd, o);
-            if (v < N && h == 0) {
+            qb::gather_head<5, 1>(reinterpret_cast<f32x4(&)[1]>(hd[0]), o);
+            if (v < N && g == 2) {
 #pragma unroll
                 for (int k = 0; k < 5; ++k) out1[v * 5 + k] = o[k];
             }
@@ -206,7 +211,7 @@ extern "C" int qbold_encoder_fwd(const qbold_ctx* ctx, const qbold_encoder_shape
     QB_REQUIRE(packed && x, "qbold_encoder_fwd: null buffer");
     const EncLayout e = qb::make_enc_layout(shape->T, shape->U, shape->L);
     const size_t smem = sizeof(float) * e.total;
-    const int64_t ntile = (N + 31) / 32;
+    const int64_t ntile = (N + 15) / 16;
     const int64_t nblk = (ntile + kEncBlock / 64 - 1) / (kEncBlock / 64);
     const int grid = (int)(nblk < ctx->num_cus ? nblk : ctx->num_cus);
     switch (shape->T) {

@@ -18,6 +18,7 @@
 struct QbDev {
     int T, se_idx, full_model, include_blood;
     int multi_norm, predict_log, use_student_t, tissue_mode;
+    int debug_skip;  // diagnostics only (env QBOLD_DEBUG_SKIP): 1 = no encoder MFMA, 2 = no sampling
     float dw_coef;   // (4/3) pi gamma b0 dchi hct                      signals.py:144
     float e_te_r2t;  // exp(-te*r2t)                                    signals.py:172
     float r2t_te;    // -r2t*te                                         signals.py:204

@@ -12,9 +12,11 @@
 // 60.8 kFLOP of MFMA + ~25 kFLOP-equivalent of VALU/transcendental at S=32, K=70: compute-bound
 // (arithmetic intensity ~900 flop/B against a machine balance of ~20 flop/B).
 //
-// One 512-thread workgroup per CU (the weight image takes ~145 KB of the 160 KB LDS); the two
-// waves per SIMD run the same program, so while one is in its VALU sampling phase the other can
-// own the SIMD's matrix pipe.
+// One 1024-thread workgroup per CU (the weight image takes ~145 KB of the 160 KB LDS).  With
+// 16-voxel tiles on v_mfma_f32_16x16x4_f32 the kernel fits 128 VGPRs, so four waves share each
+// SIMD: while some are in their VALU sampling phase others own the SIMD's matrix pipe, and the
+// LDS-table / transcendental latencies of the sampling phase are covered by thread-level
+// parallelism.
 #include "elbo_core.h"
 #include "encoder_core.h"
 #include "qbold_ctx.h"
@@ -27,13 +29,13 @@ bool elbo_fast_path(const qbold_ctx* ctx);
 namespace {
 
 using qb::EncLayout;
-using qb::f32x16;
+using qb::f32x4;
 
-constexpr int kBlock = 512;
+constexpr int kBlock = 1024;
 constexpr int kWaves = kBlock / 64;
 
 template <int T, int SE, bool FAST, bool LITERAL>
-__global__ __launch_bounds__(kBlock, 2) void vi_fwd_kernel(
+__global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
     QbDev c, EncLayout e, const float4* __restrict__ g_tab, const float* __restrict__ packed,
     const float* __restrict__ x, const float* __restrict__ mask, const float* __restrict__ prior,
     int S, int K, uint64_t seed, int64_t voxel0, float* __restrict__ q_out,
@@ -47,29 +49,37 @@ __global__ __launch_bounds__(kBlock, 2) void vi_fwd_kernel(
     qb::fwd_lds_fill(L, g_tab, true);
     __syncthreads();
 
+    constexpr int HT = (5 + T + 15) / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int h = lane >> 5, i = lane & 31;
+    const int g = lane >> 4, i = lane & 15;
     float s_nll = 0.0f, s_kl = 0.0f, s_m = 0.0f;
-    const int64_t ntile = (N + 31) / 32;
+    const int64_t ntile = (N + 15) / 16;
     for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntile;
          tile += (int64_t)gridDim.x * kWaves) {
-        const int64_t v = tile * 32 + i;
+        const int64_t v = tile * 16 + i;
         const int64_t vc = v < N ? v : N - 1;
-        float xv[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) xv[t] = x[vc * T + t];
         float o[5 + T];
         {
-            float nv[T];
+            float xv[T], nv[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) xv[t] = x[vc * T + t];
             qb::normalise<T>(c, xv, nv);
-            f32x16 b[2];
-            qb::dense_first<T>(lds_w + e.first_A, lds_w + e.first_b, nv, b, h, i);
-            for (int l = 0; l < e.L; ++l) qb::block_stream2(lds_w + e.blk0 + l * e.blk_stride, b, h, i);
-            const f32x16 hd = qb::dense_head(lds_w + e.head_A, lds_w + e.head_b, b, h, i);
-            qb::gather_head<5 + T>(hd, o);
+            f32x4 b[4];
+            qb::dense_first<T>(lds_w + e.first_A, lds_w + e.first_b, nv, b, g, i);
+            if (!(c.debug_skip & 1))
+                for (int l = 0; l < e.L; ++l) qb::block_stream2(lds_w + e.blk0 + l * e.blk_stride, b, g, i);
+            f32x4 hd[HT];
+            qb::dense_head<HT>(lds_w + e.head_A, lds_w + e.head_b, b, hd, g, i);
+            qb::gather_head<5 + T, HT>(hd, o);
         }
-        if (v < N) {
-            float sv[T], qv[5], pv[5];
+        if (v < N && !(c.debug_skip & 2)) {
+            // x is read again (an L1/L2 hit) rather than held in 11 VGPRs across the encoder; the
+            // empty asm keeps the compiler from merging the two reads
+            const float* xr = x + v * T;
+            asm volatile("" : "+v"(xr));
+            float xv[T], sv[T], qv[5], pv[5];
+#pragma unroll
+            for (int t = 0; t < T; ++t) xv[t] = xr[t];
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 qv[k] = o[k];
@@ -83,15 +93,15 @@ __global__ __launch_bounds__(kBlock, 2) void vi_fwd_kernel(
             const qb::LogitMvn qm = qb::make_mvn(qv), pm = qb::make_mvn(pv);
             float nll_part, kl_part;
             qb::voxel_mc_sums<T, SE, FAST, LITERAL>(L, c, lik, qm, pm, S, K, nullptr, nullptr, seed,
-                                          (uint64_t)(voxel0 + v), h, nll_part, kl_part);
-            const float nll = (nll_part + __shfl_xor(nll_part, 32, 64)) / (float)S;
-            const float kl = K > 0 ? (kl_part + __shfl_xor(kl_part, 32, 64)) / (float)K : 0.0f;
-            if (h == 0) {
+                                                    (uint64_t)(voxel0 + v), g, nll_part, kl_part);
+            const float nll = qb::voxel_sum(nll_part) / (float)S;
+            const float kl = K > 0 ? qb::voxel_sum(kl_part) / (float)K : 0.0f;
+            if (g == 0) {
                 if (nll_kl) nll_kl[v] = make_float2(nll, kl);
                 s_nll += nll * m;              // model.py:564
                 s_kl += m > 0.0f ? kl : 0.0f;  // model.py:661
                 s_m += m;
-            } else if (q_out) {
+            } else if (g == 1 && q_out) {
 #pragma unroll
                 for (int k = 0; k < 5; ++k) q_out[v * 5 + k] = qv[k];
             }
@@ -117,7 +127,7 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     const size_t smem = sizeof(float) * e.total + sizeof(qb::FwdLds) + sizeof(double) * 3 * kWaves;
     hipStream_t s = (hipStream_t)stream;
     double* partials = reinterpret_cast<double*>(workspace);
-    const int64_t ntile = (N + 31) / 32;
+    const int64_t ntile = (N + 15) / 16;
     const int64_t nblk = (ntile + kWaves - 1) / kWaves;
     const int grid = (int)(nblk < ctx->num_cus ? (nblk > 0 ? nblk : 1) : ctx->num_cus);
     const bool lit = ctx->dev.tissue_mode == QBOLD_TISSUE_LITERAL;
