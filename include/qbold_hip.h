@@ -137,6 +137,50 @@ int qbold_posterior_moments(const qbold_ctx* ctx, const float* q, const float* z
                             uint64_t seed, int64_t voxel0, float* means, float* vars, int64_t N,
                             void* stream);
 
+/* EncoderTrainer.normalise_data (model.py:97-113): x [N][T] -> log(clip(x)/clip(x)[se]) [N][T]. */
+int qbold_normalise(const qbold_ctx* ctx, const float* x, float* out, int64_t N, void* stream);
+
+/* Element-wise parameter transforms of EncoderTrainer / LogitMVN (model.py:288-316 =
+ * logit_mvn.py:72-100).  The FORWARD/BACKWARDS ops act on interleaved (OEF, DBV) pairs. */
+typedef enum {
+    QBOLD_TRANSFORM_STD = 0,            /* tanh(x)*3 - 1                     model.py:288-290 */
+    QBOLD_TRANSFORM_OFFDIAG = 1,        /* tanh(x)*exp(-2)                   model.py:292-294 */
+    QBOLD_INV_TRANSFORM_STD = 2,        /* atanh((x+1)/3)                    model.py:296-297 */
+    QBOLD_FORWARD_TRANSFORM = 3,        /* sigmoid * range + min             model.py:299-305 */
+    QBOLD_BACKWARDS_TRANSFORM = 4,      /* (y - min) / range                 model.py:307-311 */
+    QBOLD_BACKWARDS_TRANSFORM_LOGIT = 5 /* ... followed by logit             model.py:312-314 */
+} qbold_transform_op;
+int qbold_transform(const qbold_ctx* ctx, int op, const float* in, float* out, int64_t n,
+                    void* stream);
+
+/* fine_tune_loss_fn(return_mean=False) before the mask multiply (model.py:527-563): data x [N][T],
+ * mask [N] or NULL, predicted signals pred [N*S][T] and sigma [N*S][T] (row j belongs to voxel
+ * j % N, the reference's S-fold batch tiling, model.py:529) -> nll [N*S]. */
+int qbold_nll_fwd(const qbold_ctx* ctx, const float* x, const float* mask, const float* pred,
+                  const float* sigma, float* nll, int64_t N, int S, void* stream);
+
+/* mvg_kl_samples (model.py:592-610) per voxel: q, prior [N][5]; zk explicit normals [N][K][2] or
+ * NULL for the Philox KL stream (seed, voxel0 + i) -> kl [N]. */
+int qbold_kl_fwd(const qbold_ctx* ctx, const float* q, const float* prior, const float* zk, int K,
+                 uint64_t seed, int64_t voxel0, float* kl, int64_t N, void* stream);
+/* mvg_kl closed form, use_population_prior = False (model.py:612-652) -> kl [N]. */
+int qbold_kl_closed(const qbold_ctx* ctx, const float* q, const float* prior, float* kl, int64_t N,
+                    void* stream);
+
+/* The counter-based normal stream the fused kernels consume: z [N][n][2] for global voxels
+ * voxel0 .. voxel0+N-1; stream_id 0 = likelihood draws, 1 = KL draws, 2 = moments, 3 = noise.
+ * Replaces tf.random.normal at model.py:25 with a reproducible, sharding-invariant generator
+ * (Random123 Philox4x32-10 + Box-Muller). */
+int qbold_normals(const qbold_ctx* ctx, uint64_t seed, uint32_t stream_id, int64_t voxel0, int n,
+                  float* z, int64_t N, void* stream);
+
+/* Noise model of SignalGenerationLayer.call (signals.py:116-128), in place on signal [V][T]:
+ * std[v][t] = mean_v(signal[.][t]) / (U(snr_lo, snr_hi)[v] * norm_snr[t]).  norm_snr: HOST [T]. */
+int64_t qbold_noise_workspace_bytes(const qbold_ctx* ctx);
+int qbold_signal_add_noise(const qbold_ctx* ctx, float* signal, const float* norm_snr_host,
+                           float snr_lo, float snr_hi, uint64_t seed, int64_t voxel0,
+                           void* workspace, int64_t V, void* stream);
+
 /* ---- ELBO ----------------------------------------------------------------------------------- */
 /* Size in bytes of the scratch the ELBO / fused kernels need for their per-workgroup partials. */
 int64_t qbold_elbo_workspace_bytes(const qbold_ctx* ctx);

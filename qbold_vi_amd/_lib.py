@@ -61,6 +61,14 @@ SIGNATURES = {
     "qbold_reparam": (C.c_int, [_P, _P, _P, _P, _I64, _P]),
     "qbold_logit_mvn_nlogp": (C.c_int, [_P, _P, _P, _P, _I64, _P]),
     "qbold_posterior_moments": (C.c_int, [_P, _P, _P, C.c_int, _U64, _I64, _P, _P, _I64, _P]),
+    "qbold_normalise": (C.c_int, [_P, _P, _P, _I64, _P]),
+    "qbold_transform": (C.c_int, [_P, C.c_int, _P, _P, _I64, _P]),
+    "qbold_nll_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, C.c_int, _P]),
+    "qbold_kl_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int, _U64, _I64, _P, _I64, _P]),
+    "qbold_kl_closed": (C.c_int, [_P, _P, _P, _P, _I64, _P]),
+    "qbold_normals": (C.c_int, [_P, _U64, C.c_uint32, _I64, C.c_int, _P, _I64, _P]),
+    "qbold_noise_workspace_bytes": (_I64, [_P]),
+    "qbold_signal_add_noise": (C.c_int, [_P, _P, _P, C.c_float, C.c_float, _U64, _I64, _P, _I64, _P]),
     "qbold_elbo_workspace_bytes": (_I64, [_P]),
     "qbold_elbo_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _U64, _I64,
                                  _P, _P, _P, _I64, _P]),

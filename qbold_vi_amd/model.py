@@ -1,0 +1,347 @@
+"""Encoder, reparameterised sampling and the variational objective -- host mirror of the
+reference's model.py (ReparamTrickLayer :15-50, EncoderTrainer :53-770).
+
+Class and method names, argument order and defaults follow the reference; tensors are float32
+ROCm tensors, channel-last, with the mask carried as the LAST channel of the "true" tensors
+exactly as Keras hands them to the reference's loss callables.  Voxel batches may have any leading
+shape; the reference's 5-D (B, X, Y, Z, C) layout is accepted as is.  Arithmetic is done by
+libqbold_hip.so; torch provides memory, reshapes and trivial reductions of kernel outputs.
+
+Scope: the branches optimal.yaml disables -- population prior / MoG / inverse-gamma
+(model.py:252-271, 492-507, 666-716), non-MVG 4-parameter posteriors, dropout / GroupNorm, and
+spatial (crop) inputs to the 3x3x1 stream -- raise NotImplementedError instead of silently
+computing something else.
+"""
+import numpy as np
+import torch
+
+from .init import init_encoder_weights
+from .ops import Context, EncoderWeights
+
+
+def _flat(t, c):
+    return t.reshape(-1, c)
+
+
+class EncoderModel:
+    """Stands in for the Keras `outer_model` of create_encoder (model.py:222): model(x) ->
+    [out1 (stream 1, [...,5]), out2 (stream 2, [...,5]), sigma ([...,T])]."""
+
+    def __init__(self, trainer, weights):
+        self._trainer = trainer
+        self.weights = weights
+
+    def __call__(self, x):
+        return self.predict(x)
+
+    def predict(self, x, want=("out1", "out2", "sigma")):
+        self._trainer._check_voxelwise(x)
+        return list(self._trainer._ctx.encoder_fwd(self.weights, x, want=want))
+
+    # Weights travel as .npz with the canonical tensor names (Keras HDF5 is SURVEY N3).
+    def get_weights(self):
+        return self.weights.to_arrays()
+
+    def set_weights(self, arrays):
+        self.weights.set_from_arrays(arrays)
+
+    def save_weights(self, path):
+        np.savez(path, **self.get_weights())
+
+    def load_weights(self, path):
+        with np.load(path) as f:
+            self.set_weights({k: f[k] for k in f.files})
+
+
+class _InnerModel:
+    """create_encoder also returns the `inner_model` that starts after the first 1x1x1 layer
+    (model.py:217); nothing on the hot path calls it."""
+
+    def __call__(self, *a, **k):
+        raise NotImplementedError("inner_model (post-first-layer features in) is not part of the "
+                                  "accelerated voxel path")
+
+
+class ReparamTrickLayer:
+    """Draws (OEF, DBV) samples from the predicted logit-Normal (model.py:15-50).  The normals
+    come from the library's Philox stream (qbold_normals) unless `z` is given."""
+
+    def __init__(self, encoder_trainer):
+        self._encoder_trainer = encoder_trainer
+        self._draws = 0
+
+    def __call__(self, inputs, z=None):
+        return self.call(inputs, z=z)
+
+    def call(self, inputs, z=None, *args, **kwargs):
+        input, mask = inputs
+        tr = self._encoder_trainer
+        if not tr._use_mvg:
+            raise NotImplementedError("use_mvg=False (model.py:33-37) is disabled in optimal.yaml")
+        q = _flat(input, input.shape[-1])[:, :5]
+        if z is None:
+            z = tr._ctx.normals(q.shape[0], 1, stream_id=0, seed=tr._seed + 104729 * self._draws)
+            self._draws += 1
+        return tr._ctx.reparam(q, z.reshape(-1, 2)).reshape(input.shape[:-1] + (2,))
+
+
+class FineTuner:
+    """The `full_model` of build_fine_tuner (model.py:239-286): full_model([data, mask]) ->
+    {'predictions': q [...,5], 'predicted_images': concat[signal, sigma] [S*...,2T]}."""
+
+    def __init__(self, trainer, encoder_model, signal_generation_layer):
+        self._trainer = trainer
+        self.encoder_model = encoder_model
+        self.signal_generation_layer = signal_generation_layer
+        self._rpl = ReparamTrickLayer(trainer)
+
+    def __call__(self, inputs):
+        return self.predict(inputs)
+
+    def predict(self, inputs):
+        data, mask = inputs
+        tr = self._trainer
+        _, q, sigma = self.encoder_model.predict(data, want=("out2", "sigma"))
+        S = tr._no_samples
+        qs = torch.cat([q] * S, 0)          # model.py:245
+        sig = torch.cat([sigma] * S, 0)     # model.py:246
+        sampled = self._rpl((qs, mask))     # model.py:248
+        output = self.signal_generation_layer(sampled)  # model.py:273
+        # 'predictions' is the S-fold tiled distribution, as in the reference (model.py:245,285)
+        return {'predictions': qs, 'predicted_images': torch.cat([output, sig], -1)}
+
+    def elbo(self, data, mask, prior, no_samples=None, kl_samples=70, seed=1, voxel0=0):
+        """The fused path: one launch for encoder + S draws + forward model + NLL + K-draw KL.
+        Returns dict(nll, kl, elbo (= nll + kl, train.py:351), sums, q, nll_kl)."""
+        tr = self._trainer
+        S = tr._no_samples if no_samples is None else no_samples
+        x = _flat(data, data.shape[-1])
+        m = None if mask is None else mask.reshape(-1)
+        sums, q, nll_kl = tr._ctx.vi_fwd(self.encoder_model.weights, x, m, _flat(prior, 5), S,
+                                         kl_samples, seed=seed, voxel0=voxel0)
+        return dict(sums=sums, q=q, nll_kl=nll_kl, nll=sums[0] / sums[2], kl=sums[1] / sums[2],
+                    elbo=(sums[0] + sums[1]) / sums[2])
+
+
+class EncoderTrainer:
+    def __init__(self,
+                 system_params,
+                 no_intermediate_layers=1,
+                 no_units=10,
+                 use_layer_norm=False,
+                 dropout_rate=0.0,
+                 activation_type='gelu',
+                 student_t_df=None,
+                 initial_im_sigma=0.08,
+                 multi_image_normalisation=True,
+                 channelwise_gating=False,
+                 infer_inv_gamma=False,
+                 use_mvg=True,
+                 use_population_prior=True,
+                 mog_components=1,
+                 no_samples=1,
+                 heteroscedastic_noise=True,
+                 predict_log_data=True,
+                 full_model=True,
+                 use_blood=True,
+                 device=None,
+                 seed=1):
+        self._no_intermediate_layers = no_intermediate_layers
+        self._no_units = no_units
+        self._use_layer_norm = use_layer_norm
+        self._dropout_rate = dropout_rate
+        self._activation_type = activation_type
+        self._student_t_df = student_t_df
+        self._initial_im_sigma = initial_im_sigma
+        self._multi_image_normalisation = multi_image_normalisation
+        self._system_params = system_params
+        self._channelwise_gating = channelwise_gating
+        self._infer_inv_gamma = infer_inv_gamma
+        self._use_mvg = use_mvg
+        self._use_population_prior = use_population_prior
+        self._mog_components = mog_components
+        self._no_samples = no_samples
+        self._oef_range = 0.8
+        self._min_oef = 0.04
+        self._dbv_range = 0.2
+        self._min_dbv = 0.001
+        self._heteroscedastic_noise = heteroscedastic_noise
+        self._predict_log_data = predict_log_data
+        # Store the spin-echo index (model.py:95)
+        self._se_idx = int(abs(float(system_params['tau_start']) / float(system_params['tau_step'])))
+        self._seed = int(seed)
+        unsupported = []
+        if use_layer_norm or dropout_rate > 0.0:
+            unsupported.append("use_layer_norm / dropout_rate (model.py:133-140)")
+        if activation_type != 'relu':
+            unsupported.append(f"activation_type={activation_type!r} (kernels implement 'relu')")
+        if infer_inv_gamma:
+            unsupported.append("infer_inv_gamma (model.py:201-205)")
+        if not use_mvg:
+            unsupported.append("use_mvg=False (4-parameter posterior)")
+        if use_population_prior:
+            unsupported.append("use_population_prior (model.py:252-271)")
+        if not heteroscedastic_noise:
+            unsupported.append("heteroscedastic_noise=False (model.py:277-281)")
+        if unsupported:
+            raise NotImplementedError("configuration outside the accelerated path (disabled by "
+                                      "configurations/optimal.yaml): " + "; ".join(unsupported))
+        self._ctx = Context(system_params, full_model, use_blood,
+                            multi_image_normalisation=multi_image_normalisation,
+                            predict_log_data=predict_log_data, student_t_df=student_t_df,
+                            device=device)
+        assert self._ctx.se_idx == self._se_idx
+
+    # ------------------------------------------------------------------------------------
+    @property
+    def context(self):
+        return self._ctx
+
+    def _check_voxelwise(self, x):
+        if x.dim() == 5 and (x.shape[1] > 1 or x.shape[2] > 1) and self._no_intermediate_layers > 0:
+            raise NotImplementedError(
+                "spatial inputs to the 3x3x1 residual stream (model.py:152-157) are SURVEY row N1; "
+                "reshape voxels to (N,1,1,1,T) for the voxel-wise path")
+
+    def normalise_data(self, _data):  # model.py:97-113
+        return self._ctx.normalise(_data)
+
+    def create_encoder(self, system_constants=None, gate_offset=0.0, resid_init_std=1e-1,
+                       no_ip_images=11):
+        """model.py:122-223.  Returns (outer_model, inner_model)."""
+        if no_ip_images != self._ctx.T:
+            raise ValueError("no_ip_images must equal the number of taus of the system parameters")
+        w = init_encoder_weights(T=no_ip_images, U=self._no_units, L=self._no_intermediate_layers,
+                                 channelwise_gating=self._channelwise_gating,
+                                 resid_init_std=resid_init_std, im_loss_sigma=self._initial_im_sigma,
+                                 seed=self._seed)
+        ew = EncoderWeights(self._ctx, no_ip_images, self._no_units, self._no_intermediate_layers,
+                            self._channelwise_gating, gate_offset).set_from_arrays(w)
+        return EncoderModel(self, ew), _InnerModel()
+
+    def build_fine_tuner(self, encoder_model, signal_generation_layer, input_im=None, input_mask=None):
+        return FineTuner(self, encoder_model, signal_generation_layer)  # model.py:239-286
+
+    # -- transforms (model.py:288-316) -----------------------------------------------------
+    def transform_std(self, pred_stds):
+        return self._ctx.transform("transform_std", pred_stds)
+
+    def transform_offdiag(self, pred_offdiag):
+        return self._ctx.transform("transform_offdiag", pred_offdiag)
+
+    def inv_transform_std(self, std):
+        return self._ctx.transform("inv_transform_std", std)
+
+    def forward_transform(self, logits):
+        return self._ctx.transform("forward_transform", logits)
+
+    def backwards_transform(self, signal, include_logit):
+        return self._ctx.transform("backwards_transform_logit" if include_logit
+                                   else "backwards_transform", signal)
+
+    # -- sampling / moments (model.py:318-374) -----------------------------------------------
+    def create_samples(self, predicted_params, mask, no_samples, seed=None):
+        q = _flat(predicted_params, predicted_params.shape[-1])[:, :5]
+        z = self._ctx.normals(q.shape[0], no_samples, stream_id=2,
+                              seed=self._seed if seed is None else seed)
+        qs = q[:, None, :].expand(-1, no_samples, -1).reshape(-1, 5)
+        s = self._ctx.reparam(qs, z.reshape(-1, 2)).reshape(q.shape[0], no_samples, 2)
+        return s.permute(0, 2, 1).reshape(predicted_params.shape[:-1] + (2, no_samples))
+
+    def calculate_means(self, predicted_params, mask, include_r2p=False, return_stds=False,
+                        no_samples=20, seed=None):
+        q = _flat(predicted_params, predicted_params.shape[-1])[:, :5]
+        means, var = self._ctx.posterior_moments(q, no_samples, seed=self._seed if seed is None else seed,
+                                                 want_vars=return_stds)
+        c = 3 if include_r2p else 2
+        lead = predicted_params.shape[:-1]
+        means = means[:, :c].reshape(lead + (c,))
+        if return_stds:  # NB: biased variances under the name "stds" (model.py:331, Appendix B9)
+            return means, var[:, :c].reshape(lead + (c,))
+        return means
+
+    def oef_dbv_metrics(self, y_true, y_pred, oef_dbv_r2p=0):
+        means = self.calculate_means(y_pred, None, include_r2p=True)
+        residual = (means.reshape(-1, 3) - y_true.reshape(-1, 3))[:, oef_dbv_r2p]
+        return torch.mean(residual * residual)
+
+    def oef_metric(self, y_true, y_pred):
+        return self.oef_dbv_metrics(y_true, y_pred, 0)
+
+    def dbv_metric(self, y_true, y_pred):
+        return self.oef_dbv_metrics(y_true, y_pred, 1)
+
+    def r2p_metric(self, y_true, y_pred):
+        return self.oef_dbv_metrics(y_true, y_pred, 2)
+
+    # -- log density (model.py:376-447) ------------------------------------------------------
+    def logit_gaussian_mvg_log_prob(self, observations, predicted_params):
+        shape = predicted_params.shape[:-1]
+        out = self._ctx.logit_mvn_nlogp(observations.reshape(-1, observations.shape[-1])[:, 0:2],
+                                        _flat(predicted_params, 5))
+        return out.reshape(shape)
+
+    @staticmethod
+    def calculate_log_chol_det(oef_log_std, dbv_log_std):
+        return 2.0 * (oef_log_std + dbv_log_std)
+
+    def synthetic_data_loss(self, y_true_orig, y_pred_orig, use_r2p_loss=False, inv_gamma_alpha=0.0,
+                            inv_gamma_beta=0.0):
+        """Pre-training loss (model.py:449-514): mean negative log density of the true (OEF, DBV)."""
+        if use_r2p_loss or inv_gamma_alpha * inv_gamma_beta > 0.0:
+            raise NotImplementedError("use_r2p_loss / inverse-gamma prior (model.py:475-507) are "
+                                      "disabled in optimal.yaml")
+        y = y_true_orig.reshape(-1, 3)
+        return self._ctx.logit_mvn_nlogp(y[:, :2], _flat(y_pred_orig, 5)).mean()
+
+    def calculate_dw(self, oef):  # model.py:516-522
+        from .signals import SignalGenerationLayer
+        p = self._system_params
+        return SignalGenerationLayer.calculate_dw_static(oef, float(p['hct']), float(p['gamma']),
+                                                         float(p['b0']), float(p['dchi']))
+
+    def calculate_r2p(self, oef, dbv):
+        return self.calculate_dw(oef) * dbv
+
+    # -- objective terms ---------------------------------------------------------------------
+    def fine_tune_loss_fn(self, y_true, y_pred, return_mean=True):
+        """model.py:527-568.  y_true [..., T+1] = [data, mask]; y_pred [S*..., 2T] = [signal, sigma]."""
+        T = self._ctx.T
+        yt = _flat(y_true, T + 1)
+        yp = _flat(y_pred, 2 * T)
+        S = self._no_samples
+        N = yt.shape[0]
+        if yp.shape[0] != N * S:
+            raise ValueError("y_pred must hold no_samples copies of the batch")
+        mask = yt[:, T].contiguous()
+        nll = self._ctx.nll_fwd(yt[:, :T], mask, yp[:, :T], yp[:, T:], S)
+        nll = nll * mask.repeat(S)                       # model.py:564
+        if return_mean:
+            return nll.sum() / (mask.sum() * S)          # model.py:566 (mask is tiled S times)
+        return nll.reshape((S * y_true.shape[0],) + tuple(y_true.shape[1:-1]) + (1,))
+
+    def mvg_kl_samples(self, prior, pred, no_samples=50, seed=None):  # model.py:592-610
+        pr = _flat(prior, 6)
+        kl = self._ctx.kl_fwd(_flat(pred, 5), pr[:, :5], K=no_samples,
+                              seed=self._seed if seed is None else seed)
+        return kl.reshape(pred.shape[:-1] + (1,))
+
+    def mvg_kl(self, true, predicted):  # model.py:612-652 (closed form; cross-check)
+        pr = _flat(true, 6)
+        return self._ctx.kl_closed(_flat(predicted, 5), pr[:, :5]).reshape(predicted.shape[:-1] + (1,))
+
+    def kl_loss(self, true, predicted, return_mean=True, no_samples=70, seed=None):  # model.py:654-665
+        true = torch.cat([true] * self._no_samples, 0)
+        kl_op = self.mvg_kl_samples(true, predicted, no_samples=no_samples, seed=seed)
+        mask = true[..., 5:6]
+        kl_op = torch.where(mask > 0, kl_op, torch.zeros_like(kl_op))
+        if return_mean:
+            return kl_op.sum() / mask.sum()
+        return kl_op
+
+    def smoothness_loss(self, true_params, pred_params):
+        """Total-variation term (model.py:726-754).  It is identically 0 for voxel batches
+        (no x / y neighbours); image crops are SURVEY row N1."""
+        if pred_params.dim() == 5 and (pred_params.shape[1] > 1 or pred_params.shape[2] > 1):
+            raise NotImplementedError("smoothness_loss on image crops is SURVEY row N1")
+        return torch.zeros((), dtype=torch.float32, device=pred_params.device)

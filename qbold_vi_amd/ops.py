@@ -275,3 +275,99 @@ class Context:
                                          int(voxel0), _ptr(qo), _ptr(nk), _ptr(sums),
                                          _ptr(self._workspace()), N, _stream()), "qbold_vi_fwd")
         return sums, qo, nk
+
+
+# --------------------------------------------------------------------------------------------
+# the small pieces of the API surface (misc_kernels.hip)
+# --------------------------------------------------------------------------------------------
+TRANSFORM_OPS = {"transform_std": 0, "transform_offdiag": 1, "inv_transform_std": 2,
+                 "forward_transform": 3, "backwards_transform": 4, "backwards_transform_logit": 5}
+
+
+def _ctx_method(fn):
+    setattr(Context, fn.__name__, fn)
+    return fn
+
+
+@_ctx_method
+def normalise(self, x):
+    x = _f32(x, "x", self.T)
+    out = torch.empty_like(x)
+    _lib.check(self.lib.qbold_normalise(self.handle, _ptr(x), _ptr(out), x.numel() // self.T,
+                                        _stream()), "qbold_normalise")
+    return out
+
+
+@_ctx_method
+def transform(self, op, x):
+    x = _f32(x, "x")
+    out = torch.empty_like(x)
+    _lib.check(self.lib.qbold_transform(self.handle, TRANSFORM_OPS[op], _ptr(x), _ptr(out), x.numel(),
+                                        _stream()), "qbold_transform")
+    return out
+
+
+@_ctx_method
+def nll_fwd(self, x, mask, pred, sigma, S=1):
+    """Per-row NLL (before masking): x [N,T], pred/sigma [N*S,T] -> [N*S]."""
+    x = _f32(x, "x", self.T)
+    pred = _f32(pred, "pred", self.T)
+    sigma = _f32(sigma, "sigma", self.T)
+    mask = _f32(mask, "mask") if mask is not None else None
+    N = x.numel() // self.T
+    if pred.numel() != N * S * self.T or sigma.numel() != pred.numel():
+        raise ValueError("pred/sigma must hold N*S rows")
+    out = torch.empty(N * S, dtype=torch.float32, device=x.device)
+    _lib.check(self.lib.qbold_nll_fwd(self.handle, _ptr(x), _ptr(mask), _ptr(pred), _ptr(sigma),
+                                      _ptr(out), N, int(S), _stream()), "qbold_nll_fwd")
+    return out
+
+
+@_ctx_method
+def kl_fwd(self, q, prior, K=70, zk=None, seed=1, voxel0=0):
+    q = _f32(q, "q", 5)
+    prior = _f32(prior, "prior", 5)
+    N = q.numel() // 5
+    zk = _f32(zk, "zk", 2) if zk is not None else None
+    if zk is not None and zk.numel() != N * K * 2:
+        raise ValueError("zk must be [N, K, 2]")
+    out = torch.empty(q.shape[:-1], dtype=torch.float32, device=q.device)
+    _lib.check(self.lib.qbold_kl_fwd(self.handle, _ptr(q), _ptr(prior), _ptr(zk), int(K), int(seed),
+                                     int(voxel0), _ptr(out), N, _stream()), "qbold_kl_fwd")
+    return out
+
+
+@_ctx_method
+def kl_closed(self, q, prior):
+    q = _f32(q, "q", 5)
+    prior = _f32(prior, "prior", 5)
+    out = torch.empty(q.shape[:-1], dtype=torch.float32, device=q.device)
+    _lib.check(self.lib.qbold_kl_closed(self.handle, _ptr(q), _ptr(prior), _ptr(out), q.numel() // 5,
+                                        _stream()), "qbold_kl_closed")
+    return out
+
+
+@_ctx_method
+def normals(self, N, n, stream_id=0, seed=1, voxel0=0):
+    z = torch.empty((N, n, 2), dtype=torch.float32, device=self.device)
+    _lib.check(self.lib.qbold_normals(self.handle, int(seed), int(stream_id), int(voxel0), int(n),
+                                      _ptr(z), int(N), _stream()), "qbold_normals")
+    return z
+
+
+@_ctx_method
+def add_noise(self, signal, norm_snr, snr_lo=50.0, snr_hi=120.0, seed=1, voxel0=0):
+    """In place; signal [V, T] float32 contiguous cuda tensor."""
+    if not (signal.is_cuda and signal.dtype == torch.float32 and signal.is_contiguous()):
+        raise QboldError("add_noise needs a contiguous float32 cuda tensor (it is modified in place)")
+    norm_snr = np.ascontiguousarray(norm_snr, np.float32)
+    if norm_snr.size != self.T:
+        raise ValueError("norm_snr must have T entries")
+    ws = torch.empty(int(self.lib.qbold_noise_workspace_bytes(self.handle)), dtype=torch.uint8,
+                     device=signal.device)
+    _lib.check(self.lib.qbold_signal_add_noise(self.handle, _ptr(signal),
+                                               norm_snr.ctypes.data_as(C.c_void_p), float(snr_lo),
+                                               float(snr_hi), int(seed), int(voxel0), _ptr(ws),
+                                               signal.numel() // self.T, _stream()),
+               "qbold_signal_add_noise")
+    return signal

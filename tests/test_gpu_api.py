@@ -1,0 +1,206 @@
+"""GPU tests of the reference-shaped Python interface (qbold_vi_amd.signals / model / logit_mvn):
+they read like the calls the reference's own scripts make, and check against the CPU oracle."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+
+
+@pytest.fixture(scope="module")
+def trainer(params):
+    from qbold_vi_amd import EncoderTrainer
+    return EncoderTrainer(system_params=params, no_units=60, use_layer_norm=False, dropout_rate=0.0,
+                          no_intermediate_layers=2, student_t_df=200, initial_im_sigma=0.05,
+                          activation_type='relu', multi_image_normalisation=False,
+                          channelwise_gating=True, infer_inv_gamma=False, use_population_prior=False,
+                          use_mvg=True, predict_log_data=False)
+
+
+def oracle_weights(model, gate_offset):
+    w = model.get_weights()
+    w["gate_offset"] = gate_offset
+    w["meta"] = dict(T=11, U=60, L=2, channelwise_gating=True)
+    return w
+
+
+def gaussian_kl(q, p):
+    """KL(q || p) of the bivariate Gaussians in logit space, float64."""
+    def chol(v):
+        v = v.astype(np.float64)
+        so, sd = np.tanh(v[:, 1]) * 3 - 1, np.tanh(v[:, 3]) * 3 - 1
+        c = np.tanh(v[:, 4]) * np.exp(-2.0)
+        L = np.zeros((len(v), 2, 2))
+        L[:, 0, 0], L[:, 1, 0], L[:, 1, 1] = np.exp(so), c, np.exp(sd)
+        return np.stack([v[:, 0], v[:, 2]], -1), L, so + sd
+    mq, Lq, ldq = chol(q)
+    mp, Lp, ldp = chol(p)
+    Sq = Lq @ Lq.transpose(0, 2, 1)
+    Spi = np.linalg.inv(Lp @ Lp.transpose(0, 2, 1))
+    d = (mp - mq)[:, :, None]
+    tr = np.trace(Spi @ Sq, axis1=1, axis2=2)
+    quad = (d.transpose(0, 2, 1) @ Spi @ d)[:, 0, 0]
+    return 0.5 * (tr + quad - 2.0 + 2.0 * (ldp - ldq))
+
+
+def test_signal_layer_self_check_point(params, oracle32):
+    """The reference's only self-check (signals.py:307-314): the layer at [[[[[0.4, 0.12]]]]]."""
+    from qbold_vi_amd import SignalGenerationLayer
+    p = dict(params, simulate_noise='False')
+    layer = SignalGenerationLayer(p, True, True)
+    out = layer(dev(np.array([[[[[0.4, 0.12]]]]], np.float32)))
+    assert out.shape == (1, 1, 1, 1, 11)
+    want = oracle32.signal_fwd(np.array([[0.4, 0.12]], np.float32))[0]
+    np.testing.assert_allclose(out.cpu().numpy().ravel(), want, rtol=1e-5)
+    with pytest.raises(AssertionError):
+        layer(dev(np.zeros((4, 3), np.float32)))
+    # gradient entry: finite differences of the layer itself
+    y = dev(np.array([[0.4, 0.12], [0.3, 0.03]], np.float32))
+    g = torch.ones((2, 11), device="cuda")
+    got = layer.gradient(y, g).cpu().numpy()
+    eps = 1e-3
+    for k in range(2):
+        d = torch.zeros_like(y)
+        d[:, k] = eps
+        fd = ((layer(y + d) - layer(y - d)).sum(-1) / (2 * eps)).cpu().numpy()
+        np.testing.assert_allclose(got[:, k], fd, rtol=2e-2, atol=2e-3)
+
+
+def test_noise_model_statistics(params):
+    from qbold_vi_amd import SignalGenerationLayer
+    clean = SignalGenerationLayer(dict(params, simulate_noise='False'), True, True)
+    noisy = SignalGenerationLayer(dict(params, simulate_noise='True'), True, True)
+    y = dev(np.tile(np.array([[0.4, 0.025]], np.float32), (200000, 1)))
+    c, n = clean(y), noisy(y)
+    resid = (n - c) / c.mean(0, keepdim=True)
+    # std = 1/(U(50,120) * norm_snr): E[1/snr^2] over the uniform = 1/(50*120)
+    norm_snr = np.array([0.985, 1.00, 1.01, 1., 0.97, 0.95, 0.93, 0.90, 0.86, 0.83, 0.79])
+    want = np.sqrt(1.0 / 6000.0) / norm_snr
+    np.testing.assert_allclose(resid.std(0).cpu().numpy(), want, rtol=2e-2)
+    assert abs(float(resid.mean())) < 1e-4
+    assert not torch.equal(noisy(y), n)  # fresh noise per call
+
+
+def test_create_synthetic_dataset(params, oracle32):
+    from qbold_vi_amd import create_synthetic_dataset
+    p = dict(params, simulate_noise='False')
+    x, y = create_synthetic_dataset(p, True, True, 0.0, uniform_prop=0.1, sample_size=50)
+    assert x.shape == (2500, 11) and y.shape == (2500, 3)
+    yn = y.cpu().numpy()
+    assert yn[:, 0].min() >= 0.05 - 1e-6 and yn[:, 0].max() <= 0.8 + 1e-6
+    assert yn[:, 1].min() >= 0.003 - 1e-6 and yn[:, 1].max() <= 0.195 + 1e-6
+    np.testing.assert_allclose(x.cpu().numpy(), oracle32.signal_fwd(yn[:, :2]), rtol=1e-5)
+    np.testing.assert_allclose(yn[:, 2], 301.74327499379774 * yn[:, 0] * yn[:, 1], rtol=1e-5)
+    # meshgrid of 50 x 50 values (clipped OEF draws may coincide at the bounds)
+    assert 40 <= len(np.unique(yn[:, 0])) <= 50 and len(np.unique(yn[:, 1])) == 50
+
+
+def test_encoder_trainer_interface(trainer, params, oracle32):
+    from oracle.oracle import synth_inputs
+    from qbold_vi_amd import SignalGenerationLayer
+    model, _ = trainer.create_encoder(gate_offset=-3.0, resid_init_std=0.05, no_ip_images=11)
+    w = oracle_weights(model, -3.0)
+    n = 1000
+    x, truth = synth_inputs(n, params, seed=3, oracle=oracle32)
+    x5 = dev(x).reshape(n, 1, 1, 1, 11)
+    out1, out2, sigma = model(x5)
+    assert out1.shape == (n, 1, 1, 1, 5) and sigma.shape == (n, 1, 1, 1, 11)
+    w1, w2, ws = oracle32.encoder_fwd(w, x)
+    assert np.abs(out1.reshape(n, 5).cpu().numpy() - w1).max() < 2e-5
+    assert np.abs(out2.reshape(n, 5).cpu().numpy() - w2).max() < 2e-5
+    np.testing.assert_allclose(trainer.normalise_data(dev(x)).cpu().numpy(), oracle32.normalise(x),
+                               rtol=1e-5, atol=1e-6)
+    # pre-training loss, model.py:449-514
+    y3 = np.concatenate([truth, truth[:, :1] * truth[:, 1:2]], -1).astype(np.float32)
+    got = float(trainer.synthetic_data_loss(dev(y3).reshape(n, 1, 1, 1, 3), out1))
+    assert abs(got - oracle32.synthetic_data_loss(y3, w1)) < 1e-4 * abs(got) + 1e-5
+    # transforms
+    v = dev(np.linspace(-3, 3, 64).astype(np.float32))
+    np.testing.assert_allclose(trainer.transform_std(v).cpu().numpy(), np.tanh(v.cpu().numpy()) * 3 - 1,
+                               rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(trainer.inv_transform_std(trainer.transform_std(v * 0.3)).cpu().numpy(),
+                               (v * 0.3).cpu().numpy(), rtol=1e-4, atol=1e-5)
+    lg = dev(np.random.default_rng(0).normal(size=(32, 2)).astype(np.float32))
+    fw = trainer.forward_transform(lg)
+    np.testing.assert_allclose(trainer.backwards_transform(fw, True).cpu().numpy(), lg.cpu().numpy(),
+                               rtol=1e-4, atol=1e-5)
+    # weights round trip
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "pt_model.npz")
+        model.save_weights(path)
+        model2, _ = trainer.create_encoder(gate_offset=-3.0, resid_init_std=0.3, no_ip_images=11)
+        model2.set_weights({k: v * 0 for k, v in model2.get_weights().items()})
+        model2.load_weights(path)
+        assert torch.equal(model2(x5)[1], out2)
+
+    # fine tuner: unfused outputs + losses, and the fused ELBO
+    sig_layer = SignalGenerationLayer(dict(params, simulate_noise='False'), True, True)
+    full_model = trainer.build_fine_tuner(model, sig_layer, None, None)
+    rng = np.random.default_rng(4)
+    mask = (rng.uniform(size=(n, 1)) > 0.3).astype(np.float32)
+    mask5 = dev(mask).reshape(n, 1, 1, 1, 1)
+    outs = full_model([x5, mask5])
+    assert outs['predictions'].shape == (n, 1, 1, 1, 5)
+    assert outs['predicted_images'].shape == (n, 1, 1, 1, 22)
+    y_true = torch.cat([x5, mask5], -1)
+    nll = trainer.fine_tune_loss_fn(y_true, outs['predicted_images'])
+    pi = outs['predicted_images'].reshape(n, 22).cpu().numpy()
+    want = oracle32.nll(x, mask[:, 0], pi[:, :11], pi[:, 11:])
+    assert abs(float(nll) - (want * mask[:, 0]).sum() / mask.sum()) < 1e-4 * abs(float(nll))
+    prior_mask = torch.cat([out1, mask5], -1)
+    kl = trainer.kl_loss(prior_mask, outs['predictions'], no_samples=70, seed=5)
+    zk = oracle32.philox_normals(5, 1, 0, n, 70)
+    klv = oracle32.kl_samples(w2, w1, zk)
+    want_kl = np.where(mask[:, 0] > 0, klv, 0).sum() / mask.sum()
+    assert abs(float(kl) - want_kl) < 1e-4 * abs(want_kl) + 1e-5
+    # mvg_kl restates the reference's closed form (model.py:612-652) term by term ...
+    closed = trainer.mvg_kl(prior_mask, outs['predictions']).reshape(-1).cpu().numpy()
+    np.testing.assert_allclose(closed, oracle32.kl_closed(w2, w1), rtol=1e-3, atol=1e-4)
+    # ... which builds Sigma_p^-1 as L^-1 L^-T instead of L^-T L^-1 and is therefore exact only for
+    # zero covariance (it is never called by the reference's training).  The K -> infinity limit
+    # of the sampled KL is the true Gaussian KL in logit space, computed here in float64:
+    big = trainer.mvg_kl_samples(prior_mask, outs['predictions'], no_samples=4000).reshape(-1).cpu().numpy()
+    assert abs(big.mean() - gaussian_kl(w2, w1).mean()) < 0.02 * abs(gaussian_kl(w2, w1).mean()) + 1e-3
+    assert float(trainer.smoothness_loss(prior_mask, outs['predictions'])) == 0.0
+    fused = full_model.elbo(x5, mask5, out1, no_samples=1, kl_samples=70, seed=9)
+    zs = oracle32.philox_normals(9, 0, 0, n, 1)
+    zk = oracle32.philox_normals(9, 1, 0, n, 70)
+    ref = oracle32.elbo(x, mask[:, 0], w2, w1, ws, zs, zk)
+    assert abs(float(fused['elbo']) - ref['elbo']) < 1e-4 * abs(ref['elbo'])
+    # posterior moments via the trainer
+    means, var = trainer.calculate_means(out2, None, include_r2p=True, return_stds=True,
+                                         no_samples=200, seed=3)
+    zm = oracle32.philox_normals(3, 2, 0, n, 200)
+    wm, wv = oracle32.moments(w2, zm)
+    assert np.abs(means.reshape(n, 3).cpu().numpy()[:, :2] - wm[:, :2]).max() < 1e-5
+    np.testing.assert_allclose(var.reshape(n, 3).cpu().numpy(), wv, rtol=1e-3, atol=1e-9)
+    samples = trainer.create_samples(out2, None, 7)
+    assert samples.shape == (n, 1, 1, 1, 2, 7)
+    assert float(trainer.oef_metric(dev(y3).reshape(n, 1, 1, 1, 3), out1)) >= 0.0
+
+
+def test_disabled_branches_fail_loudly(params):
+    from qbold_vi_amd import EncoderTrainer, SignalGenerationLayer
+    with pytest.raises(NotImplementedError):
+        EncoderTrainer(params, use_population_prior=True, activation_type='relu')
+    with pytest.raises(NotImplementedError):
+        EncoderTrainer(params, use_population_prior=False, activation_type='gelu')
+    with pytest.raises(NotImplementedError):
+        SignalGenerationLayer(params, True, True, misaligned_prob=0.1)
+
+
+def test_logit_mvn(trainer, oracle32):
+    from qbold_vi_amd import LogitMVN
+    mvn = LogitMVN(trainer.context)
+    rng = np.random.default_rng(1)
+    p = rng.normal(size=(500, 5)).astype(np.float32)
+    y = np.stack([rng.uniform(0.05, 0.8, 500), rng.uniform(0.003, 0.195, 500)], -1).astype(np.float32)
+    got = mvn.logit_gaussian_mvg_log_prob(dev(y), dev(p)).cpu().numpy()
+    ref = oracle32.logit_mvn_nlogp(y, p)
+    assert np.max(np.abs(got - ref) / (np.abs(ref) + 1.0)) < 1e-4
