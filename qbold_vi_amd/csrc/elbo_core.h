@@ -30,12 +30,14 @@ struct VoxelLik {
     float mask;
 };
 
-// Normaliser of model.py:541-545: v[se] (or the mean of v[se-1..se+1]) + 1e-3.  SE >= 0 is a
-// compile-time spin-echo index; SE < 0 reads c.se_idx without dynamic register indexing.
+// Normaliser of model.py:541-545: v[se] (or the mean of v[se-1..se+1]) + 1e-3.  SE >= 0 means
+// "single-image normalisation with compile-time spin-echo index SE" (the host dispatch selects
+// it only when !multi_image_normalisation); SE < 0 reads c.se_idx / c.multi_norm at run time
+// without dynamic register indexing.
 template <int T, int SE>
 __device__ __forceinline__ float se_norm(const QbDev& c, const float (&v)[T]) {
-    if (SE >= 0 && !c.multi_norm) return v[SE >= 0 ? SE : 0] + 1e-3f;
-    const int se = SE >= 0 ? SE : c.se_idx;
+    if (SE >= 0) return v[SE >= 0 ? SE : 0] + 1e-3f;
+    const int se = c.se_idx;
     float a = 0.0f, b = 0.0f, d = 0.0f;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -99,7 +101,7 @@ __device__ __forceinline__ float sample_sq_fast(const FwdLds* L, const QbDev& c,
                                                 const VoxelLik<T>& k, float oef, float dbv) {
     const FwdFast fv = fwd_fast(c, oef, dbv);
     float acc = 0.0f;
-    if (SE >= 0 && !c.multi_norm) {
+    if (SE >= 0) {
         // spin-echo signal first, then each tau's residual as soon as its signal exists: no
         // T-element signal array is kept live
         const float s_se = fwd_signal_fast(L, c, fv, SE >= 0 ? SE : 0);
@@ -109,6 +111,9 @@ __device__ __forceinline__ float sample_sq_fast(const FwdLds* L, const QbDev& c,
             const float st = (t == SE) ? s_se : fwd_signal_fast(L, c, fv, t);
             const float r = fmaf(-st, inv_np, k.yt[t]) * k.inv_s[t];
             acc = fmaf(r, r, acc);
+            // keep at most four table rows (16 VGPRs) in flight: the scheduler would otherwise
+            // hoist all T LDS reads to the top and spill
+            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         return acc;
     }
@@ -171,11 +176,11 @@ __device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
         } else {
             normals4(seed, vox, (uint32_t)j, STREAM_LIK, z);
         }
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            if (d == 1 && !two) break;
+        // one draw at a time (not unrolled): two draws in flight double the live registers
+#pragma unroll 1
+        for (int d = 0; d < (two ? 2 : 1); ++d) {
             float a, b, oef, dbv;
-            reparam_logits(q, z[2 * d], z[2 * d + 1], a, b);
+            reparam_logits(q, d ? z[2] : z[0], d ? z[3] : z[1], a, b);
             forward_transform(a, b, oef, dbv);
             if (FAST) nll_sum += sample_sq_fast<T, SE>(L, c, lik, oef, dbv);
             else nll_sum += sample_nll<T, SE, LITERAL>(L, c, lik, oef, dbv);

@@ -203,7 +203,7 @@ extern "C" int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float*
     const bool fast = qb::elbo_fast_path(ctx);
     switch (ctx->dev.T) {
         case 11:
-            if (fast && ctx->dev.se_idx == 2) QB_LAUNCH_ELBO(11, 2, true, false);
+            if (fast && ctx->dev.se_idx == 2 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(11, 2, true, false);
             else if (fast) QB_LAUNCH_ELBO(11, -1, true, false);
             else if (lit) QB_LAUNCH_ELBO(11, -1, false, true);
             else QB_LAUNCH_ELBO(11, -1, false, false);

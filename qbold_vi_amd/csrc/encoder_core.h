@@ -1,4 +1,4 @@
-// encoder_core.h -- the voxel-wise encoder MLP on the CDNA4 matrix cores (exact-f32 MFMA).
+// encoder_core.h -- the voxel-wise encoder MLP on the CDNA4 matrix cores.
 //
 // Reference: EncoderTrainer.normalise_data (model.py:97-113) and create_encoder (model.py:122-223)
 // for (N,1,1,1,T) voxel batches, where the 3x3x1 convolutions of stream 2 act through their centre
@@ -9,19 +9,28 @@
 //   heads:     out = Wf . + bf  (5),   sigma = exp(Ws b + bs)  (T)
 //
 // Mapping.  One wave owns a tile of 16 voxels.  Every dense layer is computed TRANSPOSED,
-// Y^T[unit][voxel] = W^T[unit][k] X^T[k][voxel], with v_mfma_f32_16x16x4_f32: the weights are the A
-// operand (one 16-byte LDS read per k-step feeds the four 16-unit output tiles), the activations
-// the B operand.  The 16x16 accumulator puts the voxel on the lane (col = lane & 15) and four
-// units in the registers of each 16-lane group (row = 4 (lane >> 4) + reg), which is exactly what
-// the next layer's B operand wants for k-step (tile, reg) if the weight image is stored in that k
-// order -- so activations never leave the register file and never touch LDS.  A 64-unit
-// activation tensor costs 16 VGPRs per lane, which keeps the whole fused kernel under 128 VGPRs
-// (four waves per SIMD).  U <= 64 is padded to four 16-unit tiles.
+// Y^T[unit][voxel] = W^T[unit][k] X^T[k][voxel]: the weights are the MFMA A operand, the
+// activations the B operand.  The 16x16 accumulator puts the voxel on the lane (col = lane & 15)
+// and four units in the registers of each 16-lane group (row = 4 (lane >> 4) + reg), which is what
+// the next layer's B operand wants if the weight image is stored in that k order -- so activations
+// never leave the register file and never touch LDS.  A 64-unit activation tensor costs 16 VGPRs
+// per lane, which keeps the whole fused kernel within 128 VGPRs (four waves per SIMD).  U <= 64 is
+// padded to four 16-unit tiles.
 //
-// LDS weight image (built by pack_kernel in encoder_kernels.hip), per dense op with MT output
-// tiles:  A[kstep][group = 0..3][i = 0..15][m_out = 0..MT-1]  (lane (group, i) reads MT
-// consecutive floats; a wave reads one contiguous KiB: conflict-free),
-// bias[m_out][group][reg = 0..3].
+// Arithmetic: float32 in, float32 accumulate, through v_mfma_f32_16x16x32_f16 with every operand
+// split in two halves, x = hi + 2^-11 lo (hi = f16(x), lo = f16((x - hi) * 2^11); the scaling keeps
+// lo out of the f16 subnormals).  Three MFMAs per tile -- hi.hi into one accumulator, hi.lo and
+// lo.hi into a second that is folded in with 2^-11 -- drop only the lo.lo term: per-product
+// relative error <= ~3 * 2^-22 (7e-7), i.e. float32-grade, at 3/16 of the cycles of the exact
+// v_mfma_f32_16x16x4_f32 path.  The motive is not only the cycles: on gfx950 the f32-input MFMA runs
+// at the vector rate and, measured here, does NOT overlap with f32 VALU work from other waves
+// (profiles/), while the f16 matrix pipe does.
+//
+// LDS weight image (built by pack_kernel in encoder_kernels.hip), per dense op:
+//   A[kstep s][m_out][part = hi, lo][lane 0..63][j = 0..7] f16  (one ds_read_b128 per fragment,
+//   a wave reads one contiguous KiB: conflict-free), element = W[in = unit(s, lane>>4, j)]
+//   [out = 16 m_out + (lane & 15)], unit(s, g, j) = 16 (2s + (j >> 2)) + 4g + (j & 3);
+//   bias[m_out][group][reg = 0..3] f32.
 #pragma once
 
 #include "qbold_dev.h"
@@ -33,7 +42,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Offsets (in floats) of every piece of the packed image; wave-uniform kernel argument.
 struct EncLayout {
     int T, U, L;
-    int ksteps_first;   // ceil(T / 4)
+    int ksteps_first;   // 1 (K = 32 >= T)
     int n_head;         // 5 + T outputs of the merged head
     int head_tiles;     // ceil(n_head / 16): 1 or 2
     int first_A, first_b;
@@ -46,14 +55,14 @@ struct EncLayout {
 enum { BLK_WC_A = 0, BLK_WC_B = 4096, BLK_R1_A = 4160, BLK_R1_B = 8256, BLK_R2_A = 8320,
        BLK_R2_B = 12416, BLK_G_A = 12480, BLK_G_B = 16576, BLK_FLOATS = 16640 };
 
-__host__ __device__ inline EncLayout make_enc_layout(int T, int U, int L) {
-    EncLayout e;
+__host__ __device__ constexpr inline EncLayout make_enc_layout(int T, int U, int L) {
+    EncLayout e{};
     e.T = T; e.U = U; e.L = L;
-    e.ksteps_first = (T + 3) / 4;
+    e.ksteps_first = 1;
     e.n_head = 5 + T;
     e.head_tiles = (e.n_head + 15) / 16;
     e.first_A = 0;
-    e.first_b = e.ksteps_first * 256;
+    e.first_b = 2048;  // [m_out 4][part 2][lane 64][8 halves] = 4096 halves
     e.blk0 = e.first_b + 64;
     e.blk_stride = BLK_FLOATS;
     e.head_A = e.blk0 + L * BLK_FLOATS;
@@ -79,48 +88,88 @@ __device__ __forceinline__ f32x4 load4(const float* __restrict__ p) {
     return v;
 }
 
-#define QB_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// out[0..3] = W in + bias for a 64 -> 64 layer.  A: LDS image, bias: LDS [4][4][4].
-__device__ __forceinline__ void dense64(const float* __restrict__ A, const float* __restrict__ bias,
-                                        const f32x4 (&in)[4], f32x4 (&out)[4], int g, int i) {
+#define QB_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define QB_LO_SCALE 2048.0f
+#define QB_LO_UNSCALE (1.0f / 2048.0f)
+
+// hi / lo halves of eight float32 values as the B fragment of one K = 32 step.
+__device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) out[m] = load4(bias + m * 16 + g * 4);
-    const float4* Ap = reinterpret_cast<const float4*>(A) + g * 16 + i;
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 h = (_Float16)v[j];
+        hi[j] = h;
+        lo[j] = (_Float16)((v[j] - (float)h) * QB_LO_SCALE);
+    }
+}
+
+// B fragments (k-steps 0, 1) of a 64-unit activation tensor held as four accumulator tiles.
+struct ActFrag {
+    f16x8 hi[2], lo[2];
+};
+__device__ __forceinline__ ActFrag split_act(const f32x4 (&in)[4]) {
+    ActFrag f;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int s = 0; s < 2; ++s) {
+        const float v[8] = {in[2 * s][0], in[2 * s][1], in[2 * s][2], in[2 * s][3],
+                            in[2 * s + 1][0], in[2 * s + 1][1], in[2 * s + 1][2], in[2 * s + 1][3]};
+        split8(v, f.hi[s], f.lo[s]);
+    }
+    return f;
+}
+
+__device__ __forceinline__ f16x8 lds_frag(const float* __restrict__ A, int idx, int lane) {
+    // fragment idx of a dense op: 64 lanes x 16 bytes each
+    return *reinterpret_cast<const f16x8*>(reinterpret_cast<const unsigned char*>(A) + idx * 1024 +
+                                           lane * 16);
+}
+
+// out[0..MT-1] = W in + bias over KS k-steps of 32.  A: LDS image [s][m][part][lane][8], bias: f32.
+template <int MT, int KS>
+__device__ __forceinline__ void dense_f16x3(const float* __restrict__ A,
+                                            const float* __restrict__ bias, const f16x8 (&bhi)[KS],
+                                            const f16x8 (&blo)[KS], f32x4 (&out)[MT], int lane) {
+    const int g = lane >> 4;
+    f32x4 cross[MT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float4 a = Ap[(m * 4 + r) * 64];
-            out[0] = QB_MFMA16(a.x, in[m][r], out[0]);
-            out[1] = QB_MFMA16(a.y, in[m][r], out[1]);
-            out[2] = QB_MFMA16(a.z, in[m][r], out[2]);
-            out[3] = QB_MFMA16(a.w, in[m][r], out[3]);
+    for (int m = 0; m < MT; ++m) {
+        out[m] = load4(bias + m * 16 + g * 4);
+        cross[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const f16x8 whi = lds_frag(A, (s * MT + m) * 2 + 0, lane);
+            const f16x8 wlo = lds_frag(A, (s * MT + m) * 2 + 1, lane);
+            out[m] = QB_MFMA_F16(whi, bhi[s], out[m]);
+            cross[m] = QB_MFMA_F16(whi, blo[s], cross[m]);
+            cross[m] = QB_MFMA_F16(wlo, bhi[s], cross[m]);
         }
     }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[m][r] = fmaf(cross[m][r], QB_LO_UNSCALE, out[m][r]);
+    }
+}
+
+// 64 -> 64 layer on an activation tensor
+__device__ __forceinline__ void dense64(const float* __restrict__ A, const float* __restrict__ bias,
+                                        const f32x4 (&in)[4], f32x4 (&out)[4], int lane) {
+    const ActFrag f = split_act(in);
+    dense_f16x3<4, 2>(A, bias, f.hi, f.lo, out, lane);
 }
 
 // heads: HT (1 or 2) 16-row output tiles from a 64-unit input.
 template <int HT>
 __device__ __forceinline__ void dense_head(const float* __restrict__ A,
                                            const float* __restrict__ bias, const f32x4 (&in)[4],
-                                           f32x4 (&out)[HT], int g, int i) {
-#pragma unroll
-    for (int m = 0; m < HT; ++m) out[m] = load4(bias + m * 16 + g * 4);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float* ap = A + (((m * 4 + r) * 4 + g) * 16 + i) * HT;
-            if (HT == 1) {
-                out[0] = QB_MFMA16(ap[0], in[m][r], out[0]);
-            } else {
-                const float2 a = *reinterpret_cast<const float2*>(ap);
-                out[0] = QB_MFMA16(a.x, in[m][r], out[0]);
-                out[HT - 1] = QB_MFMA16(a.y, in[m][r], out[HT - 1]);
-            }
-        }
-    }
+                                           f32x4 (&out)[HT], int lane) {
+    const ActFrag f = split_act(in);
+    dense_f16x3<HT, 2>(A, bias, f.hi, f.lo, out, lane);
 }
 
 // normalise_data -- model.py:97-113; n[t] for this lane's voxel.
@@ -143,46 +192,44 @@ __device__ __forceinline__ void normalise(const QbDev& c, const float (&x)[T], f
     for (int t = 0; t < T; ++t) n[t] = QB_LN2 * log2f_(cl[t] * inv_den);  // model.py:108
 }
 
-// First layer: T -> 64 with relu.  The B operand of k-step s is n[4s + group].
+// First layer: T -> 64 with relu.  One K = 32 step; k-slot 8 group + j carries n[8 group + j].
 template <int T>
 __device__ __forceinline__ void dense_first(const float* __restrict__ A,
                                             const float* __restrict__ bias, const float (&n)[T],
-                                            f32x4 (&out)[4], int g, int i) {
+                                            f32x4 (&out)[4], int lane) {
+    static_assert(T <= 32, "first layer is a single K = 32 step");
+    const int g = lane >> 4;
+    float v[8];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) out[m] = load4(bias + m * 16 + g * 4);
-    const float4* Ap = reinterpret_cast<const float4*>(A) + g * 16 + i;
-    constexpr int KS = (T + 3) / 4;
+    for (int j = 0; j < 8; ++j) {
+        float x = 0.0f;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        float b = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (4 * s + k < T) b = (g == k) ? n[(4 * s + k < T) ? 4 * s + k : 0] : b;
-        const float4 a = Ap[s * 64];
-        out[0] = QB_MFMA16(a.x, b, out[0]);
-        out[1] = QB_MFMA16(a.y, b, out[1]);
-        out[2] = QB_MFMA16(a.z, b, out[2]);
-        out[3] = QB_MFMA16(a.w, b, out[3]);
+        for (int gg = 0; gg < 4; ++gg)
+            if (8 * gg + j < T) x = (g == gg) ? n[(8 * gg + j < T) ? 8 * gg + j : 0] : x;
+        v[j] = x;
     }
+    f16x8 hi[1], lo[1];
+    split8(v, hi[0], lo[0]);
+    dense_f16x3<4, 1>(A, bias, hi, lo, out, lane);
 #pragma unroll
     for (int m = 0; m < 4; ++m) out[m] = relu4(out[m]);
 }
 
 // One create_block step of stream 2 (gated residual), in place -- model.py:147-172.
-__device__ __forceinline__ void block_stream2(const float* __restrict__ W, f32x4 (&b)[4], int g,
-                                              int i) {
+__device__ __forceinline__ void block_stream2(const float* __restrict__ W, f32x4 (&b)[4],
+                                              int lane) {
     f32x4 skip[4], t[4], r[4];
-    dense64(W + BLK_WC_A, W + BLK_WC_B, b, skip, g, i);  // shared 1x1x1 conv as skip, :148
+    dense64(W + BLK_WC_A, W + BLK_WC_B, b, skip, lane);  // shared 1x1x1 conv as skip, :148
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         skip[m] = relu4(skip[m]);
         b[m] = relu4(b[m]);  // Activation before the first 3x3x1 conv, :151
     }
-    dense64(W + BLK_R1_A, W + BLK_R1_B, b, t, g, i);  // :152
+    dense64(W + BLK_R1_A, W + BLK_R1_B, b, t, lane);  // :152
 #pragma unroll
     for (int m = 0; m < 4; ++m) t[m] = relu4(t[m]);   // :155
-    dense64(W + BLK_R2_A, W + BLK_R2_B, t, r, g, i);  // :156
-    dense64(W + BLK_G_A, W + BLK_G_B, r, t, g, i);    // gating logits (+ gate_offset in bias), :164
+    dense64(W + BLK_R2_A, W + BLK_R2_B, t, r, lane);  // :156
+    dense64(W + BLK_G_A, W + BLK_G_B, r, t, lane);    // gating logits (+ gate_offset in bias), :164
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -194,10 +241,10 @@ __device__ __forceinline__ void block_stream2(const float* __restrict__ W, f32x4
 }
 
 // One create_block step of stream 1 -- model.py:144-145.
-__device__ __forceinline__ void block_stream1(const float* __restrict__ W, f32x4 (&a)[4], int g,
-                                              int i) {
+__device__ __forceinline__ void block_stream1(const float* __restrict__ W, f32x4 (&a)[4],
+                                              int lane) {
     f32x4 o[4];
-    dense64(W + BLK_WC_A, W + BLK_WC_B, a, o, g, i);
+    dense64(W + BLK_WC_A, W + BLK_WC_B, a, o, lane);
 #pragma unroll
     for (int m = 0; m < 4; ++m) a[m] = relu4(o[m]);
 }

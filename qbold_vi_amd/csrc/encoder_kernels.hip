@@ -6,8 +6,7 @@
 // the heteroscedastic sigma [N][T] (model.py:211-220).
 //
 // Roofline: 2 * 30,420 MAC = 60.8 kFLOP per voxel (U=60, L=2, T=11, stream 2) against 44 B read
-// + 64 B written -> ~560 flop/B: bound by the f32 matrix pipe (v_mfma_f32_32x32x2_f32,
-// 157.3 TFLOP/s peak), not by HBM.
+// + 64 B written -> ~560 flop/B: compute-bound (split-f16 MFMA, see encoder_core.h), not HBM.
 #include "encoder_core.h"
 #include "qbold_ctx.h"
 
@@ -55,62 +54,86 @@ __device__ __forceinline__ float wval(const float* W, int nin, int nout, int in,
     return (in < nin && out < nout) ? W[in * nout + out] : 0.0f;
 }
 
+// One element of a dense op's f16 image: fragment (s, m_out, part), lane, j.
+__device__ __forceinline__ _Float16 split_part(float w, int part) {
+    const _Float16 hi = (_Float16)w;
+    return part == 0 ? hi : (_Float16)((w - (float)hi) * QB_LO_SCALE);
+}
+__device__ __forceinline__ int frag_unit(int s, int g, int j) { return 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3); }
+
+// packed image, addressed in HALVES for the A pieces (2 per float slot) and floats for biases
 __global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset,
                             const float* __restrict__ w, float* __restrict__ packed) {
     const int U = c.U, T = c.T, G = c.G;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < e.total; p += gridDim.x * blockDim.x) {
-        float v = 0.0f;
-        if (p < e.first_b) {  // first-layer A: [s][g][i][m]
-            const int m = p & 3, i = (p >> 2) & 15, g = (p >> 6) & 3, s = p >> 8;
-            v = wval(w + c.W0, T, U, 4 * s + g, 16 * m + i);
-        } else if (p < e.blk0) {  // first-layer bias [m][g][r]
-            const int q = p - e.first_b, r = q & 3, g = (q >> 2) & 3, m = q >> 4;
+    _Float16* ph = reinterpret_cast<_Float16*>(packed);
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < 2 * e.total; p += gridDim.x * blockDim.x) {
+        const int pf = p >> 1;  // float slot this half lives in
+        if (pf < e.first_b) {   // first-layer A: [m][part][lane][j], k-slot 8g + j = input 8g + j
+            const int j = p & 7, lane = (p >> 3) & 63, part = (p >> 9) & 1, m = p >> 10;
+            const int in = 8 * (lane >> 4) + j;
+            ph[p] = split_part(wval(w + c.W0, T, U, in, 16 * m + (lane & 15)), part);
+        } else if (pf < e.blk0) {  // first-layer bias [m][g][r] (float: written by the even half)
+            if (p & 1) continue;
+            const int q = pf - e.first_b, r = q & 3, g = (q >> 2) & 3, m = q >> 4;
             const int u = qb::acc_unit(m, r, g);
-            v = u < U ? w[c.b0 + u] : 0.0f;
-        } else if (p < e.head_A) {
-            const int q = p - e.blk0, l = q / qb::BLK_FLOATS, o = q % qb::BLK_FLOATS;
+            packed[pf] = u < U ? w[c.b0 + u] : 0.0f;
+        } else if (pf < e.head_A) {
+            const int q = pf - e.blk0, l = q / qb::BLK_FLOATS, o = q % qb::BLK_FLOATS;
             const float* wb = w + c.blk0 + l * c.blk_stride;
             const int piece = o / 4160, oo = o % 4160;  // 4 x (4096 A + 64 bias)
             const int Aoff = piece == 0 ? c.Wc : piece == 1 ? c.Wr1 : piece == 2 ? c.Wr2 : c.Wg;
             const int boff = piece == 0 ? c.bc : piece == 1 ? c.br1 : piece == 2 ? c.br2 : c.bg;
             const int nout = piece == 3 ? G : U;
-            if (oo < 4096) {  // A: [kstep = m_in*4 + r][g][i][m_out]
-                const int m = oo & 3, i = (oo >> 2) & 15, g = (oo >> 6) & 3, ks = oo >> 8;
-                const int in = qb::acc_unit(ks >> 2, ks & 3, g);
-                int out = 16 * m + i;
+            if (oo < 4096) {  // A: [s][m_out][part][lane][j] in halves
+                const int h = 2 * oo + (p & 1);
+                const int j = h & 7, lane = (h >> 3) & 63, part = (h >> 9) & 1, m = (h >> 10) & 3, s = h >> 12;
+                const int in = frag_unit(s, lane >> 4, j);
+                int out = 16 * m + (lane & 15);
                 if (piece == 3 && G == 1) out = out < U ? 0 : U;  // shared gate broadcast to all units
-                v = wval(wb + Aoff, U, nout, in, out);
+                ph[p] = split_part(wval(wb + Aoff, U, nout, in, out), part);
             } else {
+                if (p & 1) continue;
                 const int qq = oo - 4096, r = qq & 3, g = (qq >> 2) & 3, m = qq >> 4;
                 const int u = qb::acc_unit(m, r, g);
+                float v = 0.0f;
                 if (u < U) {
                     v = wb[boff + ((piece == 3 && G == 1) ? 0 : u)];
                     if (piece == 3) v += gate_offset;
                 }
+                packed[pf] = v;
             }
-        } else if (p < e.head_b) {  // head A: [kstep][g][i][mh], rows: 0-4 = Wf, 5.. = Ws
-            const int q = p - e.head_A, HT = e.head_tiles;
-            const int mh = q % HT, qq = q / HT, i = qq & 15, g = (qq >> 4) & 3, ks = qq >> 6;
-            const int in = qb::acc_unit(ks >> 2, ks & 3, g);
-            const int row = 16 * mh + i;
+        } else if (pf < e.head_b) {  // head A: [s][mh][part][lane][j], rows: 0-4 = Wf, 5.. = Ws
+            const int HT = e.head_tiles;
+            const int h = p - 2 * e.head_A;
+            const int j = h & 7, lane = (h >> 3) & 63, part = (h >> 9) & 1, rest = h >> 10;
+            const int mh = rest % HT, s = rest / HT;
+            const int in = frag_unit(s, lane >> 4, j);
+            const int row = 16 * mh + (lane & 15);
+            float v = 0.0f;
             if (row < 5) v = wval(w + c.Wf, U, 5, in, row);
             else if (row < 5 + T) v = wval(w + c.Ws, U, T, in, row - 5);
-        } else if (p < e.head_b + 16 * e.head_tiles) {  // head bias [mh][g][r]
-            const int q = p - e.head_b, r = q & 3, g = (q >> 2) & 3, mh = q >> 4;
+            ph[p] = split_part(v, part);
+        } else if (pf < e.head_b + 16 * e.head_tiles) {  // head bias [mh][g][r]
+            if (p & 1) continue;
+            const int q = pf - e.head_b, r = q & 3, g = (q >> 2) & 3, mh = q >> 4;
             const int row = qb::acc_unit(mh, r, g);
+            float v = 0.0f;
             if (row < 5) v = w[c.bf + row];
             else if (row < 5 + T) v = w[c.bs + row - 5];
+            packed[pf] = v;
+        } else if (!(p & 1)) {
+            packed[pf] = 0.0f;
         }
-        packed[p] = v;
     }
 }
 
 constexpr int kEncBlock = 1024;
 
-template <int T>
+template <int T, int NL>
 __global__ __launch_bounds__(kEncBlock) void encoder_fwd_kernel(
-    QbDev c, EncLayout e, const float* __restrict__ packed, const float* __restrict__ x,
+    QbDev c, const float* __restrict__ packed, const float* __restrict__ x,
     float* __restrict__ out1, float* __restrict__ out2, float* __restrict__ sigma, int64_t N) {
+    constexpr EncLayout e = qb::make_enc_layout(T, 64, NL);
     extern __shared__ __align__(16) float lds_w[];
     for (int p = threadIdx.x; p < e.total / 4; p += kEncBlock)
         reinterpret_cast<float4*>(lds_w)[p] = reinterpret_cast<const float4*>(packed)[p];
@@ -129,12 +152,13 @@ __global__ __launch_bounds__(kEncBlock) void encoder_fwd_kernel(
         for (int t = 0; t < T; ++t) xv[t] = x[vc * T + t];
         qb::normalise<T>(c, xv, nv);
         f32x4 a[4];
-        qb::dense_first<T>(lds_w + e.first_A, lds_w + e.first_b, nv, a, g, i);
+        qb::dense_first<T>(lds_w + e.first_A, lds_w + e.first_b, nv, a, lane);
         if (out2 || sigma) {
             f32x4 b[4] = {a[0], a[1], a[2], a[3]};  // net2 = net1, model.py:185
-            for (int l = 0; l < e.L; ++l) qb::block_stream2(lds_w + e.blk0 + l * e.blk_stride, b, g, i);
+#pragma unroll
+            for (int l = 0; l < NL; ++l) qb::block_stream2(lds_w + e.blk0 + l * e.blk_stride, b, lane);
             f32x4 hd[HT];
-            qb::dense_head<HT>(lds_w + e.head_A, lds_w + e.head_b, b, hd, g, i);
+            qb::dense_head<HT>(lds_w + e.head_A, lds_w + e.head_b, b, hd, lane);
             float o[5 + T];
             qb::gather_head<5 + T, HT>(hd, o);
             if (v < N) {
@@ -149,9 +173,10 @@ __global__ __launch_bounds__(kEncBlock) void encoder_fwd_kernel(
             }
         }
         if (out1) {
-            for (int l = 0; l < e.L; ++l) qb::block_stream1(lds_w + e.blk0 + l * e.blk_stride, a, g, i);
+#pragma unroll
+            for (int l = 0; l < NL; ++l) qb::block_stream1(lds_w + e.blk0 + l * e.blk_stride, a, lane);
             f32x4 hd[HT];
-            qb::dense_head<HT>(lds_w + e.head_A, lds_w + e.head_b, a, hd, g, i);
+            qb::dense_head<HT>(lds_w + e.head_A, lds_w + e.head_b, a, hd, lane);
             float o[5];
             qb::gather_head<5, 1>(reinterpret_cast<f32x4(&)[1]>(hd[0]), o);
             if (v < N && g == 2) {
@@ -194,7 +219,7 @@ extern "C" int qbold_encoder_pack(const qbold_ctx* ctx, const qbold_encoder_shap
     QB_REQUIRE(weights && packed, "qbold_encoder_pack: null buffer");
     const EncLayout e = qb::make_enc_layout(shape->T, shape->U, shape->L);
     const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating);
-    hipLaunchKernelGGL(pack_kernel, dim3((e.total + 255) / 256), dim3(256), 0, (hipStream_t)stream, e,
+    hipLaunchKernelGGL(pack_kernel, dim3((2 * e.total + 255) / 256), dim3(256), 0, (hipStream_t)stream, e,
                        c, shape->gate_offset, weights, packed);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
@@ -214,19 +239,21 @@ extern "C" int qbold_encoder_fwd(const qbold_ctx* ctx, const qbold_encoder_shape
     const int64_t ntile = (N + 15) / 16;
     const int64_t nblk = (ntile + kEncBlock / 64 - 1) / (kEncBlock / 64);
     const int grid = (int)(nblk < ctx->num_cus ? nblk : ctx->num_cus);
-    switch (shape->T) {
-        case 11: {
-            auto k = encoder_fwd_kernel<11>;
-            QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(k, dim3(grid), dim3(kEncBlock), smem, (hipStream_t)stream, ctx->dev, e,
-                               packed, x, out1, out2, sigma, N);
-            break;
-        }
-        default:
-            qb::set_error("qbold_encoder_fwd: kernels are built for T = 11 taus");
-            return QBOLD_ERR_UNSUPPORTED;
+#define QB_LAUNCH_ENC(TT, NL)                                                                      \
+    do {                                                                                           \
+        auto k = encoder_fwd_kernel<TT, NL>;                                                       \
+        QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                               \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));        \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kEncBlock), smem, (hipStream_t)stream, ctx->dev,    \
+                           packed, x, out1, out2, sigma, N);                                       \
+    } while (0)
+    if (shape->T == 11 && shape->L == 1) QB_LAUNCH_ENC(11, 1);
+    else if (shape->T == 11 && shape->L == 2) QB_LAUNCH_ENC(11, 2);
+    else {
+        qb::set_error("qbold_encoder_fwd: kernels are built for T = 11 taus, L = 1 or 2");
+        return QBOLD_ERR_UNSUPPORTED;
     }
+#undef QB_LAUNCH_ENC
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }

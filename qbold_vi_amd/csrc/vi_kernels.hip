@@ -34,12 +34,14 @@ using qb::f32x4;
 constexpr int kBlock = 1024;
 constexpr int kWaves = kBlock / 64;
 
-template <int T, int SE, bool FAST, bool LITERAL>
+template <int T, int NL, int SE, bool FAST, bool LITERAL>
 __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
-    QbDev c, EncLayout e, const float4* __restrict__ g_tab, const float* __restrict__ packed,
+    QbDev c, const float4* __restrict__ g_tab, const float* __restrict__ packed,
     const float* __restrict__ x, const float* __restrict__ mask, const float* __restrict__ prior,
     int S, int K, uint64_t seed, int64_t voxel0, float* __restrict__ q_out,
     float2* __restrict__ nll_kl, double* __restrict__ partials, int64_t N) {
+    // compile-time weight-image layout: every LDS offset below folds into an instruction immediate
+    constexpr EncLayout e = qb::make_enc_layout(T, 64, NL);
     extern __shared__ __align__(16) unsigned char smem[];
     float* lds_w = reinterpret_cast<float*>(smem);
     qb::FwdLds* L = reinterpret_cast<qb::FwdLds*>(smem + sizeof(float) * e.total);
@@ -65,11 +67,12 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
             for (int t = 0; t < T; ++t) xv[t] = x[vc * T + t];
             qb::normalise<T>(c, xv, nv);
             f32x4 b[4];
-            qb::dense_first<T>(lds_w + e.first_A, lds_w + e.first_b, nv, b, g, i);
+            qb::dense_first<T>(lds_w + e.first_A, lds_w + e.first_b, nv, b, lane);
             if (!(c.debug_skip & 1))
-                for (int l = 0; l < e.L; ++l) qb::block_stream2(lds_w + e.blk0 + l * e.blk_stride, b, g, i);
+#pragma unroll
+                for (int l = 0; l < NL; ++l) qb::block_stream2(lds_w + e.blk0 + l * e.blk_stride, b, lane);
             f32x4 hd[HT];
-            qb::dense_head<HT>(lds_w + e.head_A, lds_w + e.head_b, b, hd, g, i);
+            qb::dense_head<HT>(lds_w + e.head_A, lds_w + e.head_b, b, hd, lane);
             qb::gather_head<5 + T, HT>(hd, o);
         }
         if (v < N && !(c.debug_skip & 2)) {
@@ -132,26 +135,29 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     const int grid = (int)(nblk < ctx->num_cus ? (nblk > 0 ? nblk : 1) : ctx->num_cus);
     const bool lit = ctx->dev.tissue_mode == QBOLD_TISSUE_LITERAL;
     float2* out = reinterpret_cast<float2*>(nll_kl);
-#define QB_LAUNCH_VI(TT, SE, FAST, LIT)                                                           \
+#define QB_LAUNCH_VI(TT, NL, SE, FAST, LIT)                                                          \
     do {                                                                                          \
-        auto k = vi_fwd_kernel<TT, SE, FAST, LIT>;                                                \
+        auto k = vi_fwd_kernel<TT, NL, SE, FAST, LIT>;                                             \
         QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                              \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));       \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), smem, s, ctx->dev, e, ctx->d_tab, packed, \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), smem, s, ctx->dev, ctx->d_tab, packed,    \
                            x, mask, prior, S, K, seed, voxel0, q_out, out, partials, N);          \
     } while (0)
     const bool fast = qb::elbo_fast_path(ctx);
-    switch (shape->T) {
-        case 11:
-            if (fast && ctx->dev.se_idx == 2) QB_LAUNCH_VI(11, 2, true, false);
-            else if (fast) QB_LAUNCH_VI(11, -1, true, false);
-            else if (lit) QB_LAUNCH_VI(11, -1, false, true);
-            else QB_LAUNCH_VI(11, -1, false, false);
-            break;
-        default:
-            qb::set_error("qbold_vi_fwd: kernels are built for T = 11 taus");
-            return QBOLD_ERR_UNSUPPORTED;
+#define QB_DISPATCH_VI(TT, NL)                                                    \
+    do {                                                                          \
+        if (fast && ctx->dev.se_idx == 2 && !ctx->dev.multi_norm && !(ctx->dev.debug_skip & 4)) QB_LAUNCH_VI(TT, NL, 2, true, false);   \
+        else if (fast) QB_LAUNCH_VI(TT, NL, -1, true, false);                     \
+        else if (lit) QB_LAUNCH_VI(TT, NL, -1, false, true);                      \
+        else QB_LAUNCH_VI(TT, NL, -1, false, false);                              \
+    } while (0)
+    if (shape->T == 11 && shape->L == 1) QB_DISPATCH_VI(11, 1);
+    else if (shape->T == 11 && shape->L == 2) QB_DISPATCH_VI(11, 2);
+    else {
+        qb::set_error("qbold_vi_fwd: kernels are built for T = 11 taus, L = 1 or 2");
+        return QBOLD_ERR_UNSUPPORTED;
     }
+#undef QB_DISPATCH_VI
 #undef QB_LAUNCH_VI
     QB_HIP(hipGetLastError());
     hipLaunchKernelGGL(qb::reduce_partials_kernel, dim3(1), dim3(192), 0, s, partials, grid, sums);
