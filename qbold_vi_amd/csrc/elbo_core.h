@@ -130,17 +130,21 @@ __device__ __forceinline__ float sample_sq_fast(const FwdLds* L, const QbDev& c,
 }
 
 // swr_p - swr_q of one draw: the only draw-dependent part of log q - log p (the Jacobian and the
-// log-determinants cancel or are constant per voxel).  Logits come from the clipped unit-interval
-// value exactly as logit_gaussian_mvg_log_prob forms them (model.py:393-396).
+// log-determinants cancel or are constant per voxel).
+//
+// The reference forms the logits by a round trip through the unit interval
+// (model.py:393-396): x = clip((y - min)/range, 1e-6, 1 - 1e-6), logit(x) = log(x / (1 - x)),
+// with y = sigmoid(a) * range + min.  For an unclipped draw that is the identity, logit(x) = a up
+// to float32 rounding of the round trip; the clip of x at [1e-6, 1 - 1e-6] is a clip of the logit
+// at +-log((1 - 1e-6) / 1e-6) = +-13.815510.  The fast path therefore clips the logit directly
+// (no sigmoid, log or reciprocal per draw); the literal / generic path keeps the round trip.
+#define QB_LOGIT_CLIP 13.815509557963774f
 __device__ __forceinline__ float kl_swr_diff(const LogitMvn& q, const LogitMvn& p, float z0,
                                              float z1) {
-    float a, b, oef, dbv;
+    float a, b;
     reparam_logits(q, z0, z1, a, b);
-    forward_transform(a, b, oef, dbv);
-    float x0 = clampf_((oef - QB_MIN_OEF) * 1.25f, 1e-6f, 1.0f - 1e-6f);
-    float x1 = clampf_((dbv - QB_MIN_DBV) * 5.0f, 1e-6f, 1.0f - 1e-6f);
-    const float l0 = QB_LN2 * log2f_(x0 * rcpf_(1.0f - x0));  // logit, model.py:10-12
-    const float l1 = QB_LN2 * log2f_(x1 * rcpf_(1.0f - x1));
+    const float l0 = clampf_(a, -QB_LOGIT_CLIP, QB_LOGIT_CLIP);
+    const float l1 = clampf_(b, -QB_LOGIT_CLIP, QB_LOGIT_CLIP);
     const float rq0 = l0 - q.mu_o, rq1 = l1 - q.mu_d;
     const float rp0 = l0 - p.mu_o, rp1 = l1 - p.mu_d;
     const float wq0 = rq0 * q.i_so, wq1 = fmaf(rq1, q.i_sd, rq0 * q.i_bl);
@@ -156,7 +160,7 @@ __device__ __forceinline__ float kl_swr_diff(const LogitMvn& q, const LogitMvn& 
 template <int T, int SE, bool FAST, bool LITERAL>
 __device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
                                               const VoxelLik<T>& lik, const LogitMvn& q,
-                                              const LogitMvn& prior, int S, int K,
+                                              const float* __restrict__ prior_row, int S, int K,
                                               const float* __restrict__ zs,
                                               const float* __restrict__ zk, uint64_t seed,
                                               uint64_t vox, int part, float& nll_sum,
@@ -189,6 +193,12 @@ __device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
     if (FAST) {  // sum_d [0.5 sum_t r^2 + sum_t log sigma + T log sqrt(2 pi)] over this lane's draws
         nll_sum = fmaf(0.5f, nll_sum, (float)n_lik * lik.log_s_sum);
     }
+    // the prior's parameters are fetched and transformed only now: they are dead weight in
+    // registers during the likelihood loop
+    float pv[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) pv[k] = prior_row[k];
+    const LogitMvn prior = make_mvn(pv);
     for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
         float z[4];
         const bool two = 2 * j + 1 < K;

@@ -32,23 +32,20 @@ __global__ __launch_bounds__(kBlock) void elbo_fwd_kernel(
     for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const int64_t v = tile * kVoxPerBlock + wave * QB_VOX_PER_WAVE + (lane & 15);
         if (v < N) {
-            float xv[T], sv[T], qv[5], pv[5];
+            float xv[T], sv[T], qv[5];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 xv[t] = x[v * T + t];
                 sv[t] = sigma[v * T + t];
             }
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                qv[i] = q[v * 5 + i];
-                pv[i] = prior[v * 5 + i];
-            }
+            for (int i = 0; i < 5; ++i) qv[i] = q[v * 5 + i];
             const float m = mask ? mask[v] : 1.0f;
             qb::VoxelLik<T> lik;
             qb::prepare_lik<T, SE, false>(c, xv, sv, m, lik);
-            const qb::LogitMvn qm = qb::make_mvn(qv), pm = qb::make_mvn(pv);
+            const qb::LogitMvn qm = qb::make_mvn(qv);
             float nll_part, kl_part;
-            qb::voxel_mc_sums<T, SE, FAST, LITERAL>(&L, c, lik, qm, pm, S, K, zs ? zs + v * S * 2 : nullptr,
+            qb::voxel_mc_sums<T, SE, FAST, LITERAL>(&L, c, lik, qm, prior + v * 5, S, K, zs ? zs + v * S * 2 : nullptr,
                                           zk ? zk + v * K * 2 : nullptr, seed,
                                           (uint64_t)(voxel0 + v), part, nll_part, kl_part);
             // the four lanes of a voxel are active together (v depends on lane & 15 only)

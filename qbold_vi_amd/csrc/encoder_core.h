@@ -138,15 +138,25 @@ __device__ __forceinline__ void dense_f16x3(const float* __restrict__ A,
         out[m] = load4(bias + m * 16 + g * 4);
         cross[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
+    // Fragments are fetched one (k-step, tile) ahead of the MFMAs that consume them; the
+    // sched_barrier keeps the scheduler from hoisting all 2*KS*MT reads to the top (64 VGPRs).
+    f16x8 whi = lds_frag(A, 0, lane), wlo = lds_frag(A, 1, lane);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const f16x8 whi = lds_frag(A, (s * MT + m) * 2 + 0, lane);
-            const f16x8 wlo = lds_frag(A, (s * MT + m) * 2 + 1, lane);
+            const int nxt = s * MT + m + 1;
+            f16x8 nhi = whi, nlo = wlo;
+            if (nxt < KS * MT) {
+                nhi = lds_frag(A, nxt * 2 + 0, lane);
+                nlo = lds_frag(A, nxt * 2 + 1, lane);
+            }
             out[m] = QB_MFMA_F16(whi, bhi[s], out[m]);
             cross[m] = QB_MFMA_F16(whi, blo[s], cross[m]);
             cross[m] = QB_MFMA_F16(wlo, bhi[s], cross[m]);
+            whi = nhi;
+            wlo = nlo;
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll

@@ -80,22 +80,19 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
             // empty asm keeps the compiler from merging the two reads
             const float* xr = x + v * T;
             asm volatile("" : "+v"(xr));
-            float xv[T], sv[T], qv[5], pv[5];
+            float xv[T], sv[T], qv[5];
 #pragma unroll
             for (int t = 0; t < T; ++t) xv[t] = xr[t];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                qv[k] = o[k];
-                pv[k] = prior[v * 5 + k];
-            }
+            for (int k = 0; k < 5; ++k) qv[k] = o[k];
 #pragma unroll
             for (int t = 0; t < T; ++t) sv[t] = o[5 + t];  // log sigma; sigma = exp(.), model.py:214
             const float m = mask ? mask[v] : 1.0f;
             qb::VoxelLik<T> lik;
             qb::prepare_lik<T, SE, true>(c, xv, sv, m, lik);
-            const qb::LogitMvn qm = qb::make_mvn(qv), pm = qb::make_mvn(pv);
+            const qb::LogitMvn qm = qb::make_mvn(qv);
             float nll_part, kl_part;
-            qb::voxel_mc_sums<T, SE, FAST, LITERAL>(L, c, lik, qm, pm, S, K, nullptr, nullptr, seed,
+            qb::voxel_mc_sums<T, SE, FAST, LITERAL>(L, c, lik, qm, prior + v * 5, S, K, nullptr, nullptr, seed,
                                                     (uint64_t)(voxel0 + v), g, nll_part, kl_part);
             const float nll = qb::voxel_sum(nll_part) / (float)S;
             const float kl = K > 0 ? qb::voxel_sum(kl_part) / (float)K : 0.0f;
