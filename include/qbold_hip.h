@@ -207,6 +207,20 @@ int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const f
                  int64_t voxel0, float* q_out, float* nll_kl, double* sums, void* workspace,
                  int64_t N, void* stream);
 
+/* ---- gradients (training) ------------------------------------------------------------------- */
+/* Adjoint of qbold_elbo_fwd with respect to the encoder's head outputs: what TensorFlow autodiff
+ * yields through build_fine_tuner's sampling + fine_tune_loss_fn + kl_loss (model.py:239-286,
+ * 527-568, 592-610; q is stop-gradient inside log q, model.py:596).
+ *   log_sigma [N][T] (the sigma head BEFORE exp, model.py:211-214)
+ *   g_q [N][5], g_log_sigma [N][T]:  m_v * d nll_v/d. + [m_v > 0] * d kl_v/d.   (NOT divided by
+ *   sum(m): the caller scales the weight gradient once)
+ *   nll_kl, sums, workspace: as qbold_elbo_fwd (same Philox stream -> same loss values).
+ * Built for the optimal.yaml configuration (table mode, Gaussian likelihood, linear data). */
+int qbold_elbo_bwd(const qbold_ctx* ctx, const float* x, const float* mask, const float* q,
+                   const float* prior, const float* log_sigma, int S, int K, uint64_t seed,
+                   int64_t voxel0, float* g_q, float* g_log_sigma, float* nll_kl, double* sums,
+                   void* workspace, int64_t N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,8 @@ SIGNATURES = {
     "qbold_elbo_workspace_bytes": (_I64, [_P]),
     "qbold_elbo_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _U64, _I64,
                                  _P, _P, _P, _I64, _P]),
+    "qbold_elbo_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _U64, _I64, _P, _P, _P, _P,
+                                 _P, _I64, _P]),
     "qbold_vi_fwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, _P, _P, C.c_int, C.c_int,
                                _U64, _I64, _P, _P, _P, _P, _I64, _P]),
 }

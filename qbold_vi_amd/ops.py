@@ -371,3 +371,24 @@ def add_noise(self, signal, norm_snr, snr_lo=50.0, snr_hi=120.0, seed=1, voxel0=
                                                signal.numel() // self.T, _stream()),
                "qbold_signal_add_noise")
     return signal
+
+
+@_ctx_method
+def elbo_bwd(self, x, mask, q, prior, log_sigma, S=1, K=70, seed=1, voxel0=0):
+    """Head gradients of the per-voxel negative ELBO (unnormalised by sum(mask)).
+    Returns (sums, g_q [N,5], g_log_sigma [N,T], nll_kl [N,2])."""
+    x = _f32(x, "x", self.T)
+    N = x.numel() // self.T
+    q = _f32(q, "q", 5)
+    prior = _f32(prior, "prior", 5)
+    ls = _f32(log_sigma, "log_sigma", self.T)
+    mask = _f32(mask, "mask") if mask is not None else None
+    sums = torch.empty(3, dtype=torch.float64, device=x.device)
+    gq = torch.empty((N, 5), dtype=torch.float32, device=x.device)
+    gls = torch.empty((N, self.T), dtype=torch.float32, device=x.device)
+    nk = torch.empty((N, 2), dtype=torch.float32, device=x.device)
+    _lib.check(self.lib.qbold_elbo_bwd(self.handle, _ptr(x), _ptr(mask), _ptr(q), _ptr(prior), _ptr(ls),
+                                       int(S), int(K), int(seed), int(voxel0), _ptr(gq), _ptr(gls),
+                                       _ptr(nk), _ptr(sums), _ptr(self._workspace()), N, _stream()),
+               "qbold_elbo_bwd")
+    return sums, gq, gls, nk
