@@ -91,6 +91,10 @@ int qbold_ctx_se_idx(const qbold_ctx* ctx);
 int qbold_ctx_taus(const qbold_ctx* ctx, float* host_out);
 int qbold_ctx_set_tissue_mode(qbold_ctx* ctx, int mode);
 int qbold_ctx_tissue_mode(const qbold_ctx* ctx);
+/* Gradient of the tissue integral: 1 (default) = TensorFlow's autodiff value, the J1-kernel
+ * Simpson sum over all 129 nodes; 0 = the exact derivative of the float32 forward value, in which
+ * node 0 is flat.  They differ by 1.95e-3 * x. */
+int qbold_ctx_set_grad_node0(qbold_ctx* ctx, int on);
 /* Host-side evaluation of the uploaded table (for tests): F(x) and dF/dx, HOST arrays. */
 int qbold_ctx_table_eval(const qbold_ctx* ctx, const float* host_x, float* host_F, float* host_dF,
                          int64_t n);
@@ -220,6 +224,32 @@ int qbold_elbo_bwd(const qbold_ctx* ctx, const float* x, const float* mask, cons
                    const float* prior, const float* log_sigma, int S, int K, uint64_t seed,
                    int64_t voxel0, float* g_q, float* g_log_sigma, float* nll_kl, double* sums,
                    void* workspace, int64_t N, void* stream);
+
+/* Encoder training (TensorFlow autodiff through create_encoder, model.py:122-223, in the Keras fit
+ * loops train.py:285-376 / :379-427).  `weights` is the canonical blob; `workspace` holds
+ * qbold_train_workspace_floats(shape, N) floats (saved activations + scratch).
+ *   stream_sel 1: pre-training stream (out_q = output 0, model.py:199), 2: fine-tuning stream
+ *   (out_q = second_net, out_log_sigma = sigma head before exp, model.py:208-214). */
+int64_t qbold_train_workspace_floats(const qbold_encoder_shape* shape, int64_t N);
+int qbold_encoder_train_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* weights,
+                            const float* x, int stream_sel, float* workspace, float* out_q,
+                            float* out_log_sigma, int64_t N, void* stream);
+/* g_q [N][5], g_log_sigma [N][T] (stream 2; may be NULL): gradients of the loss with respect to
+ * the head outputs.  sums: DEVICE double[3] whose [2] is sum(mask) -- the head gradients are
+ * divided by it (NULL: already normalised).  grad: canonical layout, overwritten. */
+int qbold_encoder_train_bwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* weights,
+                            int stream_sel, float* workspace, const float* g_q, const float* g_log_sigma,
+                            const double* sums, float* grad, int64_t N, void* stream);
+/* synthetic_data_loss (model.py:449-514; use_mvg, no r2p / inverse-gamma terms) per voxel and its
+ * gradient: y_true rows of ld_y floats (OEF, DBV first), q [N][5] -> loss_v [N] (may be NULL),
+ * g_q [N][5] = scale * d loss_v / d q. */
+int qbold_synth_loss_bwd(const qbold_ctx* ctx, const float* y_true, int ld_y, const float* q, float* g_q,
+                         float* loss_v, float scale, int64_t N, void* stream);
+/* One tfa.optimizers.AdamW step (train.py:308-310, 382-385) on a flat blob: decoupled decay
+ * var -= weight_decay * var, Keras Adam moments and bias correction at step t >= 1, eps 1e-7. */
+int qbold_adamw_step(const qbold_ctx* ctx, float* params, const float* grads, float* m, float* v,
+                     int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay,
+                     int64_t t, void* stream);
 
 #ifdef __cplusplus
 }

@@ -101,7 +101,7 @@ DEFAULT_PARAMS = dict(tr="3.0", ti="1.21", te="0.074", tau_start="-0.016", tau_e
 class Oracle:
     def __init__(self, precision="f32", params=None, full_model=True, include_blood=True,
                  multi_image_normalisation=False, predict_log_data=False, student_t_df=None,
-                 threads=None):
+                 threads=None, node0_zero=False):
         build()
         assert precision in ("f32", "f64")
         self.lib = C.CDLL(os.path.join(_BUILD, f"libqbold_oracle_{precision}.so"))
@@ -132,6 +132,8 @@ class Oracle:
         L.qbo_synthetic_data_loss.restype = C.c_double
         if threads:
             L.qbo_set_threads(int(threads))
+        # NB process-global in the C library: use one policy per precision within a test session
+        L.qbo_set_node0_zero(int(bool(node0_zero)))
         t = np.zeros(QBO_MAX_T, self.dtype)
         self.T = L.qbo_taus(C.byref(self.phys), self._p(t))
         self.taus = t[:self.T].copy()

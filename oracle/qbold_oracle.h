@@ -68,6 +68,8 @@ typedef struct {
 
 int qbo_real_bytes(void);
 void qbo_set_threads(int n);
+/* float64 test hook: evaluate F(x) with Simpson node 0 removed (float32 reference semantics). */
+void qbo_set_node0_zero(int on);
 
 /* tf.math.special.bessel_j0 for float32 = Eigen generic_j0<float> = Cephes j0f. */
 real qbo_j0(real x);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "qbold_ctx_taus": (C.c_int, [_P, _P]),
     "qbold_ctx_set_tissue_mode": (C.c_int, [_P, C.c_int]),
     "qbold_ctx_tissue_mode": (C.c_int, [_P]),
+    "qbold_ctx_set_grad_node0": (C.c_int, [_P, C.c_int]),
     "qbold_ctx_table_eval": (C.c_int, [_P, _P, _P, _P, _I64]),
     "qbold_signal_fwd": (C.c_int, [_P, _P, _P, _I64, _P]),
     "qbold_signal_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _P]),
@@ -74,6 +75,13 @@ SIGNATURES = {
                                  _P, _P, _P, _I64, _P]),
     "qbold_elbo_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _U64, _I64, _P, _P, _P, _P,
                                  _P, _I64, _P]),
+    "qbold_train_workspace_floats": (_I64, [C.POINTER(EncoderShape), _I64]),
+    "qbold_encoder_train_fwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, C.c_int, _P, _P, _P, _I64, _P]),
+    "qbold_encoder_train_bwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, C.c_int, _P, _P, _P, _P, _P,
+                                          _I64, _P]),
+    "qbold_synth_loss_bwd": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_float, _I64, _P]),
+    "qbold_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _I64, C.c_double, C.c_double, C.c_double,
+                                   C.c_double, C.c_double, _I64, _P]),
     "qbold_vi_fwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, _P, _P, C.c_int, C.c_int,
                                _U64, _I64, _P, _P, _P, _P, _I64, _P]),
 }

@@ -165,6 +165,7 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
     }
     static const Simpson simpson;
     d.dF_node0 = (float)simpson.node0_slope();
+    ctx->dF_node0_ref = d.dF_node0;
     std::vector<double> f(QB_TAB_SEG + 1), g(QB_TAB_SEG + 1);
     for (int i = 0; i <= QB_TAB_SEG; ++i) {
         f[i] = simpson.F(i * h);
@@ -221,6 +222,11 @@ extern "C" int qbold_ctx_set_tissue_mode(qbold_ctx* ctx, int mode) {
     QB_REQUIRE(mode == QBOLD_TISSUE_TABLE || mode == QBOLD_TISSUE_LITERAL,
                "qbold_ctx_set_tissue_mode: unknown mode");
     ctx->dev.tissue_mode = mode;
+    return QBOLD_OK;
+}
+extern "C" int qbold_ctx_set_grad_node0(qbold_ctx* ctx, int on) {
+    QB_REQUIRE(ctx, "qbold_ctx_set_grad_node0: null ctx");
+    ctx->dev.dF_node0 = on ? ctx->dF_node0_ref : 0.0f;
     return QBOLD_OK;
 }
 extern "C" int qbold_ctx_tissue_mode(const qbold_ctx* ctx) {

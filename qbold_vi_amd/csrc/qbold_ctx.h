@@ -18,6 +18,7 @@ struct qbold_ctx {
     float4* d_tab = nullptr;        // device copy of the F(x) cubic table
     std::vector<float> h_tab;       // host copy (4 floats per segment)
     int num_cus = 256;
+    float dF_node0_ref = 0.0f;      // TF-gradient slope of Simpson node 0 (see qbold_ctx_set_grad_node0)
 };
 
 namespace qb {

@@ -1,0 +1,491 @@
+// train_kernels.hip -- encoder training: forward with saved activations, backward (data and
+// weight gradients), the pre-training loss gradient and the AdamW update.
+//
+// Reference: the Keras fit loops of train.py (:285-376 fine-tuning, :379-427 pre-training) with
+// tfa.optimizers.AdamW; TensorFlow autodiff through create_encoder (model.py:122-223) for voxel
+// batches (3x3x1 convolutions = their centre tap).
+//
+// Unlike the inference kernels these are plain row-major [N][64] float32 GEMMs on the exact-f32
+// matrix instruction (v_mfma_f32_16x16x4_f32), one layer per launch, activations saved to HBM:
+// training steps are 190-256 k voxels in the reference (train.py:68,103), ~1 GB of activations,
+// and HBM-bound at a few ms per step -- off the voxel-ELBO headline path, correctness first.
+#include "canon_layout.h"
+#include "encoder_core.h"
+#include "qbold_ctx.h"
+
+namespace qb {
+int check_encoder_shape(const qbold_ctx* ctx, const qbold_encoder_shape* s);
+}  // namespace qb
+
+namespace {
+
+using qb::f32x4;
+#define QB_MFMA16F(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int kLd = 64;        // row stride of every activation / delta tensor
+constexpr int kWs = 65;        // LDS row stride of a staged weight matrix
+
+enum { ACT_NONE = 0, ACT_RELU = 1 };
+
+// Y[N][ldy] (cols < ndim) = act(X[N][ldx] (cols < kdim) . W + b), W given as Wl[k][j]:
+//   trans = 0: Wl[k][j] = W[k * ldw + j]   (forward, W canonical [in][out])
+//   trans = 1: Wl[k][j] = W[j * ldw + k]   (backward-data: dX = dY . W^T)
+// accum: Y += ...;  mask: result *= (mask[v][j] > 0)  (relu backward)
+__global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, int ldx, int kdim,
+                                                 const float* __restrict__ W, int ldw, int trans,
+                                                 const float* __restrict__ b, float* __restrict__ Y,
+                                                 int ldy, int ndim, int act, int accum,
+                                                 const float* __restrict__ mask, int ldm, int64_t N) {
+    __shared__ float Wl[64 * kWs];
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int k = e >> 6, j = e & 63;
+        float v = 0.0f;
+        if (k < kdim && j < ndim) v = trans ? W[j * ldw + k] : W[k * ldw + j];
+        Wl[k * kWs + j] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int64_t ntile = (N + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
+        const int64_t v0 = tile * 16;
+        const int64_t va = v0 + i < N ? v0 + i : N - 1;
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const float* xr = X + va * ldx;
+        for (int s = 0; s < 16; ++s) {
+            const int k = 4 * s + g;
+            const float a = k < kdim ? xr[k] : 0.0f;
+            const float* wr = Wl + k * kWs + i;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(a, wr[16 * m], acc[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int j = 16 * m + i;
+            if (j >= ndim) continue;
+            const float bj = b ? b[j] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t v = v0 + 4 * g + r;
+                if (v >= N) continue;
+                float y = acc[m][r] + bj;
+                if (act == ACT_RELU) y = fmaxf(y, 0.0f);
+                if (mask) y = mask[v * ldm + j] > 0.0f ? y : 0.0f;
+                if (accum) y += Y[v * ldy + j];
+                Y[v * ldy + j] = y;
+            }
+        }
+    }
+}
+
+// partial[blk][64*64 + 64]: dW[i][j] = sum_v X[v][i] D[v][j] over this block's voxels, then db[j]
+__global__ __launch_bounds__(256) void xtd_kernel(const float* __restrict__ X, int ldx, int kdim,
+                                                  const float* __restrict__ D, int ldd, int ndim,
+                                                  float* __restrict__ partial, int64_t N) {
+    __shared__ float red[64 * 64 + 64];
+    for (int e = threadIdx.x; e < 64 * 64 + 64; e += 256) red[e] = 0.0f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float dbsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int64_t nstep = (N + 3) / 4;  // 4 voxels per MFMA k-step
+    for (int64_t st = (int64_t)blockIdx.x * 4 + wave; st < nstep; st += (int64_t)gridDim.x * 4) {
+        const int64_t v = st * 4 + g;
+        const bool ok = v < N;
+        float xa[4], dd[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int c = 16 * m + i;
+            xa[m] = (ok && c < kdim) ? X[v * ldx + c] : 0.0f;
+            dd[m] = (ok && c < ndim) ? D[v * ldd + c] : 0.0f;
+            dbsum[m] += dd[m];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] = QB_MFMA16F(xa[a], dd[c], acc[a][c]);
+    }
+    // D[i][j] layout: col j = lane & 15, rows 4g + r.  The four waves add their tiles one after
+    // the other (fixed order: bitwise reproducible gradients, no float atomics).
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        red[(16 * a + 4 * g + r) * 64 + 16 * c + i] += acc[a][c][r];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float sm = dbsum[m];
+                sm += __shfl_xor(sm, 16, 64);
+                sm += __shfl_xor(sm, 32, 64);
+                if (g == 0) red[64 * 64 + 16 * m + i] += sm;
+            }
+        }
+        __syncthreads();
+    }
+    float* out = partial + (int64_t)blockIdx.x * (64 * 64 + 64);
+    for (int e = threadIdx.x; e < 64 * 64 + 64; e += 256) out[e] = red[e];
+}
+
+// dW[i * ldw + j] (+)= sum_blk partial[blk][i][j]; db[j] (+)= sum_blk partial[blk][4096 + j]
+__global__ void slab_reduce_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dW,
+                                   int ldw, int kdim, int ndim, float* __restrict__ db, int accum) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 64 * 64 + 64) return;
+    double a = 0.0;
+    for (int bk = 0; bk < nblk; ++bk) a += (double)partial[(int64_t)bk * (64 * 64 + 64) + e];
+    if (e < 64 * 64) {
+        const int i = e >> 6, j = e & 63;
+        if (i < kdim && j < ndim) dW[i * ldw + j] = (accum ? dW[i * ldw + j] : 0.0f) + (float)a;
+    } else {
+        const int j = e - 64 * 64;
+        if (db && j < ndim) db[j] = (accum ? db[j] : 0.0f) + (float)a;
+    }
+}
+
+// normalise_data into a [N][64] slot (model.py:97-113)
+__global__ void normalise64_kernel(QbDev c, const float* __restrict__ x, float* __restrict__ out,
+                                   int64_t N) {
+    const int T = c.T, se = c.se_idx;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < N;
+         v += (int64_t)gridDim.x * blockDim.x) {
+        const float* xv = x + v * T;
+        float den;
+        if (c.multi_norm)
+            den = (qb::clampf_(xv[se - 1], 1e-2f, 1e8f) + qb::clampf_(xv[se], 1e-2f, 1e8f) +
+                   qb::clampf_(xv[se + 1], 1e-2f, 1e8f)) / 3.0f;
+        else
+            den = qb::clampf_(xv[se], 1e-2f, 1e8f);
+        for (int t = 0; t < T; ++t) out[v * kLd + t] = logf(qb::clampf_(xv[t], 1e-2f, 1e8f) / den);
+    }
+}
+
+// gate: gl <- g = sigmoid(gl + offset);  bout = skip (1 - g) + r g          (model.py:167-170)
+__global__ void gate_fwd_kernel(float* __restrict__ gl, const float* __restrict__ skip,
+                                const float* __restrict__ r, float* __restrict__ bout, float offset,
+                                int U, int G, int64_t N) {
+    const int64_t total = N * kLd;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e & 63);
+        const int64_t v = e >> 6;
+        float o = 0.0f;
+        if (j < U) {
+            const float gate = 1.0f / (1.0f + expf(-(gl[v * kLd + (G == 1 ? 0 : j)] + offset)));
+            o = skip[e] * (1.0f - gate) + r[e] * gate;
+        }
+        bout[e] = o;
+    }
+}
+// gate backward: d_b in/out -> d_skip_pre (masked by skip > 0), d_r, d_gl (channelwise or summed)
+__global__ void gate_bwd_kernel(const float* __restrict__ d_b, const float* __restrict__ gl,
+                                const float* __restrict__ skip, const float* __restrict__ r,
+                                float* __restrict__ d_skip_pre, float* __restrict__ d_r,
+                                float* __restrict__ d_gl, float offset, int U, int G, int64_t N) {
+    for (int64_t v = blockIdx.x * (int64_t)(blockDim.x / 64) + (threadIdx.x >> 6); v < N;
+         v += (int64_t)gridDim.x * (blockDim.x / 64)) {
+        const int j = threadIdx.x & 63;
+        const int64_t e = v * kLd + j;
+        float dgl = 0.0f, ds = 0.0f, dr = 0.0f;
+        if (j < U) {
+            const float gate = 1.0f / (1.0f + expf(-(gl[v * kLd + (G == 1 ? 0 : j)] + offset)));
+            const float db = d_b[e];
+            ds = skip[e] > 0.0f ? db * (1.0f - gate) : 0.0f;
+            dr = db * gate;
+            dgl = db * (r[e] - skip[e]) * gate * (1.0f - gate);
+        }
+        d_skip_pre[e] = ds;
+        d_r[e] = dr;
+        if (G == 1) {  // shared gate: sum the contributions of all units
+            dgl = qb::wave_sum(dgl);
+            d_gl[e] = j == 0 ? dgl : 0.0f;
+        } else {
+            d_gl[e] = dgl;
+        }
+    }
+}
+
+// out = in * (ref > 0): the relu adjoint
+__global__ void mask_mul_kernel(const float* __restrict__ in, const float* __restrict__ ref,
+                                float* __restrict__ out, int64_t n) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * blockDim.x)
+        out[e] = ref[e] > 0.0f ? in[e] : 0.0f;
+}
+
+__global__ void relu_copy_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * blockDim.x)
+        out[e] = fmaxf(in[e], 0.0f);
+}
+
+// synthetic_data_loss (model.py:449-514) and its gradient: loss_v = -log p(y_true; q)
+__global__ void nlogp_bwd_kernel(const float* __restrict__ y_true, int ldy, const float* __restrict__ q,
+                                 float* __restrict__ g_q, int ldg, float* __restrict__ loss, float scale,
+                                 int64_t N) {
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < N;
+         v += (int64_t)gridDim.x * blockDim.x) {
+        float p[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) p[k] = q[v * 5 + k];
+        const qb::LogitMvn m = qb::make_mvn(p);
+        const qb::LogitObs o = qb::make_obs(y_true[v * ldy], y_true[v * ldy + 1]);
+        const float r0 = o.l0 - m.mu_o, r1 = o.l1 - m.mu_d;
+        const float w0 = r0 * m.i_so, w1 = r1 * m.i_sd + r0 * m.i_bl;
+        if (loss) loss[v] = 1.8378770664093453f + (m.s_o + m.s_d) + 0.5f * (w0 * w0 + w1 * w1) + o.jac;
+        const float th1 = (m.s_o + 1.0f) * (1.0f / 3.0f), th3 = (m.s_d + 1.0f) * (1.0f / 3.0f);
+        const float th4 = m.c * 7.38905609893065f;
+        float* g = g_q + v * ldg;
+        g[0] = scale * -(w0 * m.i_so + w1 * m.i_bl);
+        g[1] = scale * (1.0f - w0 * w0 - w1 * r0 * m.i_bl) * 3.0f * (1.0f - th1 * th1);
+        g[2] = scale * -(w1 * m.i_sd);
+        g[3] = scale * (1.0f - w1 * w1) * 3.0f * (1.0f - th3 * th3);
+        g[4] = scale * (w1 * -r0 * m.i_so * m.i_sd) * 0.1353352832366127f * (1.0f - th4 * th4);
+    }
+}
+
+// copy g_q [N][5] and g_ls [N][T] into one [N][64] delta tensor (cols 0-4, 5..5+T-1), scaled
+__global__ void head_delta_kernel(const float* __restrict__ g_q, const float* __restrict__ g_ls, int T,
+                                  const double* __restrict__ sums, float* __restrict__ d, int64_t N) {
+    const float scale = sums ? (float)(1.0 / sums[2]) : 1.0f;  // 1 / sum(mask)
+    const int64_t total = N * kLd;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e & 63);
+        const int64_t v = e >> 6;
+        float o = 0.0f;
+        if (j < 5) o = g_q[v * 5 + j] * scale;
+        else if (g_ls && j < 5 + T) o = g_ls[v * T + j - 5] * scale;
+        d[e] = o;
+    }
+}
+
+// tfa.optimizers.AdamW step (decoupled weight decay; Keras Adam with epsilon 1e-7):
+//   var -= wd * var;  m,v update;  var -= lr * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
+__global__ void adamw_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, float lr_t, float b1, float b2, float eps,
+                             float wd) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const float ge = g[e];
+        const float me = b1 * m[e] + (1.0f - b1) * ge;
+        const float ve = b2 * v[e] + (1.0f - b2) * ge * ge;
+        m[e] = me;
+        v[e] = ve;
+        float we = w[e];
+        we -= wd * we;
+        we -= lr_t * me / (sqrtf(ve) + eps);
+        w[e] = we;
+    }
+}
+
+struct Launcher {
+    const qbold_ctx* ctx;
+    hipStream_t s;
+    int64_t N;
+    int grid() const {
+        int64_t nb = (N + 63) / 64;
+        int64_t cap = (int64_t)ctx->num_cus * 8;
+        return (int)(nb < cap ? (nb > 0 ? nb : 1) : cap);
+    }
+    void xw(const float* X, int ldx, int kdim, const float* W, int ldw, int trans, const float* b,
+            float* Y, int ndim, int act, int accum, const float* mask) const {
+        hipLaunchKernelGGL(xw_kernel, dim3(grid()), dim3(256), 0, s, X, ldx, kdim, W, ldw, trans, b, Y,
+                           kLd, ndim, act, accum, mask, kLd, N);
+    }
+    // dW (+)= X^T D, db (+)= sum D
+    void xtd(const float* X, int kdim, const float* D, int ndim, float* partial, int nblk, float* dW,
+             int ldw, float* db, int accum) const {
+        hipLaunchKernelGGL(xtd_kernel, dim3(nblk), dim3(256), 0, s, X, kLd, kdim, D, kLd, ndim, partial, N);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64 + 255) / 256), dim3(256), 0, s, partial,
+                           nblk, dW, ldw, kdim, ndim, db, accum);
+    }
+    int ew() const {
+        int64_t nb = (N * kLd + 255) / 256;
+        int64_t cap = (int64_t)ctx->num_cus * 8;
+        return (int)(nb < cap ? (nb > 0 ? nb : 1) : cap);
+    }
+};
+
+constexpr int kSlabBlocks = 128;
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// activation slots (each [N][64] floats):
+//   0: n   1: h   then per block l (base 2 + 5 l): skip, t, r, gl (gate logits), bout
+//   stream 1 uses: 0: n, 1: h, 2 + l: a_l
+// ---------------------------------------------------------------------------------------------
+extern "C" int64_t qbold_train_workspace_floats(const qbold_encoder_shape* shape, int64_t N) {
+    if (!shape || N < 0) return QBOLD_ERR_INVALID;
+    const int64_t slots = 2 + 5 * (int64_t)shape->L + 5;  // activations + 5 delta scratch tensors
+    return slots * N * kLd + (int64_t)kSlabBlocks * (64 * 64 + 64);
+}
+
+extern "C" int qbold_encoder_train_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
+                                       const float* w, const float* x, int stream_sel, float* ws,
+                                       float* out_q, float* out_log_sigma, int64_t N, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    int rc = qb::check_encoder_shape(ctx, shape);
+    if (rc) return rc;
+    QB_REQUIRE(N > 0 && w && x && ws && out_q, "qbold_encoder_train_fwd: bad argument");
+    QB_REQUIRE(stream_sel == 1 || stream_sel == 2, "qbold_encoder_train_fwd: stream must be 1 or 2");
+    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating);
+    const int T = c.T, U = c.U, L = c.L, G = c.G;
+    Launcher k{ctx, (hipStream_t)stream, N};
+    auto slot = [&](int i) { return ws + (int64_t)i * N * kLd; };
+    hipLaunchKernelGGL(normalise64_kernel, dim3(k.grid()), dim3(256), 0, k.s, ctx->dev, x, slot(0), N);
+    k.xw(slot(0), kLd, T, w + c.W0, U, 0, w + c.b0, slot(1), U, ACT_RELU, 0, nullptr);
+    const float* cur = slot(1);
+    float* head = slot(2 + 5 * L);  // scratch slot for the head output [N][64]
+    if (stream_sel == 1) {
+        for (int l = 0; l < L; ++l) {
+            const float* wb = w + c.blk0 + l * c.blk_stride;
+            k.xw(cur, kLd, U, wb + c.Wc, U, 0, wb + c.bc, slot(2 + l), U, ACT_RELU, 0, nullptr);
+            cur = slot(2 + l);
+        }
+        k.xw(cur, kLd, U, w + c.Wf, 5, 0, w + c.bf, head, 5, ACT_NONE, 0, nullptr);
+    } else {
+        for (int l = 0; l < L; ++l) {
+            const float* wb = w + c.blk0 + l * c.blk_stride;
+            float* skip = slot(2 + 5 * l), *t = slot(3 + 5 * l), *r = slot(4 + 5 * l);
+            float* gl = slot(5 + 5 * l), *bout = slot(6 + 5 * l);
+            k.xw(cur, kLd, U, wb + c.Wc, U, 0, wb + c.bc, skip, U, ACT_RELU, 0, nullptr);
+            // relu(b) feeds the first residual conv; block 0's input h is already >= 0
+            hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, cur, bout, N * kLd);
+            k.xw(bout, kLd, U, wb + c.Wr1, U, 0, wb + c.br1, t, U, ACT_RELU, 0, nullptr);
+            k.xw(t, kLd, U, wb + c.Wr2, U, 0, wb + c.br2, r, U, ACT_NONE, 0, nullptr);
+            k.xw(r, kLd, U, wb + c.Wg, G, 0, wb + c.bg, gl, G, ACT_NONE, 0, nullptr);
+            hipLaunchKernelGGL(gate_fwd_kernel, dim3(k.ew()), dim3(256), 0, k.s, gl, skip, r, bout,
+                               shape->gate_offset, U, G, N);
+            cur = bout;
+        }
+        // merged head: cols 0-4 = Wf, 5.. = Ws  (two launches into one [N][64] tensor)
+        k.xw(cur, kLd, U, w + c.Wf, 5, 0, w + c.bf, head, 5, ACT_NONE, 0, nullptr);
+    }
+    QB_HIP(hipGetLastError());
+    // unpack the head: q [N][5] (and log sigma [N][T] through a second GEMM straight into place)
+    QB_HIP(hipMemcpy2DAsync(out_q, 5 * sizeof(float), head, kLd * sizeof(float), 5 * sizeof(float), N,
+                            hipMemcpyDeviceToDevice, k.s));
+    if (stream_sel == 2 && out_log_sigma) {
+        hipLaunchKernelGGL(xw_kernel, dim3(k.grid()), dim3(256), 0, k.s, cur, kLd, U, w + c.Ws, T, 0,
+                           w + c.bs, out_log_sigma, T, T, ACT_NONE, 0, (const float*)nullptr, 0, N);
+        QB_HIP(hipGetLastError());
+    }
+    return QBOLD_OK;
+}
+
+// g_head_q [N][5], g_head_ls [N][T] (stream 2 only; may be NULL), sums: device double[3] whose
+// third entry is sum(mask) (NULL = gradients already normalised).  grad: canonical layout, overwritten.
+extern "C" int qbold_encoder_train_bwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
+                                       const float* w, int stream_sel, float* ws, const float* g_q,
+                                       const float* g_ls, const double* sums, float* grad, int64_t N,
+                                       void* stream) {
+    QB_NEED_DEVICE(ctx);
+    int rc = qb::check_encoder_shape(ctx, shape);
+    if (rc) return rc;
+    QB_REQUIRE(N > 0 && w && ws && g_q && grad, "qbold_encoder_train_bwd: bad argument");
+    QB_REQUIRE(stream_sel == 1 || stream_sel == 2, "qbold_encoder_train_bwd: stream must be 1 or 2");
+    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating);
+    const int T = c.T, U = c.U, L = c.L, G = c.G;
+    Launcher k{ctx, (hipStream_t)stream, N};
+    auto slot = [&](int i) { return ws + (int64_t)i * N * kLd; };
+    const int base = 2 + 5 * L;
+    float* dA = slot(base), *dB = slot(base + 1), *dC = slot(base + 2), *dD = slot(base + 3),
+          *dE = slot(base + 4);
+    float* partial = ws + (int64_t)(base + 5) * N * kLd;
+    QB_HIP(hipMemsetAsync(grad, 0, sizeof(float) * c.total, k.s));
+    // head delta [N][64]: cols 0-4 = g_q, 5.. = g_ls, scaled by 1 / sum(mask)
+    hipLaunchKernelGGL(head_delta_kernel, dim3(k.ew()), dim3(256), 0, k.s, g_q,
+                       stream_sel == 2 ? g_ls : nullptr, T, sums, dA, N);
+    const float* last = stream_sel == 1 ? slot(2 + L - 1) : slot(6 + 5 * (L - 1));
+    // dWf, dbf (and dWs, dbs), d_last = g_q Wf^T (+ g_ls Ws^T)
+    k.xtd(last, U, dA, 5, partial, kSlabBlocks, grad + c.Wf, 5, grad + c.bf, 0);
+    k.xw(dA, kLd, 5, w + c.Wf, 5, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
+    if (stream_sel == 2 && g_ls) {
+        k.xtd(last, U, dA + 5, T, partial, kSlabBlocks, grad + c.Ws, T, grad + c.bs, 0);
+        k.xw(dA + 5, kLd, T, w + c.Ws, T, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
+    }
+    // dB = gradient wrt the last activation tensor
+    if (stream_sel == 1) {
+        for (int l = L - 1; l >= 0; --l) {
+            const float* wb = w + c.blk0 + l * c.blk_stride;
+            float* gb = grad + c.blk0 + l * c.blk_stride;
+            const float* a_out = slot(2 + l);
+            const float* a_in = l == 0 ? slot(1) : slot(2 + l - 1);
+            // through the relu: dC = dB * (a_out > 0)
+            hipLaunchKernelGGL(mask_mul_kernel, dim3(k.ew()), dim3(256), 0, k.s, dB, a_out, dC, N * kLd);
+            k.xtd(a_in, U, dC, U, partial, kSlabBlocks, gb + c.Wc, U, gb + c.bc, 0);
+            k.xw(dC, kLd, U, wb + c.Wc, U, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
+        }
+    } else {
+        for (int l = L - 1; l >= 0; --l) {
+            const float* wb = w + c.blk0 + l * c.blk_stride;
+            float* gb = grad + c.blk0 + l * c.blk_stride;
+            const float* skip = slot(2 + 5 * l), *t = slot(3 + 5 * l), *r = slot(4 + 5 * l);
+            const float* gl = slot(5 + 5 * l);
+            const float* b_in = l == 0 ? slot(1) : slot(6 + 5 * (l - 1));
+            // dB = d b_out.  dC = d skip_pre, dD = d r, dE = d gate logits
+            hipLaunchKernelGGL(gate_bwd_kernel, dim3(k.grid()), dim3(256), 0, k.s, dB, gl, skip, r, dC, dD,
+                               dE, shape->gate_offset, U, G, N);
+            // gating conv: dWg = r^T dE; d r += dE Wg^T
+            k.xtd(r, U, dE, G, partial, kSlabBlocks, gb + c.Wg, G, gb + c.bg, 0);
+            k.xw(dE, kLd, G, wb + c.Wg, G, 1, nullptr, dD, U, ACT_NONE, 1, nullptr);
+            // second residual conv: dWr2 = t^T dD; d t_pre = (dD Wr2^T) * (t > 0)  -> dE
+            k.xtd(t, U, dD, U, partial, kSlabBlocks, gb + c.Wr2, U, gb + c.br2, 0);
+            k.xw(dD, kLd, U, wb + c.Wr2, U, 1, nullptr, dE, U, ACT_NONE, 0, t);
+            // first residual conv: input relu(b_in): dWr1 = relu(b_in)^T dE; d b_in = (dE Wr1^T) * (b_in > 0)
+            hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, b_in, dD, N * kLd);
+            k.xtd(dD, U, dE, U, partial, kSlabBlocks, gb + c.Wr1, U, gb + c.br1, 0);
+            k.xw(dE, kLd, U, wb + c.Wr1, U, 1, nullptr, dB, U, ACT_NONE, 0, b_in);
+            // skip conv: dWc = b_in^T dC; d b_in += dC Wc^T
+            k.xtd(b_in, U, dC, U, partial, kSlabBlocks, gb + c.Wc, U, gb + c.bc, 0);
+            k.xw(dC, kLd, U, wb + c.Wc, U, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
+        }
+    }
+    // first layer: delta_pre = dB * (h > 0); dW0 = n^T delta_pre
+    hipLaunchKernelGGL(mask_mul_kernel, dim3(k.ew()), dim3(256), 0, k.s, dB, slot(1), dC, N * kLd);
+    k.xtd(slot(0), T, dC, U, partial, kSlabBlocks, grad + c.W0, U, grad + c.b0, 0);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
+// synthetic_data_loss (model.py:449-514, use_mvg, no r2p / inverse-gamma terms) and its gradient
+// with respect to q: loss_v [N] (may be NULL), g_q [N][5] = scale * d loss_v / d q.
+extern "C" int qbold_synth_loss_bwd(const qbold_ctx* ctx, const float* y_true, int ld_y, const float* q,
+                                    float* g_q, float* loss_v, float scale, int64_t N, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    QB_REQUIRE(N > 0 && y_true && q && g_q && ld_y >= 2, "qbold_synth_loss_bwd: bad argument");
+    int64_t nb = (N + 255) / 256;
+    int64_t cap = (int64_t)ctx->num_cus * 8;
+    hipLaunchKernelGGL(nlogp_bwd_kernel, dim3((int)(nb < cap ? nb : cap)), dim3(256), 0,
+                       (hipStream_t)stream, y_true, ld_y, q, g_q, 5, loss_v, scale, N);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
+// One tfa.optimizers.AdamW step on a flat parameter blob (train.py:308-310, 382-385):
+// decoupled weight decay `wd` (already scheduled), Keras-Adam bias correction at step t >= 1.
+extern "C" int qbold_adamw_step(const qbold_ctx* ctx, float* params, const float* grads, float* m,
+                                float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                                double weight_decay, int64_t t, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    QB_REQUIRE(n > 0 && params && grads && m && v && t >= 1, "qbold_adamw_step: bad argument");
+    const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
+    int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(adamw_kernel, dim3((int)(nb < 1024 ? nb : 1024)), dim3(256), 0, (hipStream_t)stream,
+                       params, grads, m, v, n, (float)lr_t, (float)beta1, (float)beta2, (float)eps,
+                       (float)weight_decay);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}

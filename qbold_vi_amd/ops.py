@@ -153,6 +153,9 @@ class Context:
         mode = {"table": 0, "literal": 1}.get(mode, mode)
         _lib.check(self.lib.qbold_ctx_set_tissue_mode(self.handle, int(mode)), "set_tissue_mode")
 
+    def set_grad_node0(self, on):
+        _lib.check(self.lib.qbold_ctx_set_grad_node0(self.handle, int(bool(on))), "set_grad_node0")
+
     def table_eval(self, x):
         x = np.ascontiguousarray(x, np.float32)
         F = np.empty_like(x)
@@ -392,3 +395,71 @@ def elbo_bwd(self, x, mask, q, prior, log_sigma, S=1, K=70, seed=1, voxel0=0):
                                        _ptr(nk), _ptr(sums), _ptr(self._workspace()), N, _stream()),
                "qbold_elbo_bwd")
     return sums, gq, gls, nk
+
+
+class TrainState:
+    """Flat AdamW state of one encoder + the activation workspace of the training kernels."""
+
+    def __init__(self, ctx, weights):
+        self.ctx = ctx
+        self.weights = weights
+        n = weights.num_params
+        dev = weights.flat.device
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.step = 0
+        self._ws = None
+        self._ws_n = 0
+
+    def workspace(self, N):
+        if self._ws is None or self._ws_n < N:
+            n = int(self.ctx.lib.qbold_train_workspace_floats(C.byref(self.weights.shape), int(N)))
+            self._ws = torch.empty(n, dtype=torch.float32, device=self.weights.flat.device)
+            self._ws_n = N
+        return self._ws
+
+    def forward(self, x, stream_sel):
+        """Training forward (activations saved).  Returns (q [N,5], log_sigma [N,T] or None)."""
+        ctx = self.ctx
+        x = _f32(x, "x", ctx.T)
+        N = x.numel() // ctx.T
+        q = torch.empty((N, 5), dtype=torch.float32, device=x.device)
+        ls = torch.empty((N, ctx.T), dtype=torch.float32, device=x.device) if stream_sel == 2 else None
+        _lib.check(ctx.lib.qbold_encoder_train_fwd(ctx.handle, C.byref(self.weights.shape),
+                                                   _ptr(self.weights.flat), _ptr(x), int(stream_sel),
+                                                   _ptr(self.workspace(N)), _ptr(q), _ptr(ls), N,
+                                                   _stream()), "qbold_encoder_train_fwd")
+        self._n = N
+        return q, ls
+
+    def backward(self, stream_sel, g_q, g_ls=None, sums=None):
+        """Fills self.grad (canonical layout) from the head gradients of the last forward()."""
+        ctx = self.ctx
+        _lib.check(ctx.lib.qbold_encoder_train_bwd(ctx.handle, C.byref(self.weights.shape),
+                                                   _ptr(self.weights.flat), int(stream_sel),
+                                                   _ptr(self._ws), _ptr(g_q), _ptr(g_ls), _ptr(sums),
+                                                   _ptr(self.grad), self._n, _stream()),
+                   "qbold_encoder_train_bwd")
+        return self.grad
+
+    def synth_loss_bwd(self, y_true, q):
+        """Pre-training loss (mean over voxels) and its head gradient (already divided by N)."""
+        ctx = self.ctx
+        y = _f32(y_true, "y_true")
+        ld = y.shape[-1]
+        N = q.shape[0]
+        gq = torch.empty((N, 5), dtype=torch.float32, device=q.device)
+        lv = torch.empty(N, dtype=torch.float32, device=q.device)
+        _lib.check(ctx.lib.qbold_synth_loss_bwd(ctx.handle, _ptr(y), int(ld), _ptr(q), _ptr(gq), _ptr(lv),
+                                                1.0 / N, N, _stream()), "qbold_synth_loss_bwd")
+        return lv, gq
+
+    def adamw(self, lr, weight_decay, beta1=0.9, beta2=0.999, eps=1e-7):
+        self.step += 1
+        _lib.check(self.ctx.lib.qbold_adamw_step(self.ctx.handle, _ptr(self.weights.flat), _ptr(self.grad),
+                                                 _ptr(self.m), _ptr(self.v), self.weights.num_params,
+                                                 float(lr), float(beta1), float(beta2), float(eps),
+                                                 float(weight_decay), self.step, _stream()),
+                   "qbold_adamw_step")
+        self.weights.mark_dirty()

@@ -12,8 +12,22 @@ def dev(a):
 
 @pytest.fixture(scope="module")
 def ctx(params):
+    """Gradients are checked as exact derivatives of the forward value: node 0's TF-autodiff slope
+    is switched off here (its value is pinned by test_signal_bwd_matches_oracle_jacobian)."""
     from qbold_vi_amd.ops import Context
-    return Context(params, full_model=True, include_blood=True)
+    c = Context(params, full_model=True, include_blood=True)
+    c.set_grad_node0(False)
+    return c
+
+
+@pytest.fixture(scope="module")
+def oracle64(params):
+    """float64 arithmetic, float32-reference semantics of the tissue integral (node 0 removed):
+    the function whose derivative the kernels compute, without float32 noise."""
+    from oracle.oracle import Oracle
+    o = Oracle("f64", params, node0_zero=True)
+    yield o
+    o.lib.qbo_set_node0_zero(0)   # the policy is process-global in the C library
 
 
 def kl_stopgrad(o, q_sample, q_logq, prior, zk):
@@ -66,15 +80,13 @@ def test_elbo_head_gradients_vs_oracle_fd(ctx, oracle32, oracle64, S, K):
         d[:, k] = h
         fd = (loss_v(q64 + d, ls) - loss_v(q64 - d, ls)) / (2 * h)
         scale = np.abs(fd).max() + 1e-3
-        # the float64 oracle keeps Simpson node 0 (+9.77e-4 x^2 in F): a few 1e-3 of systematic
-        # difference in the forward-model slope is expected
-        assert np.max(np.abs(gq[:, k] - fd)) / scale < 2e-2, (k, np.max(np.abs(gq[:, k] - fd)), scale)
+        assert np.max(np.abs(gq[:, k] - fd)) / scale < 2e-3, (k, np.max(np.abs(gq[:, k] - fd)), scale)
     for t in range(11):
         d = np.zeros_like(ls)
         d[:, t] = h
         fd = (loss_v(q64, ls + d) - loss_v(q64, ls - d)) / (2 * h)
         scale = np.abs(fd).max() + 1e-3
-        assert np.max(np.abs(gls[:, t] - fd)) / scale < 2e-2, t
+        assert np.max(np.abs(gls[:, t] - fd)) / scale < 2e-3, t
 
 
 def test_elbo_gradient_kl_only_is_exact(ctx, oracle32, oracle64):
@@ -100,3 +112,144 @@ def test_elbo_gradient_kl_only_is_exact(ctx, oracle32, oracle64):
         d[:, k] = 1e-5
         fd = (loss_v(q64 + d) - loss_v(q64 - d)) / 2e-5
         assert np.max(np.abs(gq[:, k] - fd)) < 2e-4 * (np.abs(fd).max() + 1.0), k
+
+
+def _weights(ctx, U=60, L=2, cw=True, seed=3):
+    from oracle.oracle import init_weights
+    from qbold_vi_amd.ops import EncoderWeights
+    w = init_weights(T=11, U=U, L=L, channelwise_gating=cw, seed=seed)
+    rng = np.random.default_rng(seed)
+    for k in ("b0", "bc", "br1", "br2", "bg", "bf"):
+        w[k] = (rng.standard_normal(w[k].shape) * 0.1).astype(np.float32)
+    w["gate_offset"] = -1.0   # keep the residual branch well alive for the gradient check
+    ew = EncoderWeights(ctx, 11, U, L, cw, -1.0).set_from_arrays(w)
+    return w, ew
+
+
+def _perturbed(w, direction, eps):
+    out = dict(w)
+    for k, d in direction.items():
+        out[k] = (w[k].astype(np.float64) + eps * d)
+    return out
+
+
+@pytest.mark.parametrize("U,L,cw", [(60, 2, True), (24, 1, False)])
+def test_training_forward_matches_inference_and_oracle(ctx, oracle32, U, L, cw):
+    from oracle.oracle import synth_inputs
+    from qbold_vi_amd.ops import TrainState
+    w, ew = _weights(ctx, U, L, cw)
+    x, _ = synth_inputs(777, seed=2, oracle=oracle32)
+    st = TrainState(ctx, ew)
+    q2, ls = st.forward(dev(x), 2)
+    w1, w2, wsg = oracle32.encoder_fwd(w, x)
+    assert np.abs(q2.cpu().numpy() - w2).max() < 2e-5
+    assert np.abs(ls.cpu().numpy() - np.log(wsg)).max() < 2e-5
+    q1, none = st.forward(dev(x), 1)
+    assert none is None and np.abs(q1.cpu().numpy() - w1).max() < 2e-5
+    o1, o2, sg = ctx.encoder_fwd(ew, dev(x))
+    assert torch.allclose(o2, q2, atol=2e-5) and torch.allclose(o1, q1, atol=2e-5)
+
+
+@pytest.mark.parametrize("U,L,cw", [(60, 2, True), (24, 1, False)])
+def test_pretraining_weight_gradient_directional(ctx, oracle32, oracle64, U, L, cw):
+    """d/dw mean_v -log p(y_v; q1(x_v; w)) against central differences of the float64 oracle along
+    random directions in weight space."""
+    from oracle.oracle import WEIGHT_NAMES, synth_inputs
+    from qbold_vi_amd.ops import TrainState
+    w, ew = _weights(ctx, U, L, cw)
+    n = 512
+    x, y = synth_inputs(n, seed=4, oracle=oracle32)
+    y3 = np.concatenate([y, y[:, :1]], -1).astype(np.float32)
+    st = TrainState(ctx, ew)
+    q1, _ = st.forward(dev(x), 1)
+    lv, gq = st.synth_loss_bwd(dev(y3), q1)
+    grad = st.backward(1, gq).cpu().numpy().astype(np.float64)
+    want_loss = oracle32.synthetic_data_loss(y3, oracle32.encoder_fwd(w, x)[0])
+    assert abs(float(lv.mean()) - want_loss) < 1e-4 * abs(want_loss) + 1e-5
+
+    def loss(ww):
+        return oracle64.synthetic_data_loss(y3, oracle64.encoder_fwd(ww, x)[0])
+
+    from qbold_vi_amd.ops import EncoderWeights
+    rng = np.random.default_rng(0)
+    for trial in range(4):
+        direction = {k: rng.standard_normal(w[k].shape) for k in WEIGHT_NAMES}
+        if trial == 1:   # only the stream-1 tensors
+            for k in ("Wr1", "br1", "Wr2", "br2", "Wg", "bg", "Ws", "bs"):
+                direction[k] *= 0
+        dflat = EncoderWeights(ctx, 11, U, L, cw, -1.0).set_from_arrays(
+            {k: direction[k].astype(np.float32) for k in WEIGHT_NAMES}).flat.cpu().numpy().astype(np.float64)
+        eps = 1e-4
+        fd = (loss(_perturbed(w, direction, eps)) - loss(_perturbed(w, direction, -eps))) / (2 * eps)
+        got = float(grad @ dflat)
+        assert abs(got - fd) < 5e-3 * (abs(fd) + 1e-2), (trial, got, fd)
+    # tensors that stream 1 does not touch get exactly zero gradient
+    g = EncoderWeights(ctx, 11, U, L, cw, -1.0)
+    g.flat.copy_(torch.as_tensor(grad, dtype=torch.float32))
+    ga = g.to_arrays()
+    for k in ("Wr1", "Wr2", "Wg", "Ws", "bs"):
+        assert np.all(ga[k] == 0)
+
+
+@pytest.mark.parametrize("U,L,cw", [(60, 2, True), (24, 1, False)])
+def test_finetune_weight_gradient_directional(ctx, oracle32, oracle64, U, L, cw):
+    """d/dw of the masked-mean negative ELBO through encoder stream 2 + sampling, along random
+    directions, against the float64 oracle (stop-gradient KL emulated as in kl_stopgrad)."""
+    from oracle.oracle import WEIGHT_NAMES, synth_inputs
+    from qbold_vi_amd.ops import EncoderWeights, TrainState
+    w, ew = _weights(ctx, U, L, cw)
+    n, S, K, seed = 256, 2, 6, 21
+    x, _ = synth_inputs(n, seed=6, oracle=oracle32)
+    rng = np.random.default_rng(1)
+    mask = (rng.uniform(size=n) > 0.2).astype(np.float32)
+    prior = oracle32.encoder_fwd(w, x)[0]
+    st = TrainState(ctx, ew)
+    q2, ls = st.forward(dev(x), 2)
+    sums, gq, gls, _ = ctx.elbo_bwd(dev(x), dev(mask), q2, dev(prior), ls, S, K, seed=seed)
+    grad = st.backward(2, gq, gls, sums).cpu().numpy().astype(np.float64)
+    zs = oracle32.philox_normals(seed, 0, 0, n, S)
+    zk = oracle32.philox_normals(seed, 1, 0, n, K)
+    q_fixed = oracle64.encoder_fwd(w, x)[1]
+
+    def loss(ww):
+        _, qq, sg = oracle64.encoder_fwd(ww, x)
+        e = oracle64.elbo(x, mask, qq, prior, sg, zs, zk)
+        kl = kl_stopgrad(oracle64, qq, q_fixed, prior, zk)
+        return ((e["nll_v"] * mask).sum() + np.where(mask > 0, kl, 0).sum()) / mask.sum()
+
+    for trial in range(4):
+        direction = {k: rng.standard_normal(w[k].shape) for k in WEIGHT_NAMES}
+        if trial == 1:   # sigma head only
+            for k in WEIGHT_NAMES:
+                if k not in ("Ws", "bs"):
+                    direction[k] *= 0
+        if trial == 2:   # residual branch only
+            for k in WEIGHT_NAMES:
+                if k not in ("Wr1", "br1", "Wr2", "br2", "Wg", "bg"):
+                    direction[k] *= 0
+        dflat = EncoderWeights(ctx, 11, U, L, cw, -1.0).set_from_arrays(
+            {k: direction[k].astype(np.float32) for k in WEIGHT_NAMES}).flat.cpu().numpy().astype(np.float64)
+        eps = 3e-5
+        fd = (loss(_perturbed(w, direction, eps)) - loss(_perturbed(w, direction, -eps))) / (2 * eps)
+        got = float(grad @ dflat)
+        assert abs(got - fd) < 1e-2 * (abs(fd) + 0.05), (trial, got, fd)
+
+
+def test_adamw_matches_numpy(ctx):
+    from qbold_vi_amd.ops import TrainState
+    _, ew = _weights(ctx, 24, 1, True)
+    st = TrainState(ctx, ew)
+    rng = np.random.default_rng(0)
+    w = ew.flat.cpu().numpy().astype(np.float64)
+    m = np.zeros_like(w)
+    v = np.zeros_like(w)
+    for t in range(1, 4):
+        g = rng.standard_normal(w.shape)
+        st.grad.copy_(torch.as_tensor(g, dtype=torch.float32))
+        lr, wd, b1, b2, eps = 5e-3 / t, 2e-4, 0.9, 0.9, 1e-7
+        st.adamw(lr, wd, b1, b2, eps)
+        w = w - wd * w                      # tfa DecoupledWeightDecay: before the Adam update
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        w = w - lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m / (np.sqrt(v) + eps)
+        np.testing.assert_allclose(ew.flat.cpu().numpy(), w, rtol=2e-5, atol=1e-7)
