@@ -1,0 +1,403 @@
+"""Training orchestration -- the host mirror of train.py:188-451 and qbold_train_model.py /
+qbold_build_model.py of the reference, for voxel batches.
+
+Two phases, as the reference: (1) supervised pre-training of encoder stream 1 on synthetic voxels
+(create_and_train_on_synthetic_data, train.py:379-427), (2) unsupervised ELBO fine-tuning of
+stream 2 with the stream-1 predictions as per-voxel prior (train_full_model, train.py:285-376).
+Weights are checkpointed as <save_directory>/pt_model.npz and final_model.npz with the reference's
+three-state phase skipping (qbold_build_model.py:11-56).  Every number is produced by
+libqbold_hip.so; with N > 1 ranks (torchrun) voxels are sharded and gradients / loss sums are
+all-reduced over RCCL (qbold_vi_amd.distributed).
+
+Differences from the reference, all forced by scope: fine-tuning runs on voxel batches
+(image crops with the 3x3x1 context and the TV term are row N1), so `--synthetic_voxels N` (or
+real .npy volumes flattened to masked voxels) replaces the random-crop pipeline; wandb is replaced
+by JSONL metrics with the reference's key names.
+"""
+import json
+import math
+import os
+import time
+from enum import Enum
+
+import numpy as np
+import torch
+
+from . import distributed as qd
+from .model import EncoderTrainer
+from .ops import TrainState
+from .signals import SignalGenerationLayer, create_synthetic_dataset
+
+
+class WeightStatus(Enum):  # qbold_build_model.py:11-14
+    NOT_TRAINED = 0
+    PRE_TRAINED = 1
+    FULL_TRAINED = 2
+
+
+def _get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def lr_schedule(initial, step, steps_per_epoch=100):
+    """LRSchedule.__call__ (train.py:287-306): linear from `initial` to initial/100 over 40 epochs of
+    100 steps; `step` is the optimiser's iteration count before the update."""
+    final = initial / 1e2
+    rate = (final - initial) / (40.0 * steps_per_epoch)
+    return initial + rate * step if step > 0 else initial
+
+
+def get_params(path="config"):
+    """The INI `config` [DEFAULT] section, read from the CWD as strings (train.py:189-191)."""
+    import configparser
+    cfg = configparser.ConfigParser()
+    if not cfg.read(path):
+        raise FileNotFoundError(f"INI file {path!r} not found in {os.getcwd()}")
+    return dict(cfg["DEFAULT"])
+
+
+def create_encoder_model(config_dict, params, device=None):
+    """train.create_encoder_model (train.py:430-451) = ModelBuilder.create_encoder_model
+    (qbold_build_model.py:59-82).  Returns (model, inner_model, trainer)."""
+    nl = max(1, int(_get(config_dict, "no_intermediate_layers")))
+    nu = max(1, int(_get(config_dict, "no_units")))
+    trainer = EncoderTrainer(system_params=params,
+                             no_units=nu,
+                             use_layer_norm=_get(config_dict, "use_layer_norm"),
+                             dropout_rate=_get(config_dict, "dropout_rate"),
+                             no_intermediate_layers=nl,
+                             student_t_df=_get(config_dict, "student_t_df"),
+                             initial_im_sigma=_get(config_dict, "im_loss_sigma"),
+                             activation_type=_get(config_dict, "activation"),
+                             multi_image_normalisation=_get(config_dict, "multi_image_normalisation"),
+                             channelwise_gating=_get(config_dict, "channelwise_gating"),
+                             infer_inv_gamma=_get(config_dict, "infer_inv_gamma"),
+                             use_population_prior=_get(config_dict, "use_population_prior"),
+                             use_mvg=_get(config_dict, "use_mvg"),
+                             predict_log_data=_get(config_dict, "predict_log_data"),
+                             no_samples=max(1, int(_get(config_dict, "mc_samples", 1) or 1)),
+                             full_model=_get(config_dict, "full_model", True),
+                             use_blood=_get(config_dict, "use_blood", True),
+                             device=device)
+    taus = np.arange(float(params['tau_start']), float(params['tau_end']), float(params['tau_step']))
+    model, inner_model = trainer.create_encoder(gate_offset=_get(config_dict, "gate_offset"),
+                                                resid_init_std=_get(config_dict, "resid_init_std"),
+                                                no_ip_images=len(taus))
+    return model, inner_model, trainer
+
+
+class MetricsLog:
+    """wandb.log / Keras progress replacement: one JSON object per line, reference key names."""
+
+    def __init__(self, path=None, echo=True, rank=0):
+        self.path, self.echo, self.rank = path, echo, rank
+        self.history = []
+
+    def log(self, metrics):
+        m = {k: (float(v) if not isinstance(v, (str, int)) else v) for k, v in metrics.items()}
+        self.history.append(m)
+        if self.rank != 0:
+            return
+        line = json.dumps(m)
+        if self.echo:
+            print(line, flush=True)
+        if self.path:
+            with open(self.path, "a") as fh:
+                fh.write(line + "\n")
+
+
+def _check_finite(value, what):
+    if not math.isfinite(value):  # keras.callbacks.TerminateOnNaN (train.py:375,423)
+        raise FloatingPointError(f"{what} is not finite: training terminated")
+
+
+# ----------------------------------------------------------------------------------------------
+# phase 1: pre-training on synthetic data (train.py:379-427)
+# ----------------------------------------------------------------------------------------------
+def prepare_synthetic_dataset(x, y):
+    """train.prepare_synthetic_dataset (train.py:82-104): last 10 % of the (already shuffled)
+    voxels for validation; batches of 512 'images' of 10x10x5 voxels = 256,000 voxels."""
+    vox_per_example = 10 * 10 * 5
+    n_examples = x.shape[0] // vox_per_example
+    n_valid = n_examples // 10
+    n_train_vox = (n_examples - n_valid) * vox_per_example
+    train = (x[:n_train_vox], y[:n_train_vox])
+    valid = (x[n_train_vox:n_examples * vox_per_example], y[n_train_vox:n_examples * vox_per_example])
+    return train, valid, 512 * vox_per_example
+
+
+def create_and_train_on_synthetic_data(config_dict, params, log=None, sample_size=None, device=None,
+                                       max_steps=None):
+    model, inner_model, trainer = create_encoder_model(config_dict, params, device=device)
+    rank, world, _ = qd.init_from_env()
+    log = log or MetricsLog(rank=rank)
+    x, y = create_synthetic_dataset(params, _get(config_dict, "full_model"), _get(config_dict, "use_blood"),
+                                    _get(config_dict, "misalign_prob"),
+                                    uniform_prop=_get(config_dict, "uniform_prop"),
+                                    sample_size=sample_size, device=device)
+    (tx, ty), (vx, vy), batch = prepare_synthetic_dataset(x, y)
+    state = TrainState(trainer.context, model.weights)
+    lr = float(_get(config_dict, "pt_lr"))
+    # AdamW(weight_decay=pt_adamw_decay) wrapped in SWA whose averages are never swapped in
+    # (train.py:382-385); plain Adam without decay when use_swa is off.
+    wd = float(_get(config_dict, "pt_adamw_decay")) if _get(config_dict, "use_swa") else 0.0
+    g = torch.Generator(device=tx.device)
+    g.manual_seed(1)
+    n = tx.shape[0]
+    steps = 0
+    for epoch in range(int(_get(config_dict, "no_pt_epochs"))):
+        perm = torch.randperm(n, generator=g, device=tx.device)
+        losses = []
+        for b0 in range(0, n, batch):
+            idx = perm[b0:b0 + batch]
+            a, b = qd.shard_range(idx.numel(), rank, world)
+            xb, yb = tx[idx[a:b]], ty[idx[a:b]]
+            q1, _ = state.forward(xb, 1)
+            lv, gq = state.synth_loss_bwd(yb, q1)
+            state.backward(1, gq)
+            qd.allreduce_mean_(state.grad)
+            state.adamw(lr, wd, 0.9, 0.999, 1e-7)
+            losses.append(lv.mean())
+            steps += 1
+            if max_steps and steps >= max_steps:
+                break
+        loss = float(torch.stack(losses).mean())
+        _check_finite(loss, "pre-training loss")
+        out1 = model.predict(vx, want=("out1",))[0] if vx.shape[0] else None
+        metrics = {"epoch": epoch, "loss": loss}
+        if out1 is not None:
+            metrics["val_loss"] = float(trainer.synthetic_data_loss(vy, out1))
+            metrics["val_oef_metric"] = float(trainer.oef_metric(vy, out1))
+            metrics["val_dbv_metric"] = float(trainer.dbv_metric(vy, out1))
+            metrics["val_r2p_metric"] = float(trainer.r2p_metric(vy, out1))
+        log.log(metrics)
+        if max_steps and steps >= max_steps:
+            break
+    return model, trainer, inner_model
+
+
+# ----------------------------------------------------------------------------------------------
+# phase 2: ELBO fine-tuning (train.py:285-376)
+# ----------------------------------------------------------------------------------------------
+def prepare_voxel_dataset(data, mask, model):
+    """Voxel-batch counterpart of train.prepare_dataset (train.py:17-72): data are masked, the
+    stream-1 output of the (pre-trained) model is the per-voxel prior."""
+    x = (data * mask[:, None]).contiguous()
+    prior = model.predict(x, want=("out1",))[0]
+    return x, mask.contiguous(), prior
+
+
+def train_full_model(config_dict, trainer, full_model, study_dataset, train_dataset, log=None,
+                     steps_per_epoch=100, batch_voxels=38 * 25 * 25 * 8, kl_samples=70, max_steps=None):
+    """Fine-tune stream 2 by minimising nll + 1.0 * kl (+ smoothness_weight * TV, identically 0 on
+    voxel batches); kl_weight from the YAML is unused in the reference as well (train.py:313,319)."""
+    assert isinstance(trainer, EncoderTrainer)
+    rank, world, _ = qd.init_from_env()
+    log = log or MetricsLog(rank=rank)
+    ctx = trainer.context
+    model = full_model.encoder_model
+    state = TrainState(ctx, model.weights)
+    x, mask, prior = train_dataset
+    vx, vmask, vprior = study_dataset
+    S = trainer._no_samples
+    decay0, lr0 = float(_get(config_dict, "adamw_decay")), float(_get(config_dict, "ft_lr"))
+    beta2 = 0.9 if decay0 > 0.0 else 0.999  # AdamW(..., beta_2=0.9) vs plain Adam (train.py:308-312)
+    n = x.shape[0]
+    g = torch.Generator(device=x.device)
+    g.manual_seed(2)
+    step = 0
+    for epoch in range(int(_get(config_dict, "no_ft_epochs"))):
+        tot = torch.zeros(3, dtype=torch.float64, device=x.device)
+        for _ in range(steps_per_epoch):
+            idx = torch.randint(0, n, (min(batch_voxels, n),), generator=g, device=x.device)
+            a, b = qd.shard_range(idx.numel(), rank, world)
+            sel = idx[a:b]
+            xb, mb, pb = x[sel], mask[sel], prior[sel]
+            q2, ls = state.forward(xb, 2)
+            sums, gq, gls, _ = ctx.elbo_bwd(xb, mb, q2, pb, ls, S, kl_samples, seed=1000 + step, voxel0=a)
+            qd.allreduce_sums(sums)          # global sum(mask) before the gradient is normalised
+            state.backward(2, gq, gls, sums)
+            if world > 1:
+                torch.distributed.all_reduce(state.grad)  # shard gradients add up (same 1/sum(m))
+            wd = lr_schedule(decay0, step, steps_per_epoch) if decay0 > 0.0 else 0.0
+            state.adamw(lr_schedule(lr0, step, steps_per_epoch), wd, 0.9, beta2, 1e-7)
+            tot += sums
+            step += 1
+            if max_steps and step >= max_steps:
+                break
+        nll, kl = float(tot[0] / tot[2]), float(tot[1] / tot[2])
+        _check_finite(nll + kl, "fine-tuning loss")
+        metrics = {"epoch": epoch, "loss": nll + kl, "predicted_images_loss": nll, "predictions_loss": kl}
+        metrics.update(validation_elbo(config_dict, trainer, full_model, (vx, vmask, vprior), kl_samples,
+                                       seed=epoch))
+        log.log(metrics)
+        if max_steps and step >= max_steps:
+            break
+    return model
+
+
+def validation_elbo(config_dict, trainer, full_model, study_dataset, kl_samples=70, seed=0):
+    """ELBOCallback.on_epoch_end (train.py:329-357): val_nll is the mean of 10 stochastic passes,
+    val_kl one 70-sample estimate, val_elbo = nll + kl; the smoothness terms are 0 on voxels."""
+    vx, vmask, vprior = study_dataset
+    if vx.shape[0] == 0:
+        return {}
+    a, b = qd.shard_range(vx.shape[0], *qd.init_from_env()[:2])
+    nll = torch.zeros((), dtype=torch.float64, device=vx.device)
+    for i in range(10):
+        out = full_model.elbo(vx[a:b], vmask[a:b], vprior[a:b], kl_samples=kl_samples,
+                              seed=7000 + 10 * seed + i, voxel0=a)
+        s = qd.allreduce_sums(out["sums"].clone())
+        nll = nll + s[0] / s[2]
+        if i == 9:
+            kl = s[1] / s[2]
+    nll = float(nll / 10.0)
+    kl = float(kl)
+    sw = float(_get(config_dict, "smoothness_weight", 0.0) or 0.0)
+    return {"val_nll": nll, "val_elbo": nll + kl, "val_elbo_smooth": nll + kl * 1.0 + 0.0 * sw,
+            "val_smoothness": 0.0, "val_smoothness_scaled": 0.0, "val_kl": kl}
+
+
+# ----------------------------------------------------------------------------------------------
+# data
+# ----------------------------------------------------------------------------------------------
+def synthetic_voxel_dataset(params, config_dict, n, device, seed):
+    """N i.i.d. synthetic voxels: the create_synthetic_dataset priors with
+    uniform_prop, forward model + reference noise, mask = 1."""
+    rng = np.random.default_rng(seed)
+    up = float(_get(config_dict, "uniform_prop", 0.0) or 0.0)
+    n_u = round(n * up)
+
+    def draw(lo, hi, mean, std, trunc):
+        u = rng.uniform(lo, hi, n_u)
+        z = rng.standard_normal(n - n_u) * std + mean
+        if trunc:
+            bad = (z < lo) | (z > hi)
+            while bad.any():
+                z[bad] = rng.standard_normal(int(bad.sum())) * std + mean
+                bad = (z < lo) | (z > hi)
+        else:
+            z = np.clip(z, lo, hi)
+        out = np.concatenate([u, z])
+        rng.shuffle(out)
+        return out
+    oef = draw(float(params['oef_start']), float(params['oef_end']), float(params['oef_mean']),
+               float(params['oef_std']), False)
+    dbv = draw(float(params['dbv_start']), float(params['dbv_end']), float(params['dbv_mean']),
+               float(params['dbv_std']), True)
+    layer = SignalGenerationLayer(dict(params, simulate_noise='True'), _get(config_dict, "full_model"),
+                                  _get(config_dict, "use_blood"), device=device, seed=seed)
+    y = torch.as_tensor(np.stack([oef, dbv], -1), dtype=torch.float32, device=layer.context.device)
+    return layer(y), torch.ones(n, dtype=torch.float32, device=y.device), y
+
+
+def load_real_voxels(directory, names, device):
+    """The reference's .npy volumes [subj, X, Y, 8, T+2] (train.py:208-221) flattened to voxels:
+    signals, and the LAST channel (brain mask) as mask -- the crop pipeline is row N1."""
+    xs, ms = [], []
+    for name in names:
+        arr = np.load(os.path.join(directory, name)).astype(np.float32)
+        T = arr.shape[-1] - 2
+        flat = arr.reshape(-1, T + 2)
+        xs.append(flat[:, :T])
+        ms.append(flat[:, -1])
+    x = torch.as_tensor(np.concatenate(xs), device=device)
+    m = torch.as_tensor(np.concatenate(ms), device=device)
+    return x, m
+
+
+# ----------------------------------------------------------------------------------------------
+# entry points
+# ----------------------------------------------------------------------------------------------
+def train_model(config_dict, device=None, log=None, pt_sample_size=None, max_pt_steps=None,
+                max_ft_steps=None):
+    """train.train_model (train.py:188-282) for voxel batches.  Returns (model, trainer, history)."""
+    params = get_params('config')
+    rank, world, local_rank = qd.init_from_env()
+    if device is None and torch.cuda.is_available():
+        device = f"cuda:{local_rank}"
+    save_dir = _get(config_dict, "save_directory") or "."
+    log = log or MetricsLog(os.path.join(save_dir, "metrics.jsonl") if rank == 0 else None, rank=rank)
+    if rank == 0:
+        os.makedirs(save_dir, exist_ok=True)
+    pt_path = os.path.join(save_dir, "pt_model.npz")
+    final_path = os.path.join(save_dir, "final_model.npz")
+    if os.path.isfile(pt_path):  # train.py:197-199
+        model, inner_model, trainer = create_encoder_model(config_dict, params, device=device)
+        model.load_weights(pt_path)
+    else:
+        model, trainer, inner_model = create_and_train_on_synthetic_data(
+            config_dict, params, log=log, sample_size=pt_sample_size, device=device,
+            max_steps=max_pt_steps)
+        if rank == 0:
+            model.save_weights(pt_path)
+
+    n_syn = int(_get(config_dict, "synthetic_voxels", 0) or 0)
+    if n_syn > 0:
+        x, mask, _ = synthetic_voxel_dataset(params, config_dict, n_syn, trainer.context.device, seed=11)
+        vx, vmask, _ = synthetic_voxel_dataset(params, config_dict, max(n_syn // 8, 1024),
+                                               trainer.context.device, seed=12)
+    else:
+        d = _get(config_dict, "d")
+        if not d or not os.path.exists(d):
+            raise Exception('Real data directory not found')  # train.py:204-205
+        x, mask = load_real_voxels(d, ["ASE_scan.npy", "ASE_INF.npy", "ASE_SUP.npy"], trainer.context.device)
+        vx, vmask = load_real_voxels(d, ["hyperv_ase.npy", "baseline_ase.npy"], trainer.context.device)
+    train_dataset = prepare_voxel_dataset(x, mask, model)
+    study_dataset = prepare_voxel_dataset(vx, vmask, model)
+    sig_gen_layer = SignalGenerationLayer(dict(params, simulate_noise='False'),
+                                          _get(config_dict, "full_model"), _get(config_dict, "use_blood"),
+                                          device=trainer.context.device)
+    full_model = trainer.build_fine_tuner(model, sig_gen_layer, None, None)
+    if os.path.isfile(final_path):  # train.py:260-261
+        model.load_weights(final_path)
+    else:
+        train_full_model(config_dict, trainer, full_model, study_dataset, train_dataset, log=log,
+                         max_steps=max_ft_steps)
+        if rank == 0:
+            model.save_weights(final_path)
+    return model, trainer, log.history
+
+
+class ModelBuilder:
+    """qbold_build_model.ModelBuilder (:17-82): builds the encoder and loads whichever weights exist."""
+
+    def __init__(self, config_dict, system_params=None, device=None):
+        self.config_dict = config_dict
+        self.system_params = system_params if system_params else ModelBuilder.get_params()
+        model, inner_model, trainer = create_encoder_model(config_dict, self.system_params, device=device)
+        self.model, self.inner_model, self.trainer = model, inner_model, trainer
+        self.save_dir = os.path.join(os.getcwd(), self.config_dict['save_directory'])
+        self.final_model_weights = os.path.join(self.save_dir, 'final_model.npz')
+        self.pt_model_weights = os.path.join(self.save_dir, 'pt_model.npz')
+        self.weight_status = self.load_model_weights()
+
+    @staticmethod
+    def get_params():
+        return get_params('config')
+
+    def load_model_weights(self):
+        if os.path.isfile(self.final_model_weights):
+            self.model.load_weights(self.final_model_weights)
+            return WeightStatus.FULL_TRAINED
+        if os.path.isfile(self.pt_model_weights):
+            self.model.load_weights(self.pt_model_weights)
+            return WeightStatus.PRE_TRAINED
+        print('Model weights do not exit')
+        return WeightStatus.NOT_TRAINED
+
+
+class ModelTrainer(ModelBuilder):
+    """qbold_train_model.ModelTrainer (:16-323)."""
+
+    def __init__(self, config_dict, system_params=None, device=None):
+        super().__init__(config_dict, system_params, device=device)
+        self.history = []
+
+    def train_model(self, **kw):
+        t0 = time.time()
+        _, _, self.history = train_model(self.config_dict, **kw)
+        self.weight_status = WeightStatus.FULL_TRAINED
+        return time.time() - t0

@@ -83,7 +83,7 @@ def load_arguments(argv=None, entry="qbold_train_model"):
     yaml_file = None
     if len(argv) >= 2 and ".yaml" in argv[1]:
         yaml_file = argv[1]
-        argv = [argv[0]] + (argv[2:] if entry != "qbold_train_model" else [])
+        argv = [argv[0]] + argv[2:]   # the reference drops everything else; extra flags are allowed here
     args = vars(setup_argparser(get_defaults(entry)).parse_args(argv[1:]))
     if yaml_file is not None:
         with open(yaml_file) as fh:

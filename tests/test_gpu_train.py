@@ -1,0 +1,115 @@
+"""End-to-end training on the GPU through the reference-shaped entry points: pre-training on
+synthetic voxels, ELBO fine-tuning, checkpoints and phase skipping."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def small_config(tmp, **over):
+    from qbold_vi_amd.utils import load_arguments
+    args = load_arguments(["train.py", os.path.join(ROOT, "configurations", "optimal.yaml")], entry="train")
+    args.update(no_units=24, no_intermediate_layers=1, no_pt_epochs=80, no_ft_epochs=3,
+                save_directory=str(tmp), synthetic_voxels=20000, mc_samples=2)
+    args.update(over)
+    return args
+
+
+def test_lr_schedule_is_the_reference_linear_ramp():
+    from qbold_vi_amd.training import lr_schedule
+    assert lr_schedule(5e-3, 0) == 5e-3
+    assert abs(lr_schedule(5e-3, 2000) - (5e-3 + (5e-5 - 5e-3) * 0.5)) < 1e-12
+    assert abs(lr_schedule(5e-3, 4000) - 5e-5) < 1e-12
+    assert abs(lr_schedule(2e-4, 1) - (2e-4 + (2e-6 - 2e-4) / 4000)) < 1e-15
+
+
+def test_two_phase_training_and_phase_skipping(tmp_path, monkeypatch):
+    from qbold_vi_amd import training
+    monkeypatch.chdir(ROOT)   # the INI `config` is read from the CWD, as in the reference
+    cfg = small_config(tmp_path)
+    model, trainer, hist = training.train_model(cfg, pt_sample_size=200)
+    pt = [h for h in hist if "val_oef_metric" in h]
+    ft = [h for h in hist if "val_elbo" in h]
+    assert len(pt) == 80 and len(ft) == 3
+    # supervised phase learns (one 40,000-voxel step per epoch here): the loss falls steadily and
+    # the OEF / DBV errors of the posterior mean shrink
+    assert pt[-1]["loss"] < pt[0]["loss"] - 10.0 and pt[-1]["val_loss"] < pt[0]["val_loss"] - 10.0
+    assert pt[-1]["val_oef_metric"] < 0.9 * pt[0]["val_oef_metric"]
+    assert pt[-1]["val_dbv_metric"] < 0.75 * pt[0]["val_dbv_metric"]
+    # ELBO phase: objective falls and every reference metric key is present (train.py:350-355)
+    assert ft[-1]["loss"] < ft[0]["loss"]
+    for k in ("val_nll", "val_elbo", "val_elbo_smooth", "val_smoothness", "val_smoothness_scaled", "val_kl"):
+        assert k in ft[-1]
+    assert abs(ft[-1]["val_elbo"] - (ft[-1]["val_nll"] + ft[-1]["val_kl"])) < 1e-9
+    assert os.path.isfile(tmp_path / "pt_model.npz") and os.path.isfile(tmp_path / "final_model.npz")
+    lines = [json.loads(l) for l in open(tmp_path / "metrics.jsonl")]
+    assert len(lines) == 83
+    # second call: both phases are skipped because their weight files exist (train.py:197-199,260)
+    w_before = {k: v.copy() for k, v in model.get_weights().items()}
+    model2, _, hist2 = training.train_model(cfg)
+    assert hist2 == []
+    for k, v in model2.get_weights().items():
+        np.testing.assert_array_equal(v, w_before[k])
+    # ModelBuilder reports the three-state status (qbold_build_model.py:45-56)
+    mb = training.ModelBuilder(dict(cfg, save_directory=os.path.relpath(tmp_path, ROOT)))
+    assert mb.weight_status == training.WeightStatus.FULL_TRAINED
+    os.remove(tmp_path / "final_model.npz")
+    mb = training.ModelBuilder(dict(cfg, save_directory=os.path.relpath(tmp_path, ROOT)))
+    assert mb.weight_status == training.WeightStatus.PRE_TRAINED
+
+
+def test_missing_real_data_directory_raises(tmp_path, monkeypatch):
+    from qbold_vi_amd import training
+    monkeypatch.chdir(ROOT)
+    cfg = small_config(tmp_path, synthetic_voxels=0, d=str(tmp_path / "nope"), no_pt_epochs=1)
+    with pytest.raises(Exception, match="Real data directory not found"):
+        training.train_model(cfg, pt_sample_size=100)
+
+
+def test_real_volume_layout_is_accepted(tmp_path, monkeypatch):
+    """.npy volumes shaped [subj, X, Y, 8, T+2] as the reference loads them (train.py:208-221)."""
+    from qbold_vi_amd import training
+    from qbold_vi_amd.signals import SignalGenerationLayer
+    monkeypatch.chdir(ROOT)
+    params = training.get_params("config")
+    layer = SignalGenerationLayer(dict(params, simulate_noise='True'), True, True)
+    rng = np.random.default_rng(0)
+    d = tmp_path / "data"
+    os.makedirs(d)
+    for name in ("ASE_scan", "ASE_INF", "ASE_SUP", "hyperv_ase", "baseline_ase"):
+        y = np.stack([rng.uniform(0.2, 0.6, 2 * 6 * 6 * 8), rng.uniform(0.01, 0.06, 2 * 6 * 6 * 8)], -1)
+        sig = layer(torch.as_tensor(y, dtype=torch.float32, device="cuda")).cpu().numpy() * 100.0
+        vol = np.concatenate([sig, np.ones((sig.shape[0], 2), np.float32)], -1).reshape(2, 6, 6, 8, 13)
+        vol[:, 0, :, :, -1] = 0.0   # a masked-out slab
+        np.save(d / f"{name}.npy", vol)
+    cfg = small_config(tmp_path / "run", synthetic_voxels=0, d=str(d), no_pt_epochs=1, no_ft_epochs=1)
+    _, _, hist = training.train_model(cfg, pt_sample_size=100, max_ft_steps=3)
+    assert np.isfinite(hist[-1]["val_elbo"])
+
+
+def test_train_py_cli(tmp_path):
+    """`python train.py <yaml>` exactly as the reference is invoked (YAML values win over flags,
+    train.py:473-480, so the save directory comes from the YAML)."""
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configurations", "optimal.yaml")))
+    cfg.update(save_directory=str(tmp_path / "run"), no_pt_epochs=1, no_ft_epochs=1, no_units=16,
+               no_intermediate_layers=1)
+    ypath = tmp_path / "small.yaml"
+    yaml.safe_dump(cfg, open(ypath, "w"))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), str(ypath),
+                        "--synthetic_voxels", "4096"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.isfile(tmp_path / "run" / "pt_model.npz")
+    assert os.path.isfile(tmp_path / "run" / "final_model.npz")
+    last = json.loads(r.stdout.strip().splitlines()[-1])
+    assert np.isfinite(last["val_elbo"])
