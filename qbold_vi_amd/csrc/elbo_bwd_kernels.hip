@@ -256,11 +256,14 @@ extern "C" int qbold_elbo_bwd(const qbold_ctx* ctx, const float* x, const float*
     const int64_t ntile = (N + kVoxPerBlock - 1) / kVoxPerBlock;
     const int grid = (int)(ntile < qb::elbo_grid(ctx) ? (ntile > 0 ? ntile : 1) : qb::elbo_grid(ctx));
     float2* out = reinterpret_cast<float2*>(nll_kl);
-    if (ctx->dev.T != 11) {
-        qb::set_error("qbold_elbo_bwd: kernels are built for T = 11 taus");
+    if (ctx->dev.T == 24) {
+        hipLaunchKernelGGL((elbo_bwd_kernel<24, -1>), dim3(grid), dim3(kBlock), 0, s, ctx->dev, ctx->d_tab,
+                           x, mask, q, prior, log_sigma, S, K, seed, voxel0, g_q, g_log_sigma, out,
+                           partials, N);
+    } else if (ctx->dev.T != 11) {
+        qb::set_error("qbold_elbo_bwd: kernels are built for T = 11 or 24 taus");
         return QBOLD_ERR_UNSUPPORTED;
-    }
-    if (ctx->dev.se_idx == 2 && !ctx->dev.multi_norm)
+    } else if (ctx->dev.se_idx == 2 && !ctx->dev.multi_norm)
         hipLaunchKernelGGL((elbo_bwd_kernel<11, 2>), dim3(grid), dim3(kBlock), 0, s, ctx->dev, ctx->d_tab,
                            x, mask, q, prior, log_sigma, S, K, seed, voxel0, g_q, g_log_sigma, out,
                            partials, N);

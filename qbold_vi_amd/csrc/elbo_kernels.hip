@@ -205,8 +205,13 @@ extern "C" int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float*
             else if (lit) QB_LAUNCH_ELBO(11, -1, false, true);
             else QB_LAUNCH_ELBO(11, -1, false, false);
             break;
+        case 24:  // the reference's second protocol (signals.py:120-121); se_idx = 7
+            if (fast) QB_LAUNCH_ELBO(24, -1, true, false);
+            else if (lit) QB_LAUNCH_ELBO(24, -1, false, true);
+            else QB_LAUNCH_ELBO(24, -1, false, false);
+            break;
         default:
-            qb::set_error("qbold_elbo_fwd: kernels are built for T = 11 taus");
+            qb::set_error("qbold_elbo_fwd: kernels are built for T = 11 or 24 taus");
             return QBOLD_ERR_UNSUPPORTED;
     }
 #undef QB_LAUNCH_ELBO

@@ -217,8 +217,10 @@ extern "C" int qbold_encoder_fwd(const qbold_ctx* ctx, const qbold_encoder_shape
     } while (0)
     if (shape->T == 11 && shape->L == 1) QB_LAUNCH_ENC(11, 1);
     else if (shape->T == 11 && shape->L == 2) QB_LAUNCH_ENC(11, 2);
+    else if (shape->T == 24 && shape->L == 1) QB_LAUNCH_ENC(24, 1);
+    else if (shape->T == 24 && shape->L == 2) QB_LAUNCH_ENC(24, 2);
     else {
-        qb::set_error("qbold_encoder_fwd: kernels are built for T = 11 taus, L = 1 or 2");
+        qb::set_error("qbold_encoder_fwd: kernels are built for T = 11 or 24 taus, L = 1 or 2");
         return QBOLD_ERR_UNSUPPORTED;
     }
 #undef QB_LAUNCH_ENC

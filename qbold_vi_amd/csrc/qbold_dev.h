@@ -142,9 +142,11 @@ __device__ __forceinline__ float nlogp(const LogitObs& o, const LogitMvn& m) {
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        // one 32x32->64 multiply (v_mad_u64_u32) per word instead of a mul_hi / mul_lo pair
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        c = make_uint4((uint32_t)(p1 >> 32) ^ c.y ^ k.x, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k.y,
+                       (uint32_t)p0);
         k.x += 0x9E3779B9u;
         k.y += 0xBB67AE85u;
     }
@@ -393,9 +395,11 @@ __device__ __forceinline__ FwdFast fwd_fast(const QbDev& c, float oef, float dbv
 }
 __device__ __forceinline__ float fwd_signal_fast(const FwdLds* L, const QbDev& c, const FwdFast& v,
                                                  int t) {
+    // 0 <= u < QB_TAB_SEG * 0.84: forward_transform bounds OEF by 0.84 and the table spans OEF <= 1,
+    // so the segment index needs no clamp (an out-of-range LDS read would return 0, not fault)
     const float u = fabsf(fmaf((float)t, v.ub, v.ua));
-    const int i = min((int)u, QB_TAB_SEG - 1);
-    const float f = u - (float)i;
+    const int i = (int)u;
+    const float f = __builtin_amdgcn_fractf(u);
     const float4 k = L->tab[i];
     const float F = fmaf(fmaf(fmaf(k.w, f, k.z), f, k.y), f, k.x);
     const float e1 = exp2f_(v.nd * F);

@@ -150,8 +150,10 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     } while (0)
     if (shape->T == 11 && shape->L == 1) QB_DISPATCH_VI(11, 1);
     else if (shape->T == 11 && shape->L == 2) QB_DISPATCH_VI(11, 2);
+    else if (shape->T == 24 && shape->L == 1) QB_DISPATCH_VI(24, 1);
+    else if (shape->T == 24 && shape->L == 2) QB_DISPATCH_VI(24, 2);
     else {
-        qb::set_error("qbold_vi_fwd: kernels are built for T = 11 taus, L = 1 or 2");
+        qb::set_error("qbold_vi_fwd: kernels are built for T = 11 or 24 taus, L = 1 or 2");
         return QBOLD_ERR_UNSUPPORTED;
     }
 #undef QB_DISPATCH_VI

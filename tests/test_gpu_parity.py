@@ -290,3 +290,35 @@ def test_vi_fwd_sharding_invariance(ctx, weights, oracle32):
     assert torch.equal(torch.cat([nka, nkb]), nkf)
     assert torch.equal(torch.cat([qa, qb]), qf)
     assert torch.allclose(a + b, full, rtol=1e-12)
+
+
+def test_24_tau_protocol(params):
+    """The reference's second acquisition protocol (24 taus from -0.028 s in 4 ms steps,
+    signals.py:120-121): forward model, encoder, fused ELBO and head gradients."""
+    from oracle.oracle import Oracle, init_weights, synth_inputs
+    from qbold_vi_amd.ops import Context, EncoderWeights
+    p = dict(params, tau_start="-0.028", tau_end="0.065", tau_step="0.004")
+    orc = Oracle("f32", p)
+    ctx = Context(p, full_model=True, include_blood=True)
+    assert ctx.T == orc.T == 24 and ctx.se_idx == 7
+    y = grid_oef_dbv(3000, seed=8)
+    assert rel(ctx.signal_fwd(dev(y)).cpu().numpy(), orc.signal_fwd(y)) < 1e-5
+    w = init_weights(T=24, U=60, L=2, seed=4)
+    w["gate_offset"] = -3.0
+    ew = EncoderWeights(ctx, 24, 60, 2, True, -3.0).set_from_arrays(w)
+    n, S, K, seed = 1200, 5, 9, 3
+    x, _ = synth_inputs(n, p, seed=8, noise=False, oracle=orc)
+    x = (x * (1 + 0.01 * np.random.default_rng(0).standard_normal(x.shape))).astype(np.float32)
+    prior, q_want, sigma = orc.encoder_fwd(w, x)
+    o1, o2, sg = ctx.encoder_fwd(ew, dev(x))
+    assert np.max(np.abs(o2.cpu().numpy() - q_want)) < 2e-5 and rel(sg.cpu().numpy(), sigma) < 2e-5
+    mask = np.ones(n, np.float32)
+    want = orc.elbo(x, mask, q_want, prior, sigma, orc.philox_normals(seed, 0, 0, n, S),
+                    orc.philox_normals(seed, 1, 0, n, K))
+    sums, q, nk = ctx.vi_fwd(ew, dev(x), dev(mask), dev(prior), S, K, seed=seed)
+    sums = sums.cpu().numpy()
+    assert abs((sums[0] + sums[1]) / sums[2] - want["elbo"]) < 1e-4 * abs(want["elbo"])
+    s2, nk2 = ctx.elbo_fwd(dev(x), dev(mask), q, dev(prior), sg, S, K, seed=seed)
+    assert torch.allclose(nk, nk2, rtol=1e-4, atol=1e-4)
+    s3, gq, gls, nk3 = ctx.elbo_bwd(dev(x), dev(mask), q, dev(prior), torch.log(sg), S, K, seed=seed)
+    assert torch.allclose(nk3, nk2, rtol=1e-4, atol=1e-4) and bool(torch.isfinite(gq).all())
