@@ -111,9 +111,9 @@ __device__ __forceinline__ float sample_sq_fast(const FwdLds* L, const QbDev& c,
             const float st = (t == SE) ? s_se : fwd_signal_fast(L, c, fv, t);
             const float r = fmaf(-st, inv_np, k.yt[t]) * k.inv_s[t];
             acc = fmaf(r, r, acc);
-            // keep at most four table rows (16 VGPRs) in flight: the scheduler would otherwise
-            // hoist all T LDS reads to the top and spill
-            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            // keep at most four table rows (16 VGPRs) in flight: without a compiler barrier all T
+            // LDS reads are hoisted to the top of the draw and the kernel spills
+            if ((t & 3) == 3) asm volatile("" ::: "memory");
         }
         return acc;
     }
