@@ -126,10 +126,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    device = torch.device(f"cuda:{local_rank}")
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs an MI355X: no ROCm device is visible (there is no CPU fallback)")
+    dev_index = local_rank % ndev   # one rank per GPU on a real node; rehearsals may share a card
+    torch.cuda.set_device(dev_index)
+    device = torch.device(f"cuda:{dev_index}")
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        # RCCL ("nccl" on ROCm) over xGMI; QBOLD_DIST_BACKEND=gloo only for single-card rehearsals
+        backend = os.environ.get("QBOLD_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     cfg = configparser.ConfigParser()
     cfg.read(os.path.join(ROOT, "config"))

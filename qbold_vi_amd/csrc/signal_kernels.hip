@@ -18,7 +18,8 @@ constexpr int kBlock = 256;
 template <bool LITERAL>
 __global__ __launch_bounds__(kBlock) void signal_fwd_kernel(QbDev c, const float4* __restrict__ g_tab,
                                                             const float2* __restrict__ oef_dbv,
-                                                            float* __restrict__ signal, int64_t V) {
+                                                            float* __restrict__ signal, int64_t V,
+                                                            int vec_ok) {
     extern __shared__ __align__(16) unsigned char smem[];
     qb::FwdLds* L = reinterpret_cast<qb::FwdLds*>(smem);
     float* stage = reinterpret_cast<float*>(smem + sizeof(qb::FwdLds));  // [kBlock][T]
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void signal_fwd_kernel(QbDev c, const float
         const int n = (int)min((int64_t)kBlock, V - v0);
         const int total = n * T;
         float* dst = signal + v0 * T;  // v0*T*4 bytes is a multiple of 16 (kBlock*4 is)
-        const int nvec = total >> 2;
+        const int nvec = vec_ok ? total >> 2 : 0;  // 16-byte stores need a 16-byte aligned base
         for (int i = threadIdx.x; i < nvec; i += kBlock)
             reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(stage)[i];
         for (int i = (nvec << 2) + threadIdx.x; i < total; i += kBlock) dst[i] = stage[i];
@@ -54,7 +55,8 @@ template <bool LITERAL>
 __global__ __launch_bounds__(kBlock) void signal_bwd_kernel(QbDev c, const float4* __restrict__ g_tab,
                                                             const float2* __restrict__ oef_dbv,
                                                             const float* __restrict__ grad_signal,
-                                                            float2* __restrict__ grad_in, int64_t V) {
+                                                            float2* __restrict__ grad_in, int64_t V,
+                                                            int vec_ok) {
     extern __shared__ __align__(16) unsigned char smem[];
     qb::FwdLds* L = reinterpret_cast<qb::FwdLds*>(smem);
     float* stage = reinterpret_cast<float*>(smem + sizeof(qb::FwdLds));  // [kBlock][T]
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void signal_bwd_kernel(QbDev c, const float
         const int n = (int)min((int64_t)kBlock, V - v0);
         const int total = n * T;
         const float* src = grad_signal + v0 * T;
-        const int nvec = total >> 2;
+        const int nvec = vec_ok ? total >> 2 : 0;
         for (int i = threadIdx.x; i < nvec; i += kBlock)
             reinterpret_cast<float4*>(stage)[i] = reinterpret_cast<const float4*>(src)[i];
         for (int i = (nvec << 2) + threadIdx.x; i < total; i += kBlock) stage[i] = src[i];
@@ -136,12 +138,14 @@ extern "C" int qbold_signal_fwd(const qbold_ctx* ctx, const float* oef_dbv, floa
     const size_t smem = sizeof(qb::FwdLds) + sizeof(float) * kBlock * ctx->dev.T;
     hipStream_t s = (hipStream_t)stream;
     const float2* in = reinterpret_cast<const float2*>(oef_dbv);
+    QB_REQUIRE(reinterpret_cast<uintptr_t>(oef_dbv) % 8 == 0, "qbold_signal_fwd: oef_dbv must be 8-byte aligned");
+    const int vec_ok = reinterpret_cast<uintptr_t>(signal) % 16 == 0;
     if (ctx->dev.tissue_mode == QBOLD_TISSUE_LITERAL)
         hipLaunchKernelGGL(signal_fwd_kernel<true>, dim3(grid_for(ctx, V, 8)), dim3(kBlock), smem, s,
-                           ctx->dev, ctx->d_tab, in, signal, V);
+                           ctx->dev, ctx->d_tab, in, signal, V, vec_ok);
     else
         hipLaunchKernelGGL(signal_fwd_kernel<false>, dim3(grid_for(ctx, V, 8)), dim3(kBlock), smem, s,
-                           ctx->dev, ctx->d_tab, in, signal, V);
+                           ctx->dev, ctx->d_tab, in, signal, V, vec_ok);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }
@@ -156,12 +160,15 @@ extern "C" int qbold_signal_bwd(const qbold_ctx* ctx, const float* oef_dbv, cons
     hipStream_t s = (hipStream_t)stream;
     const float2* in = reinterpret_cast<const float2*>(oef_dbv);
     float2* gout = reinterpret_cast<float2*>(grad_oef_dbv);
+    QB_REQUIRE(reinterpret_cast<uintptr_t>(oef_dbv) % 8 == 0 && reinterpret_cast<uintptr_t>(grad_oef_dbv) % 8 == 0,
+               "qbold_signal_bwd: (OEF, DBV) buffers must be 8-byte aligned");
+    const int vec_ok = reinterpret_cast<uintptr_t>(grad_signal) % 16 == 0;
     if (ctx->dev.tissue_mode == QBOLD_TISSUE_LITERAL)
         hipLaunchKernelGGL(signal_bwd_kernel<true>, dim3(grid_for(ctx, V, 8)), dim3(kBlock), smem, s,
-                           ctx->dev, ctx->d_tab, in, grad_signal, gout, V);
+                           ctx->dev, ctx->d_tab, in, grad_signal, gout, V, vec_ok);
     else
         hipLaunchKernelGGL(signal_bwd_kernel<false>, dim3(grid_for(ctx, V, 8)), dim3(kBlock), smem, s,
-                           ctx->dev, ctx->d_tab, in, grad_signal, gout, V);
+                           ctx->dev, ctx->d_tab, in, grad_signal, gout, V, vec_ok);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }

@@ -143,3 +143,21 @@ def test_shard_ranges():
             assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_c_program_links_against_the_abi(tmp_path):
+    """include/qbold_hip.h is plain C: compile tests/c/abi_smoke.c with gcc and run it."""
+    import shutil
+    import subprocess
+    from qbold_vi_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    exe = tmp_path / "abi_smoke"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", str(exe),
+                           "-L", libdir, "-lqbold_hip", "-lm", f"-Wl,-rpath,{libdir}",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "abi ok" in r.stdout
