@@ -152,7 +152,8 @@ typedef enum {
     QBOLD_INV_TRANSFORM_STD = 2,        /* atanh((x+1)/3)                    model.py:296-297 */
     QBOLD_FORWARD_TRANSFORM = 3,        /* sigmoid * range + min             model.py:299-305 */
     QBOLD_BACKWARDS_TRANSFORM = 4,      /* (y - min) / range                 model.py:307-311 */
-    QBOLD_BACKWARDS_TRANSFORM_LOGIT = 5 /* ... followed by logit             model.py:312-314 */
+    QBOLD_BACKWARDS_TRANSFORM_LOGIT = 5,/* ... followed by logit             model.py:312-314 */
+    QBOLD_EXP = 6                       /* exp(x): sigma from the sigma head, model.py:214 */
 } qbold_transform_op;
 int qbold_transform(const qbold_ctx* ctx, int op, const float* in, float* out, int64_t n,
                     void* stream);

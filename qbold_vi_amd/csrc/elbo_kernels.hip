@@ -62,6 +62,125 @@ __global__ __launch_bounds__(kBlock) void elbo_fwd_kernel(
     qb::block_partials(red, s_nll, s_kl, s_m, partials);
 }
 
+// Any number of taus (T <= 64; BASELINE config 3 uses 64): the per-voxel normalised data and inverse
+// sigmas live in LDS ([t][voxel], conflict-free) instead of registers, the tau loop is a run-time
+// loop.  Same lane mapping, Philox stream and arithmetic as the fast register path.
+constexpr int kGenBlock = 128;
+constexpr int kGenVox = kGenBlock / QB_LANES_PER_VOXEL;
+
+__global__ __launch_bounds__(kGenBlock) void elbo_fwd_generic_kernel(
+    QbDev c, const float4* __restrict__ g_tab, const float* __restrict__ x,
+    const float* __restrict__ mask, const float* __restrict__ q, const float* __restrict__ prior,
+    const float* __restrict__ sigma, const float* __restrict__ zs, const float* __restrict__ zk,
+    int S, int K, uint64_t seed, int64_t voxel0, float2* __restrict__ nll_kl,
+    double* __restrict__ partials, int64_t N) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    qb::FwdLds* L = reinterpret_cast<qb::FwdLds*>(smem);
+    float* yt = reinterpret_cast<float*>(smem + sizeof(qb::FwdLds));  // [T][kGenVox]
+    float* is = yt + QB_MAX_T * kGenVox;                               // [T][kGenVox]
+    __shared__ double red[3 * (kGenBlock / 64)];
+    qb::fwd_lds_fill(L, g_tab, false);
+    __syncthreads();
+
+    const int T = c.T, se = c.se_idx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int part = lane >> 4;
+    const int vl = wave * QB_VOX_PER_WAVE + (lane & 15);  // voxel slot inside the block
+    float s_nll = 0.0f, s_kl = 0.0f, s_m = 0.0f;
+    const int64_t ntile = (N + kGenVox - 1) / kGenVox;
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int64_t v = tile * kGenVox + vl;
+        const bool live = v < N;
+        const int64_t vc = live ? v : N - 1;
+        const float* xv = x + vc * T;
+        const float* sv = sigma + vc * T;
+        const float nt = c.multi_norm ? (xv[se - 1] + xv[se] + xv[se + 1]) / 3.0f + 1e-3f : xv[se] + 1e-3f;
+        const float inv_nt = qb::rcpf_(nt);
+        float ls = 0.0f;
+        __syncthreads();  // previous tile's readers are done
+        for (int t = part; t < T; t += QB_LANES_PER_VOXEL) {
+            yt[t * kGenVox + vl] = xv[t] * inv_nt;
+            is[t * kGenVox + vl] = qb::rcpf_(sv[t]);
+            ls += QB_LN2 * qb::log2f_(sv[t]);
+        }
+        const float log_s_sum = qb::voxel_sum(ls) + (float)T * 0.9189385332046727f;
+        __syncthreads();
+        if (live) {
+            float qv[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) qv[i] = q[v * 5 + i];
+            const float m = mask ? mask[v] : 1.0f;
+            const qb::LogitMvn qm = qb::make_mvn(qv);
+            const uint64_t vox = (uint64_t)(voxel0 + v);
+            const float* zsv = zs ? zs + v * S * 2 : nullptr;
+            const float* zkv = zk ? zk + v * K * 2 : nullptr;
+            float nll_sum = 0.0f, kl_sum = 0.0f;
+            int n_lik = 0, n_kl = 0;
+            for (int j = part; 2 * j < S; j += QB_LANES_PER_VOXEL) {
+                float z[4];
+                const bool two = 2 * j + 1 < S;
+                if (zsv) {
+                    z[0] = zsv[4 * j];
+                    z[1] = zsv[4 * j + 1];
+                    z[2] = two ? zsv[4 * j + 2] : 0.0f;
+                    z[3] = two ? zsv[4 * j + 3] : 0.0f;
+                } else {
+                    qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_LIK, z);
+                }
+                n_lik += two ? 2 : 1;
+#pragma unroll 1
+                for (int d = 0; d < (two ? 2 : 1); ++d) {
+                    float a, b, oef, dbv;
+                    qb::reparam_logits(qm, d ? z[2] : z[0], d ? z[3] : z[1], a, b);
+                    qb::forward_transform(a, b, oef, dbv);
+                    const qb::FwdFast fv = qb::fwd_fast(c, oef, dbv);
+                    float np_ = qb::fwd_signal_fast(L, c, fv, se);
+                    if (c.multi_norm)
+                        np_ = (np_ + qb::fwd_signal_fast(L, c, fv, se - 1) + qb::fwd_signal_fast(L, c, fv, se + 1)) / 3.0f;
+                    const float inv_np = qb::rcpf_(np_ + 1e-3f);
+                    float acc = 0.0f;
+                    for (int t = 0; t < T; ++t) {
+                        const float st = qb::fwd_signal_fast(L, c, fv, t);
+                        const float r = fmaf(-st, inv_np, yt[t * kGenVox + vl]) * is[t * kGenVox + vl];
+                        acc = fmaf(r, r, acc);
+                    }
+                    nll_sum += acc;
+                }
+            }
+            nll_sum = fmaf(0.5f, nll_sum, (float)n_lik * log_s_sum);
+            float pv[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) pv[i] = prior[v * 5 + i];
+            const qb::LogitMvn pm = qb::make_mvn(pv);
+            for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
+                float z[4];
+                const bool two = 2 * j + 1 < K;
+                if (zkv) {
+                    z[0] = zkv[4 * j];
+                    z[1] = zkv[4 * j + 1];
+                    z[2] = two ? zkv[4 * j + 2] : 0.0f;
+                    z[3] = two ? zkv[4 * j + 3] : 0.0f;
+                } else {
+                    qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_KL, z);
+                }
+                n_kl += two ? 2 : 1;
+                kl_sum += qb::kl_swr_diff(qm, pm, z[0], z[1]);
+                if (two) kl_sum += qb::kl_swr_diff(qm, pm, z[2], z[3]);
+            }
+            kl_sum = fmaf(0.5f, kl_sum, (float)n_kl * ((pm.s_o + pm.s_d) - (qm.s_o + qm.s_d)));
+            const float nll = qb::voxel_sum(nll_sum) / (float)S;
+            const float kl = K > 0 ? qb::voxel_sum(kl_sum) / (float)K : 0.0f;
+            if (part == 0) {
+                if (nll_kl) nll_kl[v] = make_float2(nll, kl);
+                s_nll += nll * m;
+                s_kl += m > 0.0f ? kl : 0.0f;
+                s_m += m;
+            }
+        }
+    }
+    qb::block_partials(red, s_nll, s_kl, s_m, partials);
+}
+
 __global__ void reparam_kernel(const float* __restrict__ q, const float2* __restrict__ z,
                                float2* __restrict__ out, int64_t N) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N;
@@ -210,9 +329,19 @@ extern "C" int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float*
             else if (lit) QB_LAUNCH_ELBO(24, -1, false, true);
             else QB_LAUNCH_ELBO(24, -1, false, false);
             break;
-        default:
-            qb::set_error("qbold_elbo_fwd: kernels are built for T = 11 or 24 taus");
-            return QBOLD_ERR_UNSUPPORTED;
+        default: {
+            if (!fast) {
+                qb::set_error("qbold_elbo_fwd: for T other than 11 / 24 only the optimal.yaml "
+                              "configuration (table mode, Gaussian likelihood, linear data) is built");
+                return QBOLD_ERR_UNSUPPORTED;
+            }
+            const int64_t gt = (N + kGenVox - 1) / kGenVox;
+            grid = (int)(gt < qb::elbo_grid(ctx) ? (gt > 0 ? gt : 1) : qb::elbo_grid(ctx));
+            const size_t smem = sizeof(qb::FwdLds) + sizeof(float) * 2 * QB_MAX_T * kGenVox;
+            hipLaunchKernelGGL(elbo_fwd_generic_kernel, dim3(grid), dim3(kGenBlock), smem, s, ctx->dev,
+                               ctx->d_tab, x, mask, q, prior, sigma, zs, zk, S, K, seed, voxel0, out,
+                               partials, N);
+        }
     }
 #undef QB_LAUNCH_ELBO
     QB_HIP(hipGetLastError());

@@ -52,6 +52,7 @@ __global__ void transform_kernel(int op, const float* __restrict__ in, float* __
                 if (op == QBOLD_BACKWARDS_TRANSFORM_LOGIT) r = logf(r / (1.0f - r));
                 break;
             }
+            case QBOLD_EXP: r = expf(v); break;
             default: r = v;
         }
         out[i] = r;
@@ -256,9 +257,9 @@ extern "C" int qbold_transform(const qbold_ctx* ctx, int op, const float* in, fl
     QB_NEED_DEVICE(ctx);
     if (n == 0) return QBOLD_OK;
     QB_REQUIRE(n > 0 && in && out, "qbold_transform: bad argument");
-    QB_REQUIRE(op >= QBOLD_TRANSFORM_STD && op <= QBOLD_BACKWARDS_TRANSFORM_LOGIT,
+    QB_REQUIRE(op >= QBOLD_TRANSFORM_STD && op <= QBOLD_EXP,
                "qbold_transform: unknown op");
-    QB_REQUIRE(op < QBOLD_FORWARD_TRANSFORM || (n % 2) == 0,
+    QB_REQUIRE(op < QBOLD_FORWARD_TRANSFORM || op == QBOLD_EXP || (n % 2) == 0,
                "qbold_transform: pair transforms need an even element count");
     hipLaunchKernelGGL(transform_kernel, dim3(ew_grid(ctx, n, 256)), dim3(256), 0, (hipStream_t)stream,
                        op, in, out, n);

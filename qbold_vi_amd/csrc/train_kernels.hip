@@ -22,7 +22,8 @@ namespace {
 using qb::f32x4;
 #define QB_MFMA16F(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-constexpr int kLd = 64;        // row stride of every activation / delta tensor
+constexpr int kLd = 64;        // row stride of the activation / delta tensors for U <= 64
+constexpr int kMaxU = 256;     // forward-only layer-wise path (BASELINE config 3)
 constexpr int kWs = 65;        // LDS row stride of a staged weight matrix
 
 enum { ACT_NONE = 0, ACT_RELU = 1 };
@@ -31,22 +32,27 @@ enum { ACT_NONE = 0, ACT_RELU = 1 };
 //   trans = 0: Wl[k][j] = W[k * ldw + j]   (forward, W canonical [in][out])
 //   trans = 1: Wl[k][j] = W[j * ldw + k]   (backward-data: dX = dY . W^T)
 // accum: Y += ...;  mask: result *= (mask[v][j] > 0)  (relu backward)
+// blockIdx.y selects a 64-column slab of the output; the block stages that slab of W for the whole
+// K range (kpad rows, kpad = kdim rounded up to 4) in dynamic LDS.  kdim, ndim <= 256.
 __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, int ldx, int kdim,
                                                  const float* __restrict__ W, int ldw, int trans,
                                                  const float* __restrict__ b, float* __restrict__ Y,
                                                  int ldy, int ndim, int act, int accum,
                                                  const float* __restrict__ mask, int ldm, int64_t N) {
-    __shared__ float Wl[64 * kWs];
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-        const int k = e >> 6, j = e & 63;
+    extern __shared__ float Wl[];
+    const int n0 = blockIdx.y * 64;
+    const int kpad = (kdim + 3) & ~3;
+    for (int e = threadIdx.x; e < kpad * 64; e += 256) {
+        const int k = e >> 6, j = n0 + (e & 63);
         float v = 0.0f;
         if (k < kdim && j < ndim) v = trans ? W[j * ldw + k] : W[k * ldw + j];
-        Wl[k * kWs + j] = v;
+        Wl[k * kWs + (e & 63)] = v;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
     const int64_t ntile = (N + 15) / 16;
+    const int ksteps = kpad >> 2;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
         const int64_t v0 = tile * 16;
         const int64_t va = v0 + i < N ? v0 + i : N - 1;
@@ -54,7 +60,7 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const float* xr = X + va * ldx;
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < ksteps; ++s) {
             const int k = 4 * s + g;
             const float a = k < kdim ? xr[k] : 0.0f;
             const float* wr = Wl + k * kWs + i;
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const int j = 16 * m + i;
+            const int j = n0 + 16 * m + i;
             if (j >= ndim) continue;
             const float bj = b ? b[j] : 0.0f;
 #pragma unroll
@@ -155,7 +161,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ partial, int nblk, 
 
 // normalise_data into a [N][64] slot (model.py:97-113)
 __global__ void normalise64_kernel(QbDev c, const float* __restrict__ x, float* __restrict__ out,
-                                   int64_t N) {
+                                   int ld, int64_t N) {
     const int T = c.T, se = c.se_idx;
     for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < N;
          v += (int64_t)gridDim.x * blockDim.x) {
@@ -166,22 +172,22 @@ __global__ void normalise64_kernel(QbDev c, const float* __restrict__ x, float* 
                    qb::clampf_(xv[se + 1], 1e-2f, 1e8f)) / 3.0f;
         else
             den = qb::clampf_(xv[se], 1e-2f, 1e8f);
-        for (int t = 0; t < T; ++t) out[v * kLd + t] = logf(qb::clampf_(xv[t], 1e-2f, 1e8f) / den);
+        for (int t = 0; t < T; ++t) out[v * ld + t] = logf(qb::clampf_(xv[t], 1e-2f, 1e8f) / den);
     }
 }
 
 // gate: gl <- g = sigmoid(gl + offset);  bout = skip (1 - g) + r g          (model.py:167-170)
 __global__ void gate_fwd_kernel(float* __restrict__ gl, const float* __restrict__ skip,
                                 const float* __restrict__ r, float* __restrict__ bout, float offset,
-                                int U, int G, int64_t N) {
-    const int64_t total = N * kLd;
+                                int U, int G, int ld, int64_t N) {
+    const int64_t total = N * ld;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
-        const int j = (int)(e & 63);
-        const int64_t v = e >> 6;
+        const int j = (int)(e % ld);
+        const int64_t v = e / ld;
         float o = 0.0f;
         if (j < U) {
-            const float gate = 1.0f / (1.0f + expf(-(gl[v * kLd + (G == 1 ? 0 : j)] + offset)));
+            const float gate = 1.0f / (1.0f + expf(-(gl[v * ld + (G == 1 ? 0 : j)] + offset)));
             o = skip[e] * (1.0f - gate) + r[e] * gate;
         }
         bout[e] = o;
@@ -293,17 +299,30 @@ struct Launcher {
     const qbold_ctx* ctx;
     hipStream_t s;
     int64_t N;
+    int ld;  // row stride of the activation tensors (64, or U rounded up to 64 beyond that)
     int grid() const {
         int64_t nb = (N + 63) / 64;
         int64_t cap = (int64_t)ctx->num_cus * 8;
         return (int)(nb < cap ? (nb > 0 ? nb : 1) : cap);
     }
+    // Y (row stride ldy) = act(X W + b); ndim output columns in slabs of 64
+    int xw_ld(const float* X, int ldx, int kdim, const float* W, int ldw, int trans, const float* b,
+              float* Y, int ldy, int ndim, int act, int accum, const float* mask) const {
+        const size_t smem = sizeof(float) * (size_t)((kdim + 3) & ~3) * kWs;
+        if (smem > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xw_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return qb::hip_fail(e, "hipFuncSetAttribute(xw_kernel)");
+        }
+        hipLaunchKernelGGL(xw_kernel, dim3(grid(), (ndim + 63) / 64), dim3(256), smem, s, X, ldx, kdim, W,
+                           ldw, trans, b, Y, ldy, ndim, act, accum, mask, ld, N);
+        return QBOLD_OK;
+    }
     void xw(const float* X, int ldx, int kdim, const float* W, int ldw, int trans, const float* b,
             float* Y, int ndim, int act, int accum, const float* mask) const {
-        hipLaunchKernelGGL(xw_kernel, dim3(grid()), dim3(256), 0, s, X, ldx, kdim, W, ldw, trans, b, Y,
-                           kLd, ndim, act, accum, mask, kLd, N);
+        (void)xw_ld(X, ldx, kdim, W, ldw, trans, b, Y, ld, ndim, act, accum, mask);
     }
-    // dW (+)= X^T D, db (+)= sum D
+    // dW (+)= X^T D, db (+)= sum D   (U <= 64 only)
     void xtd(const float* X, int kdim, const float* D, int ndim, float* partial, int nblk, float* dW,
              int ldw, float* db, int accum) const {
         hipLaunchKernelGGL(xtd_kernel, dim3(nblk), dim3(256), 0, s, X, kLd, kdim, D, kLd, ndim, partial, N);
@@ -311,11 +330,24 @@ struct Launcher {
                            nblk, dW, ldw, kdim, ndim, db, accum);
     }
     int ew() const {
-        int64_t nb = (N * kLd + 255) / 256;
+        int64_t nb = (N * ld + 255) / 256;
         int64_t cap = (int64_t)ctx->num_cus * 8;
         return (int)(nb < cap ? (nb > 0 ? nb : 1) : cap);
     }
 };
+
+int train_ld(int U) { return U <= 64 ? kLd : ((U + 63) / 64) * 64; }
+
+// the layer-wise path accepts wider / longer encoders than the LDS-resident fused kernels
+int check_layerwise_shape(const qbold_ctx* ctx, const qbold_encoder_shape* s) {
+    if (!s) { qb::set_error("encoder shape is null"); return QBOLD_ERR_INVALID; }
+    if (s->T != ctx->dev.T) { qb::set_error("encoder shape T differs from the context's tau grid"); return QBOLD_ERR_INVALID; }
+    if (s->U < 1 || s->U > kMaxU || s->L < 1 || s->L > 8) {
+        qb::set_error("layer-wise encoder path: need 1 <= U <= 256, 1 <= L <= 8");
+        return QBOLD_ERR_UNSUPPORTED;
+    }
+    return QBOLD_OK;
+}
 
 constexpr int kSlabBlocks = 128;
 
@@ -329,59 +361,59 @@ constexpr int kSlabBlocks = 128;
 extern "C" int64_t qbold_train_workspace_floats(const qbold_encoder_shape* shape, int64_t N) {
     if (!shape || N < 0) return QBOLD_ERR_INVALID;
     const int64_t slots = 2 + 5 * (int64_t)shape->L + 5;  // activations + 5 delta scratch tensors
-    return slots * N * kLd + (int64_t)kSlabBlocks * (64 * 64 + 64);
+    return slots * N * train_ld(shape->U) + (int64_t)kSlabBlocks * (64 * 64 + 64);
 }
 
 extern "C" int qbold_encoder_train_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
                                        const float* w, const float* x, int stream_sel, float* ws,
                                        float* out_q, float* out_log_sigma, int64_t N, void* stream) {
     QB_NEED_DEVICE(ctx);
-    int rc = qb::check_encoder_shape(ctx, shape);
+    int rc = check_layerwise_shape(ctx, shape);
     if (rc) return rc;
     QB_REQUIRE(N > 0 && w && x && ws && out_q, "qbold_encoder_train_fwd: bad argument");
     QB_REQUIRE(stream_sel == 1 || stream_sel == 2, "qbold_encoder_train_fwd: stream must be 1 or 2");
     const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating);
     const int T = c.T, U = c.U, L = c.L, G = c.G;
-    Launcher k{ctx, (hipStream_t)stream, N};
-    auto slot = [&](int i) { return ws + (int64_t)i * N * kLd; };
-    hipLaunchKernelGGL(normalise64_kernel, dim3(k.grid()), dim3(256), 0, k.s, ctx->dev, x, slot(0), N);
-    k.xw(slot(0), kLd, T, w + c.W0, U, 0, w + c.b0, slot(1), U, ACT_RELU, 0, nullptr);
+    const int ld = train_ld(U);
+    Launcher k{ctx, (hipStream_t)stream, N, ld};
+    auto slot = [&](int i) { return ws + (int64_t)i * N * ld; };
+    // slot 0 holds the normalised input with its own row stride (T may exceed ld only if T > 64: not allowed)
+    QB_HIP(hipMemsetAsync(slot(0), 0, sizeof(float) * N * ld, k.s));
+    hipLaunchKernelGGL(normalise64_kernel, dim3(k.grid()), dim3(256), 0, k.s, ctx->dev, x, slot(0), ld, N);
+    k.xw(slot(0), ld, T, w + c.W0, U, 0, w + c.b0, slot(1), U, ACT_RELU, 0, nullptr);
     const float* cur = slot(1);
-    float* head = slot(2 + 5 * L);  // scratch slot for the head output [N][64]
+    float* head = slot(2 + 5 * L);  // scratch slot for the head output
     if (stream_sel == 1) {
         for (int l = 0; l < L; ++l) {
             const float* wb = w + c.blk0 + l * c.blk_stride;
-            k.xw(cur, kLd, U, wb + c.Wc, U, 0, wb + c.bc, slot(2 + l), U, ACT_RELU, 0, nullptr);
+            k.xw(cur, ld, U, wb + c.Wc, U, 0, wb + c.bc, slot(2 + l), U, ACT_RELU, 0, nullptr);
             cur = slot(2 + l);
         }
-        k.xw(cur, kLd, U, w + c.Wf, 5, 0, w + c.bf, head, 5, ACT_NONE, 0, nullptr);
     } else {
         for (int l = 0; l < L; ++l) {
             const float* wb = w + c.blk0 + l * c.blk_stride;
             float* skip = slot(2 + 5 * l), *t = slot(3 + 5 * l), *r = slot(4 + 5 * l);
             float* gl = slot(5 + 5 * l), *bout = slot(6 + 5 * l);
-            k.xw(cur, kLd, U, wb + c.Wc, U, 0, wb + c.bc, skip, U, ACT_RELU, 0, nullptr);
+            k.xw(cur, ld, U, wb + c.Wc, U, 0, wb + c.bc, skip, U, ACT_RELU, 0, nullptr);
             // relu(b) feeds the first residual conv; block 0's input h is already >= 0
-            hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, cur, bout, N * kLd);
-            k.xw(bout, kLd, U, wb + c.Wr1, U, 0, wb + c.br1, t, U, ACT_RELU, 0, nullptr);
-            k.xw(t, kLd, U, wb + c.Wr2, U, 0, wb + c.br2, r, U, ACT_NONE, 0, nullptr);
-            k.xw(r, kLd, U, wb + c.Wg, G, 0, wb + c.bg, gl, G, ACT_NONE, 0, nullptr);
+            hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, cur, bout, N * ld);
+            k.xw(bout, ld, U, wb + c.Wr1, U, 0, wb + c.br1, t, U, ACT_RELU, 0, nullptr);
+            k.xw(t, ld, U, wb + c.Wr2, U, 0, wb + c.br2, r, U, ACT_NONE, 0, nullptr);
+            k.xw(r, ld, U, wb + c.Wg, G, 0, wb + c.bg, gl, G, ACT_NONE, 0, nullptr);
             hipLaunchKernelGGL(gate_fwd_kernel, dim3(k.ew()), dim3(256), 0, k.s, gl, skip, r, bout,
-                               shape->gate_offset, U, G, N);
+                               shape->gate_offset, U, G, ld, N);
             cur = bout;
         }
-        // merged head: cols 0-4 = Wf, 5.. = Ws  (two launches into one [N][64] tensor)
-        k.xw(cur, kLd, U, w + c.Wf, 5, 0, w + c.bf, head, 5, ACT_NONE, 0, nullptr);
+    }
+    // heads straight into the caller's [N][5] / [N][T] buffers
+    rc = k.xw_ld(cur, ld, U, w + c.Wf, 5, 0, w + c.bf, out_q, 5, 5, ACT_NONE, 0, nullptr);
+    if (rc) return rc;
+    (void)head;
+    if (stream_sel == 2 && out_log_sigma) {
+        rc = k.xw_ld(cur, ld, U, w + c.Ws, T, 0, w + c.bs, out_log_sigma, T, T, ACT_NONE, 0, nullptr);
+        if (rc) return rc;
     }
     QB_HIP(hipGetLastError());
-    // unpack the head: q [N][5] (and log sigma [N][T] through a second GEMM straight into place)
-    QB_HIP(hipMemcpy2DAsync(out_q, 5 * sizeof(float), head, kLd * sizeof(float), 5 * sizeof(float), N,
-                            hipMemcpyDeviceToDevice, k.s));
-    if (stream_sel == 2 && out_log_sigma) {
-        hipLaunchKernelGGL(xw_kernel, dim3(k.grid()), dim3(256), 0, k.s, cur, kLd, U, w + c.Ws, T, 0,
-                           w + c.bs, out_log_sigma, T, T, ACT_NONE, 0, (const float*)nullptr, 0, N);
-        QB_HIP(hipGetLastError());
-    }
     return QBOLD_OK;
 }
 
@@ -392,13 +424,17 @@ extern "C" int qbold_encoder_train_bwd(const qbold_ctx* ctx, const qbold_encoder
                                        const float* g_ls, const double* sums, float* grad, int64_t N,
                                        void* stream) {
     QB_NEED_DEVICE(ctx);
-    int rc = qb::check_encoder_shape(ctx, shape);
+    int rc = check_layerwise_shape(ctx, shape);
     if (rc) return rc;
+    if (shape->U > 64) {
+        qb::set_error("qbold_encoder_train_bwd: gradients are built for U <= 64");
+        return QBOLD_ERR_UNSUPPORTED;
+    }
     QB_REQUIRE(N > 0 && w && ws && g_q && grad, "qbold_encoder_train_bwd: bad argument");
     QB_REQUIRE(stream_sel == 1 || stream_sel == 2, "qbold_encoder_train_bwd: stream must be 1 or 2");
     const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating);
     const int T = c.T, U = c.U, L = c.L, G = c.G;
-    Launcher k{ctx, (hipStream_t)stream, N};
+    Launcher k{ctx, (hipStream_t)stream, N, kLd};
     auto slot = [&](int i) { return ws + (int64_t)i * N * kLd; };
     const int base = 2 + 5 * L;
     float* dA = slot(base), *dB = slot(base + 1), *dC = slot(base + 2), *dD = slot(base + 3),

@@ -192,10 +192,29 @@ class Context:
         return out
 
     # -- encoder ---------------------------------------------------------------------------
+    @staticmethod
+    def fits_fused(shape):
+        """The LDS-resident fused kernels cover U <= 64, L <= 2, T in {11, 24}; anything else (e.g.
+        BASELINE config 3: U = 256, T = 64) takes the layer-wise GEMM path."""
+        return shape.U <= 64 and shape.L <= 2 and shape.T in (11, 24)
+
     def encoder_fwd(self, weights, x, want=("out1", "out2", "sigma")):
         x = _f32(x, "x", self.T)
         N = x.numel() // self.T
         lead = x.shape[:-1]
+        if not self.fits_fused(weights.shape):
+            st = getattr(weights, "_layerwise_state", None)
+            if st is None:  # activation workspace is kept with the weights, not re-allocated per call
+                st = weights._layerwise_state = TrainState(self, weights, optimiser_state=False)
+            x2 = x.reshape(N, self.T)
+            o1 = o2 = sg = None
+            if "out1" in want:
+                o1 = st.forward(x2, 1)[0].reshape(lead + (5,))
+            if "out2" in want or "sigma" in want:
+                q2, ls = st.forward(x2, 2)
+                o2 = q2.reshape(lead + (5,)) if "out2" in want else None
+                sg = self.transform("exp", ls).reshape(lead + (self.T,)) if "sigma" in want else None
+            return o1, o2, sg
         mk = lambda c: torch.empty(lead + (c,), dtype=torch.float32, device=x.device)
         o1 = mk(5) if "out1" in want else None
         o2 = mk(5) if "out2" in want else None
@@ -267,6 +286,10 @@ class Context:
         N = x.numel() // self.T
         prior = _f32(prior, "prior", 5)
         mask = _f32(mask, "mask") if mask is not None else None
+        if not self.fits_fused(weights.shape):  # unfused composition of the same pieces
+            _, q2, sg = self.encoder_fwd(weights, x.reshape(N, self.T), want=("out2", "sigma"))
+            sums, nk = self.elbo_fwd(x, mask, q2, prior, sg, S, K, seed=seed, voxel0=voxel0)
+            return sums, (q2 if want_q else None), (nk if per_voxel else None)
         if out is None:
             sums = torch.empty(3, dtype=torch.float64, device=x.device)
             qo = torch.empty((N, 5), dtype=torch.float32, device=x.device) if want_q else None
@@ -283,7 +306,7 @@ class Context:
 # --------------------------------------------------------------------------------------------
 # the small pieces of the API surface (misc_kernels.hip)
 # --------------------------------------------------------------------------------------------
-TRANSFORM_OPS = {"transform_std": 0, "transform_offdiag": 1, "inv_transform_std": 2,
+TRANSFORM_OPS = {"exp": 6, "transform_std": 0, "transform_offdiag": 1, "inv_transform_std": 2,
                  "forward_transform": 3, "backwards_transform": 4, "backwards_transform_logit": 5}
 
 
@@ -400,10 +423,10 @@ def elbo_bwd(self, x, mask, q, prior, log_sigma, S=1, K=70, seed=1, voxel0=0):
 class TrainState:
     """Flat AdamW state of one encoder + the activation workspace of the training kernels."""
 
-    def __init__(self, ctx, weights):
+    def __init__(self, ctx, weights, optimiser_state=True):
         self.ctx = ctx
         self.weights = weights
-        n = weights.num_params
+        n = weights.num_params if optimiser_state else 1
         dev = weights.flat.device
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)

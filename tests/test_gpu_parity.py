@@ -322,3 +322,45 @@ def test_24_tau_protocol(params):
     assert torch.allclose(nk, nk2, rtol=1e-4, atol=1e-4)
     s3, gq, gls, nk3 = ctx.elbo_bwd(dev(x), dev(mask), q, dev(prior), torch.log(sg), S, K, seed=seed)
     assert torch.allclose(nk3, nk2, rtol=1e-4, atol=1e-4) and bool(torch.isfinite(gq).all())
+
+
+def test_config3_wide_encoder_64_taus(params):
+    """BASELINE config 3 shapes (T = 64 taus, encoder width 256, SURVEY H6 tau grid) through the
+    layer-wise GEMM encoder and the any-T ELBO kernel, against the oracle at small N."""
+    from oracle.oracle import Oracle, init_weights, synth_inputs
+    from qbold_vi_amd.ops import Context, EncoderWeights
+    p = dict(params, tau_start="-0.015", tau_end="0.065", tau_step="0.00125")
+    orc = Oracle("f32", p)
+    ctx = Context(p, full_model=True, include_blood=True)
+    assert ctx.T == orc.T == 64 and ctx.se_idx == 12
+    n, S, K, seed = 700, 4, 6, 5
+    x, _ = synth_inputs(n, p, seed=3, noise=False, oracle=orc)
+    x = (x * (1 + 0.01 * np.random.default_rng(1).standard_normal(x.shape))).astype(np.float32)
+    assert rel(ctx.signal_fwd(dev(synth_inputs(50, p, seed=1, noise=False, oracle=orc)[1])).cpu().numpy(),
+               orc.signal_fwd(synth_inputs(50, p, seed=1, noise=False, oracle=orc)[1])) < 1e-5
+    for U, L in ((256, 2), (100, 3)):
+        w = init_weights(T=64, U=U, L=L, seed=U)
+        w["gate_offset"] = -3.0
+        ew = EncoderWeights(ctx, 64, U, L, True, -3.0).set_from_arrays(w)
+        prior, q_want, sigma = orc.encoder_fwd(w, x)
+        o1, o2, sg = ctx.encoder_fwd(ew, dev(x))
+        assert np.max(np.abs(o1.cpu().numpy() - prior)) < 5e-5
+        assert np.max(np.abs(o2.cpu().numpy() - q_want)) < 5e-5
+        assert rel(sg.cpu().numpy(), sigma) < 5e-5
+        mask = (np.random.default_rng(2).uniform(size=n) > 0.1).astype(np.float32)
+        want = orc.elbo(x, mask, q_want, prior, sigma, orc.philox_normals(seed, 0, 0, n, S),
+                        orc.philox_normals(seed, 1, 0, n, K))
+        sums, q, nk = ctx.vi_fwd(ew, dev(x), dev(mask), dev(prior), S, K, seed=seed)
+        sums = sums.cpu().numpy()
+        assert abs((sums[0] + sums[1]) / sums[2] - want["elbo"]) < 1e-4 * abs(want["elbo"])
+        assert rel(nk.cpu().numpy()[:, 0], want["nll_v"], 1.0) < 5e-4
+        # explicit normals through the any-T kernel as well
+        rng = np.random.default_rng(4)
+        zs = rng.standard_normal((n, S, 2)).astype(np.float32)
+        zk = rng.standard_normal((n, K, 2)).astype(np.float32)
+        want2 = orc.elbo(x, mask, q_want, prior, sigma, zs, zk)
+        s2, nk2 = ctx.elbo_fwd(dev(x), dev(mask), dev(q_want), dev(prior), dev(sigma), S, K, dev(zs), dev(zk))
+        # 64 residuals at sigma ~ 0.05 with an untrained posterior: |r| ~ 4, so the table's ~2e-6
+        # signal error is amplified to a few 1e-4 of a per-voxel NLL of order 1e3
+        assert rel(nk2.cpu().numpy()[:, 0], want2["nll_v"], 1.0) < 5e-4
+        assert np.max(np.abs(nk2.cpu().numpy()[:, 1] - want2["kl_v"]) / (np.abs(want2["kl_v"]) + 1.0)) < 1e-4
