@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define QBOLD_MAX_T 64
-#define QBOLD_ABI_VERSION 1
+#define QBOLD_ABI_VERSION 2
 
 typedef enum {
     QBOLD_OK = 0,
@@ -71,7 +71,15 @@ typedef struct {
     int32_t L;                  /* no_intermediate_layers */
     int32_t channelwise_gating; /* model.py:160-162 */
     float gate_offset;          /* model.py:169 */
+    int32_t spatial_taps;       /* 1: Wr1/Wr2 hold the centre tap [U][U] only (voxel batches);
+                                   9: full 3x3x1 kernels [3][3][U][U] in Keras order (model.py:152-157) */
 } qbold_encoder_shape;
+
+/* Image-crop geometry of a [B][X][Y][Z][C] batch (train.py:17-72): voxel v = ((b X + x) Y + y) Z + z.
+ * The 3x3x1 'same' convolutions couple (x, y) neighbours within one b and z. */
+typedef struct {
+    int32_t B, X, Y, Z;
+} qbold_geometry;
 
 typedef struct qbold_ctx qbold_ctx;
 
@@ -111,8 +119,8 @@ int qbold_signal_bwd(const qbold_ctx* ctx, const float* oef_dbv, const float* gr
 
 /* ---- encoder ------------------------------------------------------------------------------- */
 /* Number of floats of the canonical (Keras-orientation, [in][out]) weight blob:
- * W0[T][U] b0[U] { Wc[U][U] bc[U] Wr1[U][U] br1[U] Wr2[U][U] br2[U] Wg[U][G] bg[G] } x L
- * Wf[U][5] bf[5] Ws[U][T] bs[T]   (model.py:181,144,152,156,164,196,211-214). */
+ * W0[T][U] b0[U] { Wc[U][U] bc[U] Wr1[taps][U][U] br1[U] Wr2[taps][U][U] br2[U] Wg[U][G] bg[G] } x L
+ * Wf[U][5] bf[5] Ws[U][T] bs[T]   (model.py:181,144,152,156,164,196,211-214); taps = spatial_taps. */
 int64_t qbold_encoder_num_params(const qbold_encoder_shape* shape);
 /* Size in floats of the device workspace holding the MFMA-ordered copy of the weights. */
 int64_t qbold_encoder_packed_floats(const qbold_encoder_shape* shape);
@@ -235,6 +243,19 @@ int64_t qbold_train_workspace_floats(const qbold_encoder_shape* shape, int64_t N
 int qbold_encoder_train_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* weights,
                             const float* x, int stream_sel, float* workspace, float* out_q,
                             float* out_log_sigma, int64_t N, void* stream);
+/* The same on image crops: geom->B*X*Y*Z voxels, stream 2 with its 3x3x1 'same' convolutions
+ * (shape->spatial_taps must be 9).  geom = NULL is the voxel-batch call above. */
+int qbold_encoder_spatial_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* weights,
+                              const float* x, const qbold_geometry* geom, float* workspace, float* out_q,
+                              float* out_log_sigma, void* stream);
+int qbold_encoder_spatial_bwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* weights,
+                              const qbold_geometry* geom, float* workspace, const float* g_q,
+                              const float* g_log_sigma, const double* sums, float* grad, void* stream);
+/* smoothness_loss (model.py:726-754) on crops: q [V][5], mask [V].  tv_sum: DEVICE double[1] =
+ * sum |dx| + sum |dy| (divide by sum(mask)); if g_q is not NULL, weight * d tv_sum / d q is ADDED to
+ * g_q [V][5] (unnormalised, like qbold_elbo_bwd's output). */
+int qbold_smoothness(const qbold_ctx* ctx, const float* q, const float* mask, const qbold_geometry* geom,
+                     float weight, float* g_q, double* tv_sum, void* stream);
 /* g_q [N][5], g_log_sigma [N][T] (stream 2; may be NULL): gradients of the loss with respect to
  * the head outputs.  sums: DEVICE double[3] whose [2] is sum(mask) -- the head gradients are
  * divided by it (NULL: already normalised).  grad: canonical layout, overwritten. */

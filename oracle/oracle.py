@@ -46,7 +46,8 @@ class _LossCfg(C.Structure):
 def _weights_struct(ptr_t):
     class _Weights(C.Structure):
         _fields_ = [("T", C.c_int32), ("U", C.c_int32), ("L", C.c_int32),
-                    ("channelwise_gating", C.c_int32), ("gate_offset", C.c_double)] + \
+                    ("channelwise_gating", C.c_int32), ("taps", C.c_int32),
+                    ("gate_offset", C.c_double)] + \
                    [(n, ptr_t) for n in ("W0", "b0", "Wc", "bc", "Wr1", "br1", "Wr2", "br2",
                                          "Wg", "bg", "Wf", "bf", "Ws", "bs")]
     return _Weights
@@ -64,12 +65,14 @@ def weight_shapes(T, U, L, channelwise_gating=True):
 
 
 def init_weights(T=11, U=60, L=2, channelwise_gating=True, resid_init_std=0.05,
-                 im_loss_sigma=0.05, seed=1):
+                 im_loss_sigma=0.05, seed=1, taps=1):
     """Reference initialisers (model.py:119,129,211-214): HeNormal (truncated normal, stddev
     sqrt(2/fan_in)/0.8796) for the 1x1x1 layers, N(0, resid_init_std) for residual / gating /
     sigma-head kernels, zero biases except the sigma head (log im_loss_sigma)."""
     rng = np.random.default_rng(seed)
     shapes = weight_shapes(T, U, L, channelwise_gating)
+    if taps == 9:  # full 3x3x1 kernels [L][3][3][U][U] (Keras layout) for the residual convolutions
+        shapes["Wr1"] = shapes["Wr2"] = (L, 3, 3, U, U)
 
     def he(shape, fan_in):
         std = np.sqrt(2.0 / fan_in) / 0.87962566103423978
@@ -89,7 +92,7 @@ def init_weights(T=11, U=60, L=2, channelwise_gating=True, resid_init_std=0.05,
     for n in ("b0", "bc", "br1", "br2", "bg", "bf"):
         w[n] = np.zeros(shapes[n], np.float32)
     w["bs"] = np.full(shapes["bs"], np.log(im_loss_sigma), np.float32)
-    w["meta"] = dict(T=T, U=U, L=L, channelwise_gating=bool(channelwise_gating))
+    w["meta"] = dict(T=T, U=U, L=L, channelwise_gating=bool(channelwise_gating), taps=taps)
     return w
 
 
@@ -156,7 +159,8 @@ class Oracle:
         meta = w["meta"]
         keep = [self._a(w[n]) for n in WEIGHT_NAMES]
         ws = self._W(meta["T"], meta["U"], meta["L"], int(meta["channelwise_gating"]),
-                     float(w.get("gate_offset", 0.0)), *[self._p(a) for a in keep])
+                     int(meta.get("taps", 1)), float(w.get("gate_offset", 0.0)),
+                     *[self._p(a) for a in keep])
         return ws, keep
 
     # -- scalar functions ----------------------------------------------------------------
@@ -215,6 +219,28 @@ class Oracle:
                                  self._p(o2), self._p(sg), C.c_int64(N))
         del keep
         return o1, o2, sg
+
+    def encoder_fwd_spatial(self, w, x):
+        """x [B, X, Y, Z, T] -> (out2 [B,X,Y,Z,5], sigma [B,X,Y,Z,T]); needs 9-tap weights."""
+        x = self._a(x)
+        B, X, Y, Z, T = x.shape
+        ws, keep = self._weights(w)
+        assert ws.taps == 9 and T == ws.T
+        o2 = np.empty((B, X, Y, Z, 5), self.dtype)
+        sg = np.empty((B, X, Y, Z, T), self.dtype)
+        self.lib.qbo_encoder_fwd_spatial(C.byref(ws), C.byref(self.cfg), self._p(x), B, X, Y, Z,
+                                         self._p(o2), self._p(sg))
+        del keep
+        return o2, sg
+
+    def smoothness_loss(self, q, mask):
+        """model.py:726-754 on q [B,X,Y,Z,5], mask [B,X,Y,Z]."""
+        q = self._a(q)
+        B, X, Y, Z, _ = q.shape
+        mask = self._a(mask, (B, X, Y, Z))
+        self.lib.qbo_smoothness_sum.restype = C.c_double
+        s = self.lib.qbo_smoothness_sum(self._p(q), self._p(mask), B, X, Y, Z)
+        return s / float(mask.sum())
 
     # -- logit-normal --------------------------------------------------------------------
     def reparam(self, q, z):

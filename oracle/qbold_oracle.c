@@ -377,6 +377,12 @@ void qbo_normalise(const qbo_loss_cfg *C, const real *x, real *n, int T, int64_t
 
 static inline real sigmoidr(real v) { return R(1) / (R(1) + r_exp(-v)); }
 
+/* ranges of forward_transform -- model.py:88-91 */
+#define OEF_RANGE R(0.8)
+#define MIN_OEF R(0.04)
+#define DBV_RANGE R(0.2)
+#define MIN_DBV R(0.001)
+
 /* y[o] = act(sum_i x[i] W[i][o] + b[o]) ; W is [nin][nout] (Keras kernel orientation). */
 static void dense(const real *x, const real *W, const real *b, real *y, int nin, int nout,
                   int relu) {
@@ -407,8 +413,10 @@ void qbo_encoder_fwd(const qbo_weights *W, const qbo_loss_cfg *C, const real *x,
             memcpy(a, tmp, sizeof(real) * U);
             dense(b, Wc, bc, skip, U, U, 1); /* shared conv as skip, model.py:148 */
             for (int i = 0; i < U; ++i) tmp[i] = b[i] > 0 ? b[i] : 0; /* model.py:151 */
-            dense(tmp, W->Wr1 + (int64_t)l * U * U, W->br1 + l * U, t1, U, U, 1); /* :152,155 */
-            dense(t1, W->Wr2 + (int64_t)l * U * U, W->br2 + l * U, r, U, U, 0);   /* :156 */
+            /* a (N,1,1,1,T) batch sees only the centre tap of a 'same'-padded 3x3x1 kernel */
+            const int64_t ts = (int64_t)(W->taps == 9 ? 9 : 1) * U * U, tc = W->taps == 9 ? 4 * U * U : 0;
+            dense(tmp, W->Wr1 + l * ts + tc, W->br1 + l * U, t1, U, U, 1); /* :152,155 */
+            dense(t1, W->Wr2 + l * ts + tc, W->br2 + l * U, r, U, U, 0);   /* :156 */
             dense(r, W->Wg + (int64_t)l * U * G, W->bg + l * G, gt, U, G, 0);     /* :164 */
             for (int i = 0; i < U; ++i) { /* gate_convs, model.py:167-170 */
                 real gate = sigmoidr(gt[G == 1 ? 0 : i] + goff);
@@ -434,15 +442,108 @@ void qbo_encoder_fwd(const qbo_weights *W, const qbo_loss_cfg *C, const real *x,
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Encoder on image volumes: stream 2 with its 3x3x1 'same' convolutions -- model.py:142-174.
+ * Layer by layer over the whole volume (the convolutions couple x/y neighbours).
+ * ---------------------------------------------------------------------------------------- */
+static void conv3x3(const real *in, const real *K /*[3][3][U][U]*/, const real *b, real *out, int B,
+                    int X, int Y, int Z, int U, int relu_out) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int bb = 0; bb < B; ++bb)
+        for (int x = 0; x < X; ++x)
+            for (int y = 0; y < Y; ++y)
+                for (int z = 0; z < Z; ++z) {
+                    real *o = out + ((((int64_t)bb * X + x) * Y + y) * Z + z) * U;
+                    for (int c = 0; c < U; ++c) o[c] = 0;
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j < 3; ++j) {
+                            const int xx = x + i - 1, yy = y + j - 1;
+                            if (xx < 0 || xx >= X || yy < 0 || yy >= Y) continue; /* zero padding */
+                            const real *v = in + ((((int64_t)bb * X + xx) * Y + yy) * Z + z) * U;
+                            const real *k = K + (int64_t)(i * 3 + j) * U * U;
+                            for (int ci = 0; ci < U; ++ci) {
+                                const real a = v[ci];
+                                for (int c = 0; c < U; ++c) o[c] += a * k[(int64_t)ci * U + c];
+                            }
+                        }
+                    for (int c = 0; c < U; ++c) {
+                        o[c] += b[c];
+                        if (relu_out && o[c] < 0) o[c] = 0;
+                    }
+                }
+}
+
+void qbo_encoder_fwd_spatial(const qbo_weights *W, const qbo_loss_cfg *C, const real *x, int B, int X,
+                             int Y, int Z, real *out2, real *sigma) {
+    const int T = W->T, U = W->U, L = W->L;
+    const int G = W->channelwise_gating ? U : 1;
+    const real goff = R(W->gate_offset);
+    const int64_t V = (int64_t)B * X * Y * Z;
+    real *b = (real *)malloc(sizeof(real) * V * U * 4);
+    real *skip = b + V * U, *t1 = skip + V * U, *r = t1 + V * U;
+    for (int64_t v = 0; v < V; ++v) {
+        real n[QBO_MAX_T];
+        normalise_one(C, x + v * T, n, T);
+        dense(n, W->W0, W->b0, b + v * U, T, U, 1);
+    }
+    for (int l = 0; l < L; ++l) {
+        const real *Wc = W->Wc + (int64_t)l * U * U, *bc = W->bc + l * U;
+        for (int64_t v = 0; v < V; ++v) dense(b + v * U, Wc, bc, skip + v * U, U, U, 1); /* :148 */
+        for (int64_t e = 0; e < V * U; ++e) r[e] = b[e] > 0 ? b[e] : 0;                  /* :151 */
+        conv3x3(r, W->Wr1 + (int64_t)l * 9 * U * U, W->br1 + l * U, t1, B, X, Y, Z, U, 1); /* :152,155 */
+        conv3x3(t1, W->Wr2 + (int64_t)l * 9 * U * U, W->br2 + l * U, r, B, X, Y, Z, U, 0); /* :156 */
+        for (int64_t v = 0; v < V; ++v) {
+            real gt[256];
+            dense(r + v * U, W->Wg + (int64_t)l * U * G, W->bg + l * G, gt, U, G, 0);      /* :164 */
+            for (int i = 0; i < U; ++i) {
+                real gate = sigmoidr(gt[G == 1 ? 0 : i] + goff);
+                b[v * U + i] = skip[v * U + i] * (R(1.0) - gate) + r[v * U + i] * gate;    /* :170 */
+            }
+        }
+    }
+    for (int64_t v = 0; v < V; ++v) {
+        if (out2) dense(b + v * U, W->Wf, W->bf, out2 + v * 5, U, 5, 0);
+        if (sigma) {
+            real s[QBO_MAX_T];
+            dense(b + v * U, W->Ws, W->bs, s, U, T, 0);
+            for (int t = 0; t < T; ++t) sigma[v * T + t] = r_exp(s[t]);
+        }
+    }
+    free(b);
+}
+
+/* smoothness_loss numerator -- model.py:735-752 */
+double qbo_smoothness_sum(const real *q, const real *mask, int B, int X, int Y, int Z) {
+    double acc = 0;
+    for (int bb = 0; bb < B; ++bb)
+        for (int x = 0; x < X; ++x)
+            for (int y = 0; y < Y; ++y)
+                for (int z = 0; z < Z; ++z) {
+                    const int64_t v = (((int64_t)bb * X + x) * Y + y) * Z + z;
+                    /* forward_transform / range: sigmoid + min/range */
+                    const real po = sigmoidr(q[5 * v]) + MIN_OEF / OEF_RANGE;
+                    const real pd = sigmoidr(q[5 * v + 2]) + MIN_DBV / DBV_RANGE;
+                    if (x + 1 < X) {
+                        const int64_t w = v + (int64_t)Y * Z;
+                        if (mask[v] > 0 && mask[w] > 0)
+                            acc += r_fabs(po - (sigmoidr(q[5 * w]) + MIN_OEF / OEF_RANGE)) +
+                                   r_fabs(pd - (sigmoidr(q[5 * w + 2]) + MIN_DBV / DBV_RANGE));
+                    }
+                    if (y + 1 < Y) {
+                        const int64_t w = v + Z;
+                        if (mask[v] > 0 && mask[w] > 0)
+                            acc += r_fabs(po - (sigmoidr(q[5 * w]) + MIN_OEF / OEF_RANGE)) +
+                                   r_fabs(pd - (sigmoidr(q[5 * w + 2]) + MIN_DBV / DBV_RANGE));
+                    }
+                }
+    return acc;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Logit-Normal pieces -- model.py:288-316 = logit_mvn.py:72-100, :376-447 = logit_mvn.py:20-70.
  * ---------------------------------------------------------------------------------------- */
 static inline real transform_std(real p) { return (r_tanh(p) * R(3.0)) - R(1.0); } /* :288-290 */
 static inline real transform_offdiag(real p) { return r_tanh(p) * R(exp(-2.0)); }  /* :292-294 */
 
-#define OEF_RANGE R(0.8)
-#define MIN_OEF R(0.04)
-#define DBV_RANGE R(0.2)
-#define MIN_DBV R(0.001)
 
 static inline void reparam_one(const real *q, real z0, real z1, real *oef, real *dbv) {
     /* model.py:25-31 */

@@ -56,6 +56,8 @@ typedef struct {
 typedef struct {
     int32_t T, U, L;
     int32_t channelwise_gating; /* model.py:160-162 */
+    int32_t taps;               /* 1: Wr1/Wr2 are centre taps [L][U][U]; 9: full 3x3x1 kernels
+                                   [L][3][3][U][U] (Keras kernel layout, model.py:152-157) */
     double gate_offset;         /* model.py:169 */
     const real *W0, *b0;        /* [T][U], [U]            model.py:181 */
     const real *Wc, *bc;        /* [L][U][U], [L][U]      model.py:144 (shared by both streams) */
@@ -98,6 +100,16 @@ void qbo_normalise(const qbo_loss_cfg *C, const real *x /*[N][T]*/, real *n /*[N
 void qbo_encoder_fwd(const qbo_weights *W, const qbo_loss_cfg *C, const real *x /*[N][T]*/,
                      real *out1 /*[N][5]*/, real *out2 /*[N][5]*/, real *sigma /*[N][T]*/,
                      int64_t N);
+
+/* create_encoder forward on image volumes x [B][X][Y][Z][T] with the 3x3x1 'same'-padded
+ * convolutions of stream 2 (model.py:152-157); W->taps must be 9.  out2 [B X Y Z][5],
+ * sigma [B X Y Z][T]. */
+void qbo_encoder_fwd_spatial(const qbo_weights *W, const qbo_loss_cfg *C, const real *x, int B, int X,
+                             int Y, int Z, real *out2, real *sigma);
+/* smoothness_loss (model.py:726-754) numerator: sum |dx| + sum |dy| of the forward-transformed,
+ * range-scaled means over neighbour pairs whose masks are both > 0 (divide by sum(mask)). */
+double qbo_smoothness_sum(const real *q /*[V][5]*/, const real *mask /*[V]*/, int B, int X, int Y,
+                          int Z);
 
 /* ReparamTrickLayer.call (use_mvg) + forward_transform -- model.py:24-31,47-50,299-305. */
 void qbo_reparam(const real *q /*[N][5]*/, const real *z /*[N][2]*/, real *oef_dbv /*[N][2]*/,

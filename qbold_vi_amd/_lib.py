@@ -33,7 +33,13 @@ class LossCfg(C.Structure):
 
 class EncoderShape(C.Structure):
     _fields_ = [("T", C.c_int32), ("U", C.c_int32), ("L", C.c_int32),
-                ("channelwise_gating", C.c_int32), ("gate_offset", C.c_float)]
+                ("channelwise_gating", C.c_int32), ("gate_offset", C.c_float),
+                ("spatial_taps", C.c_int32)]
+
+
+class Geometry(C.Structure):
+    """qbold_geometry: a [B][X][Y][Z][C] crop batch."""
+    _fields_ = [("B", C.c_int32), ("X", C.c_int32), ("Y", C.c_int32), ("Z", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -79,6 +85,11 @@ SIGNATURES = {
     "qbold_encoder_train_fwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, C.c_int, _P, _P, _P, _I64, _P]),
     "qbold_encoder_train_bwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, C.c_int, _P, _P, _P, _P, _P,
                                           _I64, _P]),
+    "qbold_encoder_spatial_fwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, C.POINTER(Geometry), _P, _P,
+                                            _P, _P]),
+    "qbold_encoder_spatial_bwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, C.POINTER(Geometry), _P, _P, _P,
+                                            _P, _P, _P]),
+    "qbold_smoothness": (C.c_int, [_P, _P, _P, C.POINTER(Geometry), C.c_float, _P, _P, _P]),
     "qbold_synth_loss_bwd": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_float, _I64, _P]),
     "qbold_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _I64, C.c_double, C.c_double, C.c_double,
                                    C.c_double, C.c_double, _I64, _P]),

@@ -8,23 +8,24 @@ namespace qb {
 
 // Canonical blob offsets (floats); see qbold_encoder_num_params in include/qbold_hip.h.
 struct CanonLayout {
-    int T, U, L, G;
+    int T, U, L, G, taps;
     int W0, b0, blk0, blk_stride, Wf, bf, Ws, bs, total;
     // inside a block
     int Wc, bc, Wr1, br1, Wr2, br2, Wg, bg;
 };
-__host__ __device__ inline CanonLayout make_canon(int T, int U, int L, int cw) {
+__host__ __device__ inline CanonLayout make_canon(int T, int U, int L, int cw, int taps = 1) {
     CanonLayout c;
     c.T = T; c.U = U; c.L = L; c.G = cw ? U : 1;
+    c.taps = taps == 9 ? 9 : 1;
     c.W0 = 0;
     c.b0 = T * U;
     c.blk0 = c.b0 + U;
     c.Wc = 0;
     c.bc = U * U;
     c.Wr1 = c.bc + U;
-    c.br1 = c.Wr1 + U * U;
+    c.br1 = c.Wr1 + c.taps * U * U;
     c.Wr2 = c.br1 + U;
-    c.br2 = c.Wr2 + U * U;
+    c.br2 = c.Wr2 + c.taps * U * U;
     c.Wg = c.br2 + U;
     c.bg = c.Wg + U * c.G;
     c.blk_stride = c.bg + c.G;

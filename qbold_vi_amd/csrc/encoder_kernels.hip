@@ -49,7 +49,9 @@ __global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset,
             const int q = pf - e.blk0, l = q / qb::BLK_FLOATS, o = q % qb::BLK_FLOATS;
             const float* wb = w + c.blk0 + l * c.blk_stride;
             const int piece = o / 4160, oo = o % 4160;  // 4 x (4096 A + 64 bias)
-            const int Aoff = piece == 0 ? c.Wc : piece == 1 ? c.Wr1 : piece == 2 ? c.Wr2 : c.Wg;
+            // voxel batches see only the centre tap (index 4 of 3x3) of the residual convolutions
+            const int ctr = c.taps == 9 ? 4 * U * U : 0;
+            const int Aoff = piece == 0 ? c.Wc : piece == 1 ? c.Wr1 + ctr : piece == 2 ? c.Wr2 + ctr : c.Wg;
             const int boff = piece == 0 ? c.bc : piece == 1 ? c.br1 : piece == 2 ? c.br2 : c.bg;
             const int nout = piece == 3 ? G : U;
             if (oo < 4096) {  // A: [s][m_out][part][lane][j] in halves
@@ -171,7 +173,7 @@ int check_encoder_shape(const qbold_ctx* ctx, const qbold_encoder_shape* s) {
 
 extern "C" int64_t qbold_encoder_num_params(const qbold_encoder_shape* s) {
     if (!s) return QBOLD_ERR_INVALID;
-    return qb::make_canon(s->T, s->U, s->L, s->channelwise_gating).total;
+    return qb::make_canon(s->T, s->U, s->L, s->channelwise_gating, s->spatial_taps).total;
 }
 
 extern "C" int64_t qbold_encoder_packed_floats(const qbold_encoder_shape* s) {
@@ -186,7 +188,8 @@ extern "C" int qbold_encoder_pack(const qbold_ctx* ctx, const qbold_encoder_shap
     if (rc) return rc;
     QB_REQUIRE(weights && packed, "qbold_encoder_pack: null buffer");
     const EncLayout e = qb::make_enc_layout(shape->T, shape->U, shape->L);
-    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating);
+    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating,
+                                             shape->spatial_taps);
     hipLaunchKernelGGL(pack_kernel, dim3((2 * e.total + 255) / 256), dim3(256), 0, (hipStream_t)stream, e,
                        c, shape->gate_offset, weights, packed);
     QB_HIP(hipGetLastError());

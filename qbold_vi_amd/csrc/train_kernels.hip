@@ -28,6 +28,20 @@ constexpr int kWs = 65;        // LDS row stride of a staged weight matrix
 
 enum { ACT_NONE = 0, ACT_RELU = 1 };
 
+// Row gather of one 3x3x1 tap on a [B][X][Y][Z] crop batch: row v reads its (dx, dy) neighbour, or
+// zeros outside the crop ('same' padding).  Z == 0 disables the gather.
+struct Gather {
+    int X, Y, Z, dx, dy;
+};
+__device__ __forceinline__ int64_t gather_row(const Gather& gt, int64_t v) {
+    if (gt.Z == 0) return v;
+    const int64_t yz = (int64_t)gt.Y * gt.Z;
+    const int x = (int)((v / yz) % gt.X), y = (int)((v / gt.Z) % gt.Y);
+    const int xx = x + gt.dx, yy = y + gt.dy;
+    if (xx < 0 || xx >= gt.X || yy < 0 || yy >= gt.Y) return -1;
+    return v + (int64_t)gt.dx * yz + (int64_t)gt.dy * gt.Z;
+}
+
 // Y[N][ldy] (cols < ndim) = act(X[N][ldx] (cols < kdim) . W + b), W given as Wl[k][j]:
 //   trans = 0: Wl[k][j] = W[k * ldw + j]   (forward, W canonical [in][out])
 //   trans = 1: Wl[k][j] = W[j * ldw + k]   (backward-data: dX = dY . W^T)
@@ -38,7 +52,8 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
                                                  const float* __restrict__ W, int ldw, int trans,
                                                  const float* __restrict__ b, float* __restrict__ Y,
                                                  int ldy, int ndim, int act, int accum,
-                                                 const float* __restrict__ mask, int ldm, int64_t N) {
+                                                 const float* __restrict__ mask, int ldm, int64_t N,
+                                                 Gather gt) {
     extern __shared__ float Wl[];
     const int n0 = blockIdx.y * 64;
     const int kpad = (kdim + 3) & ~3;
@@ -55,14 +70,14 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
     const int ksteps = kpad >> 2;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
         const int64_t v0 = tile * 16;
-        const int64_t va = v0 + i < N ? v0 + i : N - 1;
+        const int64_t va = gather_row(gt, v0 + i < N ? v0 + i : N - 1);
         f32x4 acc[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        const float* xr = X + va * ldx;
+        const float* xr = X + (va < 0 ? 0 : va) * ldx;
         for (int s = 0; s < ksteps; ++s) {
             const int k = 4 * s + g;
-            const float a = k < kdim ? xr[k] : 0.0f;
+            const float a = (k < kdim && va >= 0) ? xr[k] : 0.0f;
             const float* wr = Wl + k * kWs + i;
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(a, wr[16 * m], acc[m]);
@@ -77,9 +92,9 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
                 const int64_t v = v0 + 4 * g + r;
                 if (v >= N) continue;
                 float y = acc[m][r] + bj;
+                if (accum) y += Y[v * ldy + j];
                 if (act == ACT_RELU) y = fmaxf(y, 0.0f);
                 if (mask) y = mask[v * ldm + j] > 0.0f ? y : 0.0f;
-                if (accum) y += Y[v * ldy + j];
                 Y[v * ldy + j] = y;
             }
         }
@@ -89,7 +104,7 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
 // partial[blk][64*64 + 64]: dW[i][j] = sum_v X[v][i] D[v][j] over this block's voxels, then db[j]
 __global__ __launch_bounds__(256) void xtd_kernel(const float* __restrict__ X, int ldx, int kdim,
                                                   const float* __restrict__ D, int ldd, int ndim,
-                                                  float* __restrict__ partial, int64_t N) {
+                                                  float* __restrict__ partial, int64_t N, Gather gt) {
     __shared__ float red[64 * 64 + 64];
     for (int e = threadIdx.x; e < 64 * 64 + 64; e += 256) red[e] = 0.0f;
     __syncthreads();
@@ -105,11 +120,12 @@ __global__ __launch_bounds__(256) void xtd_kernel(const float* __restrict__ X, i
     for (int64_t st = (int64_t)blockIdx.x * 4 + wave; st < nstep; st += (int64_t)gridDim.x * 4) {
         const int64_t v = st * 4 + g;
         const bool ok = v < N;
+        const int64_t vx = ok ? gather_row(gt, v) : -1;
         float xa[4], dd[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int c = 16 * m + i;
-            xa[m] = (ok && c < kdim) ? X[v * ldx + c] : 0.0f;
+            xa[m] = (vx >= 0 && c < kdim) ? X[vx * ldx + c] : 0.0f;
             dd[m] = (ok && c < ndim) ? D[v * ldd + c] : 0.0f;
             dbsum[m] += dd[m];
         }
@@ -300,6 +316,7 @@ struct Launcher {
     hipStream_t s;
     int64_t N;
     int ld;  // row stride of the activation tensors (64, or U rounded up to 64 beyond that)
+    Gather gather{0, 0, 0, 0, 0};
     int grid() const {
         int64_t nb = (N + 63) / 64;
         int64_t cap = (int64_t)ctx->num_cus * 8;
@@ -315,8 +332,20 @@ struct Launcher {
             if (e != hipSuccess) return qb::hip_fail(e, "hipFuncSetAttribute(xw_kernel)");
         }
         hipLaunchKernelGGL(xw_kernel, dim3(grid(), (ndim + 63) / 64), dim3(256), smem, s, X, ldx, kdim, W,
-                           ldw, trans, b, Y, ldy, ndim, act, accum, mask, ld, N);
+                           ldw, trans, b, Y, ldy, ndim, act, accum, mask, ld, N, gather);
         return QBOLD_OK;
+    }
+    // 3x3x1 'same' convolution as nine gathered GEMMs: Y = act(sum_taps X[nbr] K[tap] + b).
+    // flip = 1 is the adjoint wrt the input (taps mirrored, kernels transposed).
+    void conv3x3(const float* X, const float* K9, int U, const float* b, float* Y, int act, int flip,
+                 const float* mask, const qbold_geometry& gm) {
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dx = tap / 3 - 1, dy = tap % 3 - 1;
+            gather = Gather{gm.X, gm.Y, gm.Z, flip ? -dx : dx, flip ? -dy : dy};
+            (void)xw_ld(X, ld, U, K9 + (int64_t)tap * U * U, U, flip, tap == 0 ? b : nullptr, Y, ld, U,
+                        tap == 8 ? act : ACT_NONE, tap != 0, tap == 8 ? mask : nullptr);
+        }
+        gather = Gather{0, 0, 0, 0, 0};
     }
     void xw(const float* X, int ldx, int kdim, const float* W, int ldw, int trans, const float* b,
             float* Y, int ndim, int act, int accum, const float* mask) const {
@@ -325,7 +354,8 @@ struct Launcher {
     // dW (+)= X^T D, db (+)= sum D   (U <= 64 only)
     void xtd(const float* X, int kdim, const float* D, int ndim, float* partial, int nblk, float* dW,
              int ldw, float* db, int accum) const {
-        hipLaunchKernelGGL(xtd_kernel, dim3(nblk), dim3(256), 0, s, X, kLd, kdim, D, kLd, ndim, partial, N);
+        hipLaunchKernelGGL(xtd_kernel, dim3(nblk), dim3(256), 0, s, X, kLd, kdim, D, kLd, ndim, partial, N,
+                           gather);
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64 + 255) / 256), dim3(256), 0, s, partial,
                            nblk, dW, ldw, kdim, ndim, db, accum);
     }
@@ -364,15 +394,20 @@ extern "C" int64_t qbold_train_workspace_floats(const qbold_encoder_shape* shape
     return slots * N * train_ld(shape->U) + (int64_t)kSlabBlocks * (64 * 64 + 64);
 }
 
-extern "C" int qbold_encoder_train_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
-                                       const float* w, const float* x, int stream_sel, float* ws,
-                                       float* out_q, float* out_log_sigma, int64_t N, void* stream) {
+static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* w,
+                          const float* x, int stream_sel, float* ws, float* out_q, float* out_log_sigma,
+                          int64_t N, void* stream, const qbold_geometry* gm) {
     QB_NEED_DEVICE(ctx);
     int rc = check_layerwise_shape(ctx, shape);
     if (rc) return rc;
     QB_REQUIRE(N > 0 && w && x && ws && out_q, "qbold_encoder_train_fwd: bad argument");
+    if (gm) {
+        QB_REQUIRE(shape->spatial_taps == 9, "spatial encoder needs 9-tap (3x3x1) residual kernels");
+        QB_REQUIRE(shape->U <= 64, "spatial encoder path is built for U <= 64");
+        QB_REQUIRE(stream_sel == 2, "only stream 2 has spatial convolutions");
+    }
     QB_REQUIRE(stream_sel == 1 || stream_sel == 2, "qbold_encoder_train_fwd: stream must be 1 or 2");
-    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating);
+    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating, shape->spatial_taps);
     const int T = c.T, U = c.U, L = c.L, G = c.G;
     const int ld = train_ld(U);
     Launcher k{ctx, (hipStream_t)stream, N, ld};
@@ -397,8 +432,14 @@ extern "C" int qbold_encoder_train_fwd(const qbold_ctx* ctx, const qbold_encoder
             k.xw(cur, ld, U, wb + c.Wc, U, 0, wb + c.bc, skip, U, ACT_RELU, 0, nullptr);
             // relu(b) feeds the first residual conv; block 0's input h is already >= 0
             hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, cur, bout, N * ld);
-            k.xw(bout, ld, U, wb + c.Wr1, U, 0, wb + c.br1, t, U, ACT_RELU, 0, nullptr);
-            k.xw(t, ld, U, wb + c.Wr2, U, 0, wb + c.br2, r, U, ACT_NONE, 0, nullptr);
+            if (gm) {  // 3x3x1 'same' convolutions, model.py:152-157
+                k.conv3x3(bout, wb + c.Wr1, U, wb + c.br1, t, ACT_RELU, 0, nullptr, *gm);
+                k.conv3x3(t, wb + c.Wr2, U, wb + c.br2, r, ACT_NONE, 0, nullptr, *gm);
+            } else {   // voxel batch: centre tap only
+                const int ctr = c.taps == 9 ? 4 * U * U : 0;
+                k.xw(bout, ld, U, wb + c.Wr1 + ctr, U, 0, wb + c.br1, t, U, ACT_RELU, 0, nullptr);
+                k.xw(t, ld, U, wb + c.Wr2 + ctr, U, 0, wb + c.br2, r, U, ACT_NONE, 0, nullptr);
+            }
             k.xw(r, ld, U, wb + c.Wg, G, 0, wb + c.bg, gl, G, ACT_NONE, 0, nullptr);
             hipLaunchKernelGGL(gate_fwd_kernel, dim3(k.ew()), dim3(256), 0, k.s, gl, skip, r, bout,
                                shape->gate_offset, U, G, ld, N);
@@ -417,12 +458,27 @@ extern "C" int qbold_encoder_train_fwd(const qbold_ctx* ctx, const qbold_encoder
     return QBOLD_OK;
 }
 
+extern "C" int qbold_encoder_train_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
+                                       const float* w, const float* x, int stream_sel, float* ws,
+                                       float* out_q, float* out_log_sigma, int64_t N, void* stream) {
+    return train_fwd_impl(ctx, shape, w, x, stream_sel, ws, out_q, out_log_sigma, N, stream, nullptr);
+}
+
+extern "C" int qbold_encoder_spatial_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
+                                         const float* w, const float* x, const qbold_geometry* geom,
+                                         float* ws, float* out_q, float* out_log_sigma, void* stream) {
+    QB_REQUIRE(geom && geom->B > 0 && geom->X > 0 && geom->Y > 0 && geom->Z > 0,
+               "qbold_encoder_spatial_fwd: bad geometry");
+    const int64_t N = (int64_t)geom->B * geom->X * geom->Y * geom->Z;
+    return train_fwd_impl(ctx, shape, w, x, 2, ws, out_q, out_log_sigma, N, stream, geom);
+}
+
 // g_head_q [N][5], g_head_ls [N][T] (stream 2 only; may be NULL), sums: device double[3] whose
 // third entry is sum(mask) (NULL = gradients already normalised).  grad: canonical layout, overwritten.
-extern "C" int qbold_encoder_train_bwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
-                                       const float* w, int stream_sel, float* ws, const float* g_q,
-                                       const float* g_ls, const double* sums, float* grad, int64_t N,
-                                       void* stream) {
+static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* w,
+                          int stream_sel, float* ws, const float* g_q, const float* g_ls,
+                          const double* sums, float* grad, int64_t N, void* stream,
+                          const qbold_geometry* gm) {
     QB_NEED_DEVICE(ctx);
     int rc = check_layerwise_shape(ctx, shape);
     if (rc) return rc;
@@ -432,7 +488,7 @@ extern "C" int qbold_encoder_train_bwd(const qbold_ctx* ctx, const qbold_encoder
     }
     QB_REQUIRE(N > 0 && w && ws && g_q && grad, "qbold_encoder_train_bwd: bad argument");
     QB_REQUIRE(stream_sel == 1 || stream_sel == 2, "qbold_encoder_train_bwd: stream must be 1 or 2");
-    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating);
+    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating, shape->spatial_taps);
     const int T = c.T, U = c.U, L = c.L, G = c.G;
     Launcher k{ctx, (hipStream_t)stream, N, kLd};
     auto slot = [&](int i) { return ws + (int64_t)i * N * kLd; };
@@ -477,13 +533,32 @@ extern "C" int qbold_encoder_train_bwd(const qbold_ctx* ctx, const qbold_encoder
             // gating conv: dWg = r^T dE; d r += dE Wg^T
             k.xtd(r, U, dE, G, partial, kSlabBlocks, gb + c.Wg, G, gb + c.bg, 0);
             k.xw(dE, kLd, G, wb + c.Wg, G, 1, nullptr, dD, U, ACT_NONE, 1, nullptr);
-            // second residual conv: dWr2 = t^T dD; d t_pre = (dD Wr2^T) * (t > 0)  -> dE
-            k.xtd(t, U, dD, U, partial, kSlabBlocks, gb + c.Wr2, U, gb + c.br2, 0);
-            k.xw(dD, kLd, U, wb + c.Wr2, U, 1, nullptr, dE, U, ACT_NONE, 0, t);
-            // first residual conv: input relu(b_in): dWr1 = relu(b_in)^T dE; d b_in = (dE Wr1^T) * (b_in > 0)
-            hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, b_in, dD, N * kLd);
-            k.xtd(dD, U, dE, U, partial, kSlabBlocks, gb + c.Wr1, U, gb + c.br1, 0);
-            k.xw(dE, kLd, U, wb + c.Wr1, U, 1, nullptr, dB, U, ACT_NONE, 0, b_in);
+            if (gm) {
+                // second residual conv (3x3x1): dK2[tap] = t[nbr]^T dD; d t_pre = conv^T(dD) * (t > 0) -> dE
+                for (int tap = 0; tap < 9; ++tap) {
+                    k.gather = Gather{gm->X, gm->Y, gm->Z, tap / 3 - 1, tap % 3 - 1};
+                    k.xtd(t, U, dD, U, partial, kSlabBlocks, gb + c.Wr2 + tap * U * U, U,
+                          tap == 0 ? gb + c.br2 : nullptr, 0);
+                }
+                k.conv3x3(dD, wb + c.Wr2, U, nullptr, dE, ACT_NONE, 1, t, *gm);
+                // first residual conv: input relu(b_in)
+                hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, b_in, dD, N * kLd);
+                for (int tap = 0; tap < 9; ++tap) {
+                    k.gather = Gather{gm->X, gm->Y, gm->Z, tap / 3 - 1, tap % 3 - 1};
+                    k.xtd(dD, U, dE, U, partial, kSlabBlocks, gb + c.Wr1 + tap * U * U, U,
+                          tap == 0 ? gb + c.br1 : nullptr, 0);
+                }
+                k.conv3x3(dE, wb + c.Wr1, U, nullptr, dB, ACT_NONE, 1, b_in, *gm);
+            } else {
+                const int ctr = c.taps == 9 ? 4 * U * U : 0;
+                // second residual conv: dWr2 = t^T dD; d t_pre = (dD Wr2^T) * (t > 0)  -> dE
+                k.xtd(t, U, dD, U, partial, kSlabBlocks, gb + c.Wr2 + ctr, U, gb + c.br2, 0);
+                k.xw(dD, kLd, U, wb + c.Wr2 + ctr, U, 1, nullptr, dE, U, ACT_NONE, 0, t);
+                // first residual conv: input relu(b_in): dWr1 = relu(b_in)^T dE; d b_in = (dE Wr1^T) * (b_in > 0)
+                hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, b_in, dD, N * kLd);
+                k.xtd(dD, U, dE, U, partial, kSlabBlocks, gb + c.Wr1 + ctr, U, gb + c.br1, 0);
+                k.xw(dE, kLd, U, wb + c.Wr1 + ctr, U, 1, nullptr, dB, U, ACT_NONE, 0, b_in);
+            }
             // skip conv: dWc = b_in^T dC; d b_in += dC Wc^T
             k.xtd(b_in, U, dC, U, partial, kSlabBlocks, gb + c.Wc, U, gb + c.bc, 0);
             k.xw(dC, kLd, U, wb + c.Wc, U, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
@@ -492,6 +567,87 @@ extern "C" int qbold_encoder_train_bwd(const qbold_ctx* ctx, const qbold_encoder
     // first layer: delta_pre = dB * (h > 0); dW0 = n^T delta_pre
     hipLaunchKernelGGL(mask_mul_kernel, dim3(k.ew()), dim3(256), 0, k.s, dB, slot(1), dC, N * kLd);
     k.xtd(slot(0), T, dC, U, partial, kSlabBlocks, grad + c.W0, U, grad + c.b0, 0);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
+extern "C" int qbold_encoder_train_bwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
+                                       const float* w, int stream_sel, float* ws, const float* g_q,
+                                       const float* g_ls, const double* sums, float* grad, int64_t N,
+                                       void* stream) {
+    return train_bwd_impl(ctx, shape, w, stream_sel, ws, g_q, g_ls, sums, grad, N, stream, nullptr);
+}
+
+extern "C" int qbold_encoder_spatial_bwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
+                                         const float* w, const qbold_geometry* geom, float* ws,
+                                         const float* g_q, const float* g_ls, const double* sums,
+                                         float* grad, void* stream) {
+    QB_REQUIRE(geom && geom->B > 0 && geom->X > 0 && geom->Y > 0 && geom->Z > 0,
+               "qbold_encoder_spatial_bwd: bad geometry");
+    QB_REQUIRE(shape && shape->spatial_taps == 9, "qbold_encoder_spatial_bwd: needs 9-tap kernels");
+    const int64_t N = (int64_t)geom->B * geom->X * geom->Y * geom->Z;
+    return train_bwd_impl(ctx, shape, w, 2, ws, g_q, g_ls, sums, grad, N, stream, geom);
+}
+
+namespace {
+// smoothness_loss (model.py:726-754): p = forward_transform(mean) / range = sigmoid(mu) + min/range;
+// sum over x- and y-neighbour pairs with both masks > 0 of |p_v - p_w| (OEF and DBV channels).
+// Each voxel owns the pairs towards +x and +y for the sum, and gathers the sign of all four
+// differences it takes part in for the gradient (no atomics on g_q).
+__global__ void smoothness_kernel(const float* __restrict__ q, const float* __restrict__ mask,
+                                  qbold_geometry gm, float weight, float* __restrict__ g_q,
+                                  double* __restrict__ tv_sum, int64_t N) {
+    __shared__ double red[4];
+    float acc = 0.0f;
+    const int64_t yz = (int64_t)gm.Y * gm.Z;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < N;
+         v += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)((v / yz) % gm.X), y = (int)((v / gm.Z) % gm.Y);
+        const bool mv = mask[v] > 0.0f;
+        const float so = 1.0f / (1.0f + expf(-q[5 * v])), sd = 1.0f / (1.0f + expf(-q[5 * v + 2]));
+        float go = 0.0f, gd = 0.0f;
+        const int64_t off[4] = {yz, (int64_t)gm.Z, -yz, -(int64_t)gm.Z};
+        const bool inside[4] = {x + 1 < gm.X, y + 1 < gm.Y, x > 0, y > 0};
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            if (!inside[n]) continue;
+            const int64_t w = v + off[n];
+            if (!(mv && mask[w] > 0.0f)) continue;
+            const float wo = 1.0f / (1.0f + expf(-q[5 * w])), wd = 1.0f / (1.0f + expf(-q[5 * w + 2]));
+            const float dO = so - wo, dD = sd - wd;
+            if (n < 2) acc += fabsf(dO) + fabsf(dD);
+            go += (dO > 0.0f) - (dO < 0.0f);
+            gd += (dD > 0.0f) - (dD < 0.0f);
+        }
+        if (g_q) {
+            g_q[5 * v] += weight * go * so * (1.0f - so);
+            g_q[5 * v + 2] += weight * gd * sd * (1.0f - sd);
+        }
+    }
+    acc = qb::wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = (double)acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += red[w];
+        atomicAdd(tv_sum, a);
+    }
+}
+}  // namespace
+
+extern "C" int qbold_smoothness(const qbold_ctx* ctx, const float* q, const float* mask,
+                                const qbold_geometry* geom, float weight, float* g_q, double* tv_sum,
+                                void* stream) {
+    QB_NEED_DEVICE(ctx);
+    QB_REQUIRE(q && mask && geom && tv_sum, "qbold_smoothness: null argument");
+    QB_REQUIRE(geom->B > 0 && geom->X > 0 && geom->Y > 0 && geom->Z > 0, "qbold_smoothness: bad geometry");
+    const int64_t N = (int64_t)geom->B * geom->X * geom->Y * geom->Z;
+    hipStream_t s = (hipStream_t)stream;
+    QB_HIP(hipMemsetAsync(tv_sum, 0, sizeof(double), s));
+    int64_t nb = (N + 255) / 256;
+    int64_t cap = (int64_t)ctx->num_cus * 8;
+    hipLaunchKernelGGL(smoothness_kernel, dim3((int)(nb < cap ? nb : cap)), dim3(256), 0, s, q, mask, *geom,
+                       weight, g_q, tv_sum, N);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }

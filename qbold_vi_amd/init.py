@@ -10,10 +10,11 @@ The random stream is NumPy's, not TensorFlow's: initial values match in distribu
 import numpy as np
 
 
-def weight_shapes(T, U, L, channelwise_gating=True):
+def weight_shapes(T, U, L, channelwise_gating=True, spatial_taps=1):
     G = U if channelwise_gating else 1
-    return dict(W0=(T, U), b0=(U,), Wc=(L, U, U), bc=(L, U), Wr1=(L, U, U), br1=(L, U),
-                Wr2=(L, U, U), br2=(L, U), Wg=(L, U, G), bg=(L, G), Wf=(U, 5), bf=(5,),
+    rs = (L, 3, 3, U, U) if spatial_taps == 9 else (L, U, U)  # Keras (3,3,1,in,out) kernels
+    return dict(W0=(T, U), b0=(U,), Wc=(L, U, U), bc=(L, U), Wr1=rs, br1=(L, U),
+                Wr2=rs, br2=(L, U), Wg=(L, U, G), bg=(L, G), Wf=(U, 5), bf=(5,),
                 Ws=(U, T), bs=(T,))
 
 
@@ -28,9 +29,9 @@ def _he_normal(rng, shape, fan_in):
 
 
 def init_encoder_weights(T=11, U=60, L=2, channelwise_gating=True, resid_init_std=0.05,
-                         im_loss_sigma=0.05, seed=1):
+                         im_loss_sigma=0.05, seed=1, spatial_taps=1):
     rng = np.random.default_rng(seed)
-    sh = weight_shapes(T, U, L, channelwise_gating)
+    sh = weight_shapes(T, U, L, channelwise_gating, spatial_taps)
     w = {"W0": _he_normal(rng, sh["W0"], T), "Wc": _he_normal(rng, sh["Wc"], U),
          "Wf": _he_normal(rng, sh["Wf"], U)}
     for n in ("Wr1", "Wr2", "Wg", "Ws"):

@@ -8,9 +8,9 @@ shape; the reference's 5-D (B, X, Y, Z, C) layout is accepted as is.  Arithmetic
 libqbold_hip.so; torch provides memory, reshapes and trivial reductions of kernel outputs.
 
 Scope: the branches optimal.yaml disables -- population prior / MoG / inverse-gamma
-(model.py:252-271, 492-507, 666-716), non-MVG 4-parameter posteriors, dropout / GroupNorm, and
-spatial (crop) inputs to the 3x3x1 stream -- raise NotImplementedError instead of silently
-computing something else.
+(model.py:252-271, 492-507, 666-716), non-MVG 4-parameter posteriors, dropout / GroupNorm -- raise
+NotImplementedError instead of silently computing something else.  Image crops [B, X, Y, Z, C]
+ take the layer-wise spatial kernels; voxel batches the fused ones.
 """
 import numpy as np
 import torch
@@ -35,8 +35,19 @@ class EncoderModel:
         return self.predict(x)
 
     def predict(self, x, want=("out1", "out2", "sigma")):
-        self._trainer._check_voxelwise(x)
-        return list(self._trainer._ctx.encoder_fwd(self.weights, x, want=want))
+        """Voxel batches go through the fused kernels; image crops [B, X, Y, Z, T] (X or Y > 1) get
+        stream 2 with its 3x3x1 'same' convolutions (stream 1 is voxel-wise by construction)."""
+        ctx = self._trainer._ctx
+        if not self._trainer._is_spatial(x):
+            return list(ctx.encoder_fwd(self.weights, x, want=want))
+        o1 = ctx.encoder_fwd(self.weights, x, want=("out1",))[0] if "out1" in want else None
+        o2 = sg = None
+        if "out2" in want or "sigma" in want:
+            st = self._trainer._spatial_state(self.weights)
+            q, ls = st.forward_spatial(x)
+            o2 = q.reshape(x.shape[:-1] + (5,)) if "out2" in want else None
+            sg = ctx.transform("exp", ls).reshape(x.shape) if "sigma" in want else None
+        return [o1, o2, sg]
 
     # Weights travel as .npz with the canonical tensor names (Keras HDF5 is SURVEY N3).
     def get_weights(self):
@@ -111,14 +122,21 @@ class FineTuner:
         return {'predictions': qs, 'predicted_images': torch.cat([output, sig], -1)}
 
     def elbo(self, data, mask, prior, no_samples=None, kl_samples=70, seed=1, voxel0=0):
-        """The fused path: one launch for encoder + S draws + forward model + NLL + K-draw KL.
+        """The fused path: one launch for encoder + S draws + forward model + NLL + K-draw KL
+        (image crops: spatial encoder, then the ELBO kernel).
         Returns dict(nll, kl, elbo (= nll + kl, train.py:351), sums, q, nll_kl)."""
         tr = self._trainer
         S = tr._no_samples if no_samples is None else no_samples
         x = _flat(data, data.shape[-1])
         m = None if mask is None else mask.reshape(-1)
-        sums, q, nll_kl = tr._ctx.vi_fwd(self.encoder_model.weights, x, m, _flat(prior, 5), S,
-                                         kl_samples, seed=seed, voxel0=voxel0)
+        if tr._is_spatial(data):
+            _, q5, sg5 = self.encoder_model.predict(data, want=("out2", "sigma"))
+            q = _flat(q5, 5)
+            sums, nll_kl = tr._ctx.elbo_fwd(x, m, q, _flat(prior, 5), _flat(sg5, x.shape[-1]), S,
+                                            kl_samples, seed=seed, voxel0=voxel0)
+        else:
+            sums, q, nll_kl = tr._ctx.vi_fwd(self.encoder_model.weights, x, m, _flat(prior, 5), S,
+                                             kl_samples, seed=seed, voxel0=voxel0)
         return dict(sums=sums, q=q, nll_kl=nll_kl, nll=sums[0] / sums[2], kl=sums[1] / sums[2],
                     elbo=(sums[0] + sums[1]) / sums[2])
 
@@ -197,11 +215,18 @@ class EncoderTrainer:
     def context(self):
         return self._ctx
 
-    def _check_voxelwise(self, x):
-        if x.dim() == 5 and (x.shape[1] > 1 or x.shape[2] > 1) and self._no_intermediate_layers > 0:
-            raise NotImplementedError(
-                "spatial inputs to the 3x3x1 residual stream (model.py:152-157) are SURVEY row N1; "
-                "reshape voxels to (N,1,1,1,T) for the voxel-wise path")
+    @staticmethod
+    def _is_spatial(x):
+        return x.dim() == 5 and (x.shape[1] > 1 or x.shape[2] > 1)
+
+    def _spatial_state(self, weights):
+        from .ops import TrainState
+        st = getattr(weights, "_spatial_state", None)
+        if st is None:
+            if weights.shape.spatial_taps != 9:
+                raise ValueError("image crops need an encoder created with 3x3x1 kernels (spatial_taps=9)")
+            st = weights._spatial_state = TrainState(self._ctx, weights, optimiser_state=False)
+        return st
 
     def normalise_data(self, _data):  # model.py:97-113
         return self._ctx.normalise(_data)
@@ -211,12 +236,14 @@ class EncoderTrainer:
         """model.py:122-223.  Returns (outer_model, inner_model)."""
         if no_ip_images != self._ctx.T:
             raise ValueError("no_ip_images must equal the number of taus of the system parameters")
+        # the residual stream owns full 3x3x1 kernels as in the reference (146,176 parameters at
+        # optimal.yaml); voxel batches act through their centre tap
         w = init_encoder_weights(T=no_ip_images, U=self._no_units, L=self._no_intermediate_layers,
                                  channelwise_gating=self._channelwise_gating,
                                  resid_init_std=resid_init_std, im_loss_sigma=self._initial_im_sigma,
-                                 seed=self._seed)
+                                 seed=self._seed, spatial_taps=9)
         ew = EncoderWeights(self._ctx, no_ip_images, self._no_units, self._no_intermediate_layers,
-                            self._channelwise_gating, gate_offset).set_from_arrays(w)
+                            self._channelwise_gating, gate_offset, spatial_taps=9).set_from_arrays(w)
         return EncoderModel(self, ew), _InnerModel()
 
     def build_fine_tuner(self, encoder_model, signal_generation_layer, input_im=None, input_mask=None):
@@ -340,8 +367,12 @@ class EncoderTrainer:
         return kl_op
 
     def smoothness_loss(self, true_params, pred_params):
-        """Total-variation term (model.py:726-754).  It is identically 0 for voxel batches
-        (no x / y neighbours); image crops are SURVEY row N1."""
-        if pred_params.dim() == 5 and (pred_params.shape[1] > 1 or pred_params.shape[2] > 1):
-            raise NotImplementedError("smoothness_loss on image crops is SURVEY row N1")
-        return torch.zeros((), dtype=torch.float32, device=pred_params.device)
+        """Total-variation term (model.py:726-754): sum of |differences| of the range-scaled
+        forward-transformed means over x / y neighbours with both masks set, over sum(mask).
+        Identically 0 for voxel batches."""
+        true_params = torch.cat([true_params] * self._no_samples, 0)
+        if not self._is_spatial(pred_params):
+            return torch.zeros((), dtype=torch.float32, device=pred_params.device)
+        mask = true_params[..., 5]
+        tv = self._ctx.smoothness(pred_params[..., :5], mask)
+        return (tv[0] / mask.sum()).float()

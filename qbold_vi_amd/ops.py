@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Consts, EncoderShape, LossCfg, QboldError
+from ._lib import Consts, EncoderShape, Geometry, LossCfg, QboldError
 
 PARAM_KEYS = ("gamma", "b0", "dchi", "te", "r2t", "tr", "ti", "t1b", "hct",
               "tau_start", "tau_end", "tau_step")
@@ -43,10 +43,10 @@ class EncoderWeights:
 
     NAMES = ("W0", "b0", "Wc", "bc", "Wr1", "br1", "Wr2", "br2", "Wg", "bg", "Wf", "bf", "Ws", "bs")
 
-    def __init__(self, ctx, T, U, L, channelwise_gating=True, gate_offset=0.0):
+    def __init__(self, ctx, T, U, L, channelwise_gating=True, gate_offset=0.0, spatial_taps=1):
         self.ctx = ctx
         self.shape = EncoderShape(int(T), int(U), int(L), int(bool(channelwise_gating)),
-                                  float(gate_offset))
+                                  float(gate_offset), 9 if spatial_taps == 9 else 1)
         lib = _lib.load()
         self.num_params = int(lib.qbold_encoder_num_params(C.byref(self.shape)))
         self.flat = torch.zeros(self.num_params, dtype=torch.float32, device=ctx.device)
@@ -58,6 +58,7 @@ class EncoderWeights:
     def _slices(self):
         T, U, L = self.shape.T, self.shape.U, self.shape.L
         G = U if self.shape.channelwise_gating else 1
+        rs = (3, 3, U, U) if self.shape.spatial_taps == 9 else (U, U)  # residual conv kernels
         out, off = {}, 0
 
         def take(name, *shape):
@@ -67,8 +68,8 @@ class EncoderWeights:
             off += n
         take("W0", T, U); take("b0", U)
         for _ in range(L):
-            take("Wc", U, U); take("bc", U); take("Wr1", U, U); take("br1", U)
-            take("Wr2", U, U); take("br2", U); take("Wg", U, G); take("bg", G)
+            take("Wc", U, U); take("bc", U); take("Wr1", *rs); take("br1", U)
+            take("Wr2", *rs); take("br2", U); take("Wg", U, G); take("bg", G)
         take("Wf", U, 5); take("bf", 5); take("Ws", U, T); take("bs", T)
         assert off == self.num_params
         return out
@@ -466,6 +467,34 @@ class TrainState:
                    "qbold_encoder_train_bwd")
         return self.grad
 
+    def forward_spatial(self, x5):
+        """Stream 2 on an image-crop batch x5 [B, X, Y, Z, T] with the 3x3x1 convolutions.
+        Returns (q [V,5], log_sigma [V,T]) with V = B X Y Z."""
+        ctx = self.ctx
+        x = _f32(x5, "x", ctx.T)
+        if x.dim() != 5:
+            raise ValueError("forward_spatial expects [B, X, Y, Z, T]")
+        B, X, Y, Z, _ = x.shape
+        self._geom = Geometry(B, X, Y, Z)
+        N = B * X * Y * Z
+        q = torch.empty((N, 5), dtype=torch.float32, device=x.device)
+        ls = torch.empty((N, ctx.T), dtype=torch.float32, device=x.device)
+        _lib.check(ctx.lib.qbold_encoder_spatial_fwd(ctx.handle, C.byref(self.weights.shape),
+                                                     _ptr(self.weights.flat), _ptr(x), C.byref(self._geom),
+                                                     _ptr(self.workspace(N)), _ptr(q), _ptr(ls), _stream()),
+                   "qbold_encoder_spatial_fwd")
+        self._n = N
+        return q, ls
+
+    def backward_spatial(self, g_q, g_ls, sums=None):
+        ctx = self.ctx
+        _lib.check(ctx.lib.qbold_encoder_spatial_bwd(ctx.handle, C.byref(self.weights.shape),
+                                                     _ptr(self.weights.flat), C.byref(self._geom),
+                                                     _ptr(self._ws), _ptr(g_q), _ptr(g_ls), _ptr(sums),
+                                                     _ptr(self.grad), _stream()),
+                   "qbold_encoder_spatial_bwd")
+        return self.grad
+
     def synth_loss_bwd(self, y_true, q):
         """Pre-training loss (mean over voxels) and its head gradient (already divided by N)."""
         ctx = self.ctx
@@ -486,3 +515,21 @@ class TrainState:
                                                  float(weight_decay), self.step, _stream()),
                    "qbold_adamw_step")
         self.weights.mark_dirty()
+
+
+@_ctx_method
+def smoothness(self, q5, mask5, weight=0.0, g_q=None):
+    """smoothness_loss numerator on a crop batch: q5 [B,X,Y,Z,5], mask5 [B,X,Y,Z(,1)].  Returns the
+    device double sum |dx| + |dy|; if g_q [V,5] is given, weight * d sum / d q is added to it."""
+    q = _f32(q5, "q", 5)
+    if q.dim() != 5:
+        raise ValueError("smoothness expects [B, X, Y, Z, 5]")
+    B, X, Y, Z, _ = q.shape
+    m = _f32(mask5, "mask").reshape(-1)
+    if m.numel() != B * X * Y * Z:
+        raise ValueError("mask does not match q")
+    geom = Geometry(B, X, Y, Z)
+    tv = torch.empty(1, dtype=torch.float64, device=q.device)
+    _lib.check(self.lib.qbold_smoothness(self.handle, _ptr(q), _ptr(m), C.byref(geom), float(weight),
+                                         _ptr(g_q), _ptr(tv), _stream()), "qbold_smoothness")
+    return tv

@@ -9,9 +9,10 @@ three-state phase skipping (qbold_build_model.py:11-56).  Every number is produc
 libqbold_hip.so; with N > 1 ranks (torchrun) voxels are sharded and gradients / loss sums are
 all-reduced over RCCL (qbold_vi_amd.distributed).
 
-Differences from the reference, all forced by scope: fine-tuning runs on voxel batches
-(image crops with the 3x3x1 context and the TV term are row N1), so `--synthetic_voxels N` (or
-real .npy volumes flattened to masked voxels) replaces the random-crop pipeline; wandb is replaced
+Fine-tuning data: real `.npy` volumes go through the reference's random-crop pipeline
+(prepare_dataset, train.py:17-72: 38 crops of crop_size x crop_size x Z per step, stream 2 with its
+3x3x1 convolutions, TV smoothness term) on the layer-wise spatial kernels; `--synthetic_voxels N`
+fine-tunes on N i.i.d. synthetic voxels through the fused voxel kernels instead.  wandb is replaced
 by JSONL metrics with the reference's key names.
 """
 import json
@@ -189,6 +190,102 @@ def prepare_voxel_dataset(data, mask, model):
     return x, mask.contiguous(), prior
 
 
+class CropDataset:
+    """train.prepare_dataset (train.py:17-72) for image volumes [subj, X, Y, Z, T+1] (mask last):
+    optional blank crop [17:-17, 10:-10], data masked, prior = stream-1 prediction per voxel, random
+    crop_size x crop_size crops over (X, Y) keeping every slice and channel."""
+
+    def __init__(self, real_data, model, crop_size=20, training=True, blank_crop=True):
+        if blank_crop and real_data.shape[1] > 34 + 8 and real_data.shape[2] > 20 + 8:
+            real_data = real_data[:, 17:-17, 10:-10]
+        self.mask = real_data[..., -1].contiguous()
+        self.data = (real_data[..., :-1] * real_data[..., -1:]).contiguous()
+        self.crop = [min(crop_size, self.data.shape[1]), min(crop_size, self.data.shape[2])]
+        self.prior = model.predict(self.data, want=("out1",))[0]
+        self.batch = 38 if training else 3  # train.py:66-70
+        self.training = training
+        self._cursor = 0
+
+    def next_batch(self, generator):
+        n_subj, X, Y = self.data.shape[:3]
+        cx, cy = self.crop
+        dev = self.data.device
+        if self.training:  # shuffled, repeated
+            subj = torch.randint(0, n_subj, (self.batch,), generator=generator, device=dev)
+        else:
+            subj = (torch.arange(self.batch, device=dev) + self._cursor) % n_subj
+            self._cursor += self.batch
+        x0 = torch.randint(0, X - cx + 1, (self.batch,), generator=generator, device=dev)
+        y0 = torch.randint(0, Y - cy + 1, (self.batch,), generator=generator, device=dev)
+        ix = (x0[:, None] + torch.arange(cx, device=dev)[None])[:, :, None]
+        iy = (y0[:, None] + torch.arange(cy, device=dev)[None])[:, None, :]
+        sb = subj[:, None, None]
+        return (self.data[sb, ix, iy].contiguous(), self.mask[sb, ix, iy].contiguous(),
+                self.prior[sb, ix, iy].contiguous())
+
+
+def _train_full_model_crops(config_dict, trainer, full_model, study_dataset, train_dataset, log,
+                            steps_per_epoch, kl_samples, max_steps):
+    rank, world, _ = qd.init_from_env()
+    ctx = trainer.context
+    model = full_model.encoder_model
+    state = TrainState(ctx, model.weights)
+    S = trainer._no_samples
+    sw = float(_get(config_dict, "smoothness_weight", 0.0) or 0.0)
+    decay0, lr0 = float(_get(config_dict, "adamw_decay")), float(_get(config_dict, "ft_lr"))
+    beta2 = 0.9 if decay0 > 0.0 else 0.999
+    dev = train_dataset.data.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(2 + rank)   # every rank draws its own crops (data-parallel over crops)
+    gv = torch.Generator(device=dev)
+    gv.manual_seed(3)
+    step = 0
+    for epoch in range(int(_get(config_dict, "no_ft_epochs"))):
+        tot = torch.zeros(4, dtype=torch.float64, device=dev)
+        for _ in range(steps_per_epoch):
+            x5, m5, p5 = train_dataset.next_batch(g)
+            n = m5.numel()
+            q, ls = state.forward_spatial(x5)
+            sums, gq, gls, _ = ctx.elbo_bwd(x5.reshape(n, -1), m5.reshape(n), q, p5.reshape(n, 5), ls, S,
+                                            kl_samples, seed=1000 + step, voxel0=rank * n)
+            tv = ctx.smoothness(q.reshape(m5.shape + (5,)), m5, weight=sw, g_q=gq)
+            red = torch.cat([sums, tv])
+            if world > 1:
+                torch.distributed.all_reduce(red)
+            state.backward_spatial(gq, gls, red[:3].contiguous())
+            if world > 1:
+                torch.distributed.all_reduce(state.grad)
+            wd = lr_schedule(decay0, step, steps_per_epoch) if decay0 > 0.0 else 0.0
+            state.adamw(lr_schedule(lr0, step, steps_per_epoch), wd, 0.9, beta2, 1e-7)
+            tot += red
+            step += 1
+            if max_steps and step >= max_steps:
+                break
+        nll, kl, smooth = float(tot[0] / tot[2]), float(tot[1] / tot[2]), float(tot[3] / tot[2])
+        _check_finite(nll + kl + smooth, "fine-tuning loss")
+        metrics = {"epoch": epoch, "loss": nll + kl + sw * smooth, "predicted_images_loss": nll,
+                   "predictions_loss": kl + sw * smooth, "predictions_smoothness_metric": smooth,
+                   "predictions_kl_metric": kl}
+        # ELBOCallback (train.py:329-357): 4 validation batches, NLL averaged over 10 stochastic passes
+        vn = vk = vs = 0.0
+        for b in range(4):
+            x5, m5, p5 = study_dataset.next_batch(gv)
+            nll_b = 0.0
+            for i in range(10):
+                out = full_model.elbo(x5, m5, p5, kl_samples=kl_samples, seed=7000 + 100 * epoch + 10 * b + i)
+                nll_b += float(out["nll"])
+            vn += nll_b / 10.0
+            vk += float(out["kl"])
+            vs += float(ctx.smoothness(out["q"].reshape(m5.shape + (5,)), m5)[0] / m5.sum())
+        vn, vk, vs = vn / 4, vk / 4, vs / 4
+        metrics.update({"val_nll": vn, "val_elbo": vn + vk, "val_elbo_smooth": vn + vk * 1.0 + vs * sw,
+                        "val_smoothness": vs, "val_smoothness_scaled": vs * sw, "val_kl": vk})
+        log.log(metrics)
+        if max_steps and step >= max_steps:
+            break
+    return model
+
+
 def train_full_model(config_dict, trainer, full_model, study_dataset, train_dataset, log=None,
                      steps_per_epoch=100, batch_voxels=38 * 25 * 25 * 8, kl_samples=70, max_steps=None):
     """Fine-tune stream 2 by minimising nll + 1.0 * kl (+ smoothness_weight * TV, identically 0 on
@@ -196,6 +293,9 @@ def train_full_model(config_dict, trainer, full_model, study_dataset, train_data
     assert isinstance(trainer, EncoderTrainer)
     rank, world, _ = qd.init_from_env()
     log = log or MetricsLog(rank=rank)
+    if isinstance(train_dataset, CropDataset):
+        return _train_full_model_crops(config_dict, trainer, full_model, study_dataset, train_dataset, log,
+                                       steps_per_epoch, kl_samples, max_steps)
     ctx = trainer.context
     model = full_model.encoder_model
     state = TrainState(ctx, model.weights)
@@ -293,19 +393,21 @@ def synthetic_voxel_dataset(params, config_dict, n, device, seed):
     return layer(y), torch.ones(n, dtype=torch.float32, device=y.device), y
 
 
-def load_real_voxels(directory, names, device):
-    """The reference's .npy volumes [subj, X, Y, 8, T+2] (train.py:208-221) flattened to voxels:
-    signals, and the LAST channel (brain mask) as mask -- the crop pipeline is row N1."""
-    xs, ms = [], []
+def load_real_volumes(directory, names, T, device, use_brain_mask=False):
+    """The reference's .npy volumes [subj, X, Y, 8, T+2] = signals + grey-matter mask + brain mask
+    (data_preprocessing.py:265-266; train.py:208-221).  Returns [subj, X, Y, Z, T+1] with ONE mask
+    as last channel: the grey-matter mask for the loss (train.py:216,219) or the brain mask for
+    whole-brain predictions (:215,218).  Files that already carry T+1 channels pass through."""
+    vols = []
     for name in names:
         arr = np.load(os.path.join(directory, name)).astype(np.float32)
-        T = arr.shape[-1] - 2
-        flat = arr.reshape(-1, T + 2)
-        xs.append(flat[:, :T])
-        ms.append(flat[:, -1])
-    x = torch.as_tensor(np.concatenate(xs), device=device)
-    m = torch.as_tensor(np.concatenate(ms), device=device)
-    return x, m
+        if arr.shape[-1] == T + 2:
+            keep = -1 if use_brain_mask else -2
+            arr = np.concatenate([arr[..., :T], arr[..., keep:][..., :1]], -1)
+        elif arr.shape[-1] != T + 1:
+            raise ValueError(f"{name}: last dimension {arr.shape[-1]} is neither T+1 nor T+2 (T={T})")
+        vols.append(arr)
+    return torch.as_tensor(np.concatenate(vols, 0), device=device)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -343,10 +445,15 @@ def train_model(config_dict, device=None, log=None, pt_sample_size=None, max_pt_
         d = _get(config_dict, "d")
         if not d or not os.path.exists(d):
             raise Exception('Real data directory not found')  # train.py:204-205
-        x, mask = load_real_voxels(d, ["ASE_scan.npy", "ASE_INF.npy", "ASE_SUP.npy"], trainer.context.device)
-        vx, vmask = load_real_voxels(d, ["hyperv_ase.npy", "baseline_ase.npy"], trainer.context.device)
-    train_dataset = prepare_voxel_dataset(x, mask, model)
-    study_dataset = prepare_voxel_dataset(vx, vmask, model)
+        T, dev = trainer.context.T, trainer.context.device
+        train_vol = load_real_volumes(d, ["ASE_scan.npy", "ASE_INF.npy", "ASE_SUP.npy"], T, dev)
+        study_vol = load_real_volumes(d, ["hyperv_ase.npy", "baseline_ase.npy"], T, dev)
+    if n_syn > 0:
+        train_dataset = prepare_voxel_dataset(x, mask, model)
+        study_dataset = prepare_voxel_dataset(vx, vmask, model)
+    else:  # prepare_dataset(train_data, model, crop_size) / (study_data, model, 76, training=False)
+        train_dataset = CropDataset(train_vol, model, int(_get(config_dict, "crop_size")), training=True)
+        study_dataset = CropDataset(study_vol, model, 76, training=False)
     sig_gen_layer = SignalGenerationLayer(dict(params, simulate_noise='False'),
                                           _get(config_dict, "full_model"), _get(config_dict, "use_blood"),
                                           device=trainer.context.device)

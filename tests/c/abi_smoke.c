@@ -28,7 +28,7 @@ int main(void) {
     /* float32-semantics values of the Simpson-129 integral (0.2886, 3.0380) */
     if (F[0] != 0.0f || fabsf(F[1] - 0.28860f) > 2e-4f || fabsf(F[2] - 3.0380f) > 2e-3f) return 6;
     if (qbold_signal_fwd(ctx, NULL, NULL, 4, NULL) != QBOLD_ERR_NO_DEVICE) return 7;
-    qbold_encoder_shape s = {11, 60, 2, 1, -3.0f};
+    qbold_encoder_shape s = {11, 60, 2, 1, -3.0f, 1};
     if (qbold_encoder_num_params(&s) != 30976) return 8;
     qbold_ctx_destroy(ctx);
     printf("abi ok: F(1)=%.6f F(4)=%.6f dF(4)=%.6f\n", F[1], F[2], dF[2]);

@@ -24,7 +24,7 @@ def trainer(params):
 def oracle_weights(model, gate_offset):
     w = model.get_weights()
     w["gate_offset"] = gate_offset
-    w["meta"] = dict(T=11, U=60, L=2, channelwise_gating=True)
+    w["meta"] = dict(T=11, U=60, L=2, channelwise_gating=True, taps=9)
     return w
 
 

@@ -74,8 +74,9 @@ def test_missing_real_data_directory_raises(tmp_path, monkeypatch):
         training.train_model(cfg, pt_sample_size=100)
 
 
-def test_real_volume_layout_is_accepted(tmp_path, monkeypatch):
-    """.npy volumes shaped [subj, X, Y, 8, T+2] as the reference loads them (train.py:208-221)."""
+def test_fine_tuning_on_image_crops(tmp_path, monkeypatch):
+    """.npy volumes shaped [subj, X, Y, 8, T+2] as the reference loads them (train.py:208-221):
+    random-crop pipeline, stream 2 with 3x3x1 convolutions, NLL + KL + 5 x TV objective."""
     from qbold_vi_amd import training
     from qbold_vi_amd.signals import SignalGenerationLayer
     monkeypatch.chdir(ROOT)
@@ -84,15 +85,30 @@ def test_real_volume_layout_is_accepted(tmp_path, monkeypatch):
     rng = np.random.default_rng(0)
     d = tmp_path / "data"
     os.makedirs(d)
+    nx = ny = 14
+    gx, gy = np.meshgrid(np.linspace(0, 1, nx), np.linspace(0, 1, ny), indexing="ij")
     for name in ("ASE_scan", "ASE_INF", "ASE_SUP", "hyperv_ase", "baseline_ase"):
-        y = np.stack([rng.uniform(0.2, 0.6, 2 * 6 * 6 * 8), rng.uniform(0.01, 0.06, 2 * 6 * 6 * 8)], -1)
-        sig = layer(torch.as_tensor(y, dtype=torch.float32, device="cuda")).cpu().numpy() * 100.0
-        vol = np.concatenate([sig, np.ones((sig.shape[0], 2), np.float32)], -1).reshape(2, 6, 6, 8, 13)
-        vol[:, 0, :, :, -1] = 0.0   # a masked-out slab
+        # smooth parameter maps: neighbouring voxels are similar, as in a brain
+        oef = 0.3 + 0.2 * gx[None, :, :, None] + 0.05 * rng.standard_normal((2, 1, 1, 8))
+        dbv = 0.02 + 0.03 * gy[None, :, :, None] + 0.0 * oef
+        y = np.stack([np.broadcast_to(oef, (2, nx, ny, 8)), np.broadcast_to(dbv, (2, nx, ny, 8))], -1)
+        sig = layer(torch.as_tensor(y.reshape(-1, 2), dtype=torch.float32, device="cuda")).cpu().numpy()
+        vol = np.concatenate([sig * 100.0, np.ones((sig.shape[0], 2), np.float32)], -1)
+        vol = vol.reshape(2, nx, ny, 8, 13)
+        vol[:, 0, :, :, -2:] = 0.0   # a slab outside the masks
         np.save(d / f"{name}.npy", vol)
-    cfg = small_config(tmp_path / "run", synthetic_voxels=0, d=str(d), no_pt_epochs=1, no_ft_epochs=1)
-    _, _, hist = training.train_model(cfg, pt_sample_size=100, max_ft_steps=3)
-    assert np.isfinite(hist[-1]["val_elbo"])
+    cfg = small_config(tmp_path / "run", synthetic_voxels=0, d=str(d), no_pt_epochs=40, no_ft_epochs=2,
+                       crop_size=10)
+    model, trainer, hist = training.train_model(cfg, pt_sample_size=200, max_ft_steps=None)
+    ft = [h for h in hist if "val_elbo" in h]
+    assert len(ft) == 2 and all(np.isfinite(h["val_elbo"]) for h in ft)
+    assert ft[-1]["loss"] < ft[0]["loss"]
+    assert ft[-1]["val_smoothness"] > 0.0 and "predictions_smoothness_metric" in ft[-1]
+    assert abs(ft[-1]["val_elbo_smooth"] - (ft[-1]["val_elbo"] + 5.0 * ft[-1]["val_smoothness"])) < 1e-9
+    # whole-volume prediction through the spatial path
+    vol = torch.as_tensor(np.load(d / "baseline_ase.npy")[..., :11], device="cuda")
+    o1, o2, sg = model.predict(vol)
+    assert o2.shape == (2, nx, ny, 8, 5) and sg.shape == (2, nx, ny, 8, 11) and bool(torch.isfinite(o2).all())
 
 
 def test_train_py_cli(tmp_path):

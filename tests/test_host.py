@@ -65,7 +65,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/qbold_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().qbold_abi_version() == 1
+    assert _lib.load().qbold_abi_version() == 2
 
 
 def test_host_only_context_tau_grid_and_table(params, oracle32, oracle64):
@@ -127,11 +127,13 @@ def test_fails_loudly_without_gpu(params):
 def test_encoder_param_count_matches_survey():
     from qbold_vi_amd import _lib
     lib = _lib.load()
-    s = _lib.EncoderShape(11, 60, 2, 1, -3.0)
+    s = _lib.EncoderShape(11, 60, 2, 1, -3.0, 1)
     assert lib.qbold_encoder_num_params(C.byref(s)) == 30976   # centre-tap subset
-    s1 = _lib.EncoderShape(11, 60, 2, 0, 0.0)
+    s1 = _lib.EncoderShape(11, 60, 2, 0, 0.0, 1)
     assert lib.qbold_encoder_num_params(C.byref(s1)) == 30976 - 2 * (60 * 60 + 60) + 2 * (60 + 1)
     assert lib.qbold_encoder_packed_floats(C.byref(s)) * 4 < 150 * 1024  # fits the 160 KiB LDS
+    s9 = _lib.EncoderShape(11, 60, 2, 1, -3.0, 9)   # full 3x3x1 residual kernels
+    assert lib.qbold_encoder_num_params(C.byref(s9)) == 146176  # SURVEY 2.1 parameter count
 
 
 def test_shard_ranges():

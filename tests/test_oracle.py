@@ -229,6 +229,59 @@ def test_encoder_matches_numpy(params):
         np.testing.assert_allclose(sg, np.exp(b @ W["Ws"] + W["bs"]), rtol=1e-9)
 
 
+def test_spatial_encoder_matches_scipy_correlate(params):
+    """Keras Conv3D((3,3,1), padding='same') is a cross-correlation with zero padding: out[x,y] =
+    sum_{i,j} in[x+i-1, y+j-1] @ K[i,j] (model.py:152-157).  Checked against scipy.ndimage.correlate
+    channel by channel; the TV term (model.py:726-754) against a numpy restatement."""
+    import scipy.ndimage as ndi
+    from oracle.oracle import Oracle, init_weights
+    o = Oracle("f64", params)
+    w = init_weights(T=11, U=8, L=2, channelwise_gating=True, seed=7, taps=9)
+    rng = np.random.default_rng(7)
+    for k in ("b0", "bc", "br1", "br2", "bg", "bf"):
+        w[k] = rng.normal(size=w[k].shape).astype(np.float32) * 0.1
+    w["Wr1"] = (w["Wr1"] * 6).astype(np.float32)
+    w["Wr2"] = (w["Wr2"] * 6).astype(np.float32)
+    w["gate_offset"] = 0.3
+    B, X, Y, Z = 2, 5, 4, 3
+    x = rng.uniform(0.05, 1.0, (B, X, Y, Z, 11))
+    W = {k: np.asarray(v, np.float64) for k, v in w.items() if k not in ("meta", "gate_offset")}
+    relu = lambda v: np.maximum(v, 0)
+
+    def conv(a, K, bias):  # a [B,X,Y,Z,Cin], K [3,3,Cin,Cout]
+        out = np.zeros(a.shape[:-1] + (K.shape[-1],))
+        for co in range(K.shape[-1]):
+            for ci in range(K.shape[-2]):
+                k5 = K[:, :, ci, co][None, :, :, None]
+                out[..., co] += ndi.correlate(a[..., ci], k5, mode="constant", cval=0.0)
+        return out + bias
+
+    xc = np.clip(x, 1e-2, 1e8)
+    b = relu(np.log(xc / xc[..., 2:3]) @ W["W0"] + W["b0"])
+    for l in range(2):
+        skip = relu(b @ W["Wc"][l] + W["bc"][l])
+        r = conv(relu(conv(relu(b), W["Wr1"][l], W["br1"][l])), W["Wr2"][l], W["br2"][l])
+        g = 1 / (1 + np.exp(-(r @ W["Wg"][l] + W["bg"][l] + 0.3)))
+        b = skip * (1 - g) + r * g
+    o2, sg = o.encoder_fwd_spatial(w, x)
+    np.testing.assert_allclose(o2, b @ W["Wf"] + W["bf"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(sg, np.exp(b @ W["Ws"] + W["bs"]), rtol=1e-9)
+    # a 1x1 crop sees only the centre tap: the voxel-wise encoder with centre-tap weights
+    wc = dict(w, Wr1=w["Wr1"][:, 1, 1], Wr2=w["Wr2"][:, 1, 1], meta=dict(w["meta"], taps=1))
+    x1 = x.reshape(-1, 1, 1, 1, 11)
+    np.testing.assert_allclose(o.encoder_fwd_spatial(w, x1)[0].reshape(-1, 5), o.encoder_fwd(wc, x1)[1],
+                               rtol=1e-10, atol=1e-13)
+
+    q = rng.normal(size=(B, X, Y, Z, 5))
+    mask = (rng.uniform(size=(B, X, Y, Z)) > 0.3).astype(np.float64)
+    sig = lambda v: 1 / (1 + np.exp(-v))
+    oef, dbv = sig(q[..., 0]) * 0.8 + 0.04, sig(q[..., 2]) * 0.2 + 0.001   # forward_transform
+    p = np.stack([oef / 0.8, dbv / 0.2], -1)                                  # model.py:735-736
+    dx = np.abs(p[:, 1:] - p[:, :-1]).sum(-1) * (mask[:, 1:] * mask[:, :-1] > 0)
+    dy = np.abs(p[:, :, 1:] - p[:, :, :-1]).sum(-1) * (mask[:, :, 1:] * mask[:, :, :-1] > 0)
+    np.testing.assert_allclose(o.smoothness_loss(q, mask), (dx.sum() + dy.sum()) / mask.sum(), rtol=1e-10)
+
+
 def test_moments_and_elbo_composition(oracle64):
     rng = np.random.default_rng(4)
     n, S, K = 30, 3, 5
