@@ -376,3 +376,77 @@ class EncoderTrainer:
         mask = true_params[..., 5]
         tv = self._ctx.smoothness(pred_params[..., :5], mask)
         return (tv[0] / mask.sum()).float()
+
+    def estimate_population_param_distribution(self, model, data):
+        """model.py:756-770: masked population mean / std of the predicted OEF and DBV logits
+        (first head), printed and returned as (mean_oef, log_std_oef, mean_dbv, log_std_dbv)."""
+        predictions = model.predict(data[..., :-1] * data[..., -1:], want=("out1",))[0]
+        mask = data[..., -1:]
+        oef, dbv = predictions[..., 0:1] * mask, predictions[..., 2:3] * mask
+        mask_pix = mask.sum()
+        out = []
+        for v in (oef, dbv):
+            mean = v.sum() / mask_pix
+            std = torch.sqrt((torch.square(v - mean) * mask).sum() / mask_pix)
+            out += [mean, self.inv_transform_std(torch.log(std).reshape(1))[0]]
+        print('final results for mean_oef, log_std_oef, mean_dbv, log_std_dbv, respectively: ')
+        print(*[float(o) for o in out])
+        return tuple(out)
+
+    def save_predictions(self, model, data, filename, transform_directory=None, use_first_op=True,
+                         fine_tuner_model=None, priors=None):
+        """model.py:772-887: write `<filename>_{oef,dbv,r2p,logstds}.nii.gz` (posterior means of
+        OEF / DBV / R2' over 200 draws and their variances) and, with a fine tuner,
+        `_likelihood` (per-voxel NLL averaged over 100 stochastic passes), `_kl` (100-draw KL to
+        `priors`) and `_residual` (mean |normalised data - one sampled prediction|).
+        data [subj, X, Y, Z, T+1] with the mask last; each map is stored as [X, Y, Z, subj*C].
+        `transform_directory/example.nii.gz`, when present, donates its header (:794-797); the
+        FSL `applywarp`/`fslmerge` MNI step (:850-879) is preprocessing outside this package and
+        is skipped."""
+        import os
+        from . import nifti
+        data = torch.as_tensor(data, dtype=torch.float32, device=self._ctx.device)
+        T = self._ctx.T
+        mask = data[..., -1:]
+        predictions, predictions2, _ = model.predict(data[..., :-1] * mask)
+        if use_first_op is False:
+            predictions = predictions2
+        means, log_stds = self.calculate_means(predictions, torch.ones_like(predictions[..., :1]),
+                                               include_r2p=True, return_stds=True, no_samples=200)
+        template = None
+        if transform_directory is not None:
+            ex = os.path.join(transform_directory, 'example.nii.gz')
+            if os.path.isfile(ex):
+                template = nifti.load(ex)[1]
+
+        def save_im_data(im_data, _filename):
+            im = im_data.detach().cpu().numpy() if torch.is_tensor(im_data) else np.asarray(im_data)
+            images = np.concatenate(np.split(im, im.shape[0], axis=0), axis=-1)[0]
+            nifti.save(images.astype(np.float32), _filename + '.nii.gz', template)
+
+        if fine_tuner_model:
+            if priors is None:
+                raise ValueError("save_predictions with a fine tuner needs the prior maps (train.py:272-279)")
+            no_passes = 100
+            out = fine_tuner_model.elbo(data[..., :-1], mask, torch.as_tensor(priors, device=data.device)[..., :5],
+                                        no_samples=no_passes * self._no_samples, kl_samples=100,
+                                        seed=self._seed + 17)
+            m = mask.reshape(-1)
+            lik = (out["nll_kl"][:, 0] * m).reshape(data.shape[:4] + (1,))
+            kl = torch.where(m > 0, out["nll_kl"][:, 1], torch.zeros_like(m)).reshape(data.shape[:4] + (1,))
+            save_im_data(lik, filename + '_likelihood')
+            save_im_data(kl, filename + '_kl')
+            y_true = data[..., :-1]
+            y_pred = fine_tuner_model.predict([y_true, mask])['predicted_images'][:data.shape[0], ..., :T]
+            if self._multi_image_normalisation:
+                sl = slice(self._se_idx - 1, self._se_idx + 2)
+            else:
+                sl = slice(self._se_idx, self._se_idx + 1)
+            y_true = y_true / (y_true[..., sl].mean(-1, keepdim=True) + 1e-3)
+            y_pred = y_pred / (y_pred[..., sl].mean(-1, keepdim=True) + 1e-3)
+            save_im_data((y_true - y_pred).abs().mean(-1, keepdim=True), filename + '_residual')
+
+        save_im_data(means[..., 0:1], filename + '_oef')
+        save_im_data(means[..., 1:2], filename + '_dbv')
+        save_im_data(means[..., 2:3], filename + '_r2p')
+        save_im_data(log_stds, filename + '_logstds')

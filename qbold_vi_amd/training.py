@@ -448,6 +448,18 @@ def train_model(config_dict, device=None, log=None, pt_sample_size=None, max_pt_
         T, dev = trainer.context.T, trainer.context.device
         train_vol = load_real_volumes(d, ["ASE_scan.npy", "ASE_INF.npy", "ASE_SUP.npy"], T, dev)
         study_vol = load_real_volumes(d, ["hyperv_ase.npy", "baseline_ase.npy"], T, dev)
+        # brain-masked copies for image export and their stream-1 priors (train.py:215-236)
+        export = {n: load_real_volumes(d, [f"{n}_ase.npy"], T, dev, use_brain_mask=True)
+                  for n in ("baseline", "hyperv")}
+        export_priors = {n: model.predict(v[..., :-1] * v[..., -1:], want=("out1",))[0][..., :5]
+                         for n, v in export.items()}
+        tdirs = {n: os.path.join(d, f"transforms_{n}") for n in export}
+        baseline_gm = load_real_volumes(d, ["baseline_ase.npy"], T, dev)
+        trainer.estimate_population_param_distribution(model, baseline_gm)   # train.py:242
+        if rank == 0:                                                         # train.py:248-251
+            for n, v in export.items():
+                trainer.save_predictions(model, v, os.path.join(save_dir, f"pt_{n}"),
+                                         transform_directory=tdirs[n])
     if n_syn > 0:
         train_dataset = prepare_voxel_dataset(x, mask, model)
         study_dataset = prepare_voxel_dataset(vx, vmask, model)
@@ -463,8 +475,15 @@ def train_model(config_dict, device=None, log=None, pt_sample_size=None, max_pt_
     else:
         train_full_model(config_dict, trainer, full_model, study_dataset, train_dataset, log=log,
                          max_steps=max_ft_steps)
+        if n_syn == 0:
+            trainer.estimate_population_param_distribution(model, baseline_gm)   # train.py:265
         if rank == 0:
             model.save_weights(final_path)
+            if n_syn == 0:                                                        # train.py:272-279
+                for n, v in export.items():
+                    trainer.save_predictions(model, v, os.path.join(save_dir, n), transform_directory=tdirs[n],
+                                             use_first_op=False, fine_tuner_model=full_model,
+                                             priors=export_priors[n])
     return model, trainer, log.history
 
 

@@ -105,6 +105,20 @@ def test_fine_tuning_on_image_crops(tmp_path, monkeypatch):
     assert ft[-1]["loss"] < ft[0]["loss"]
     assert ft[-1]["val_smoothness"] > 0.0 and "predictions_smoothness_metric" in ft[-1]
     assert abs(ft[-1]["val_elbo_smooth"] - (ft[-1]["val_elbo"] + 5.0 * ft[-1]["val_smoothness"])) < 1e-9
+    # NIfTI export set of save_predictions (model.py:772-887; train.py:248-251, 272-279)
+    from qbold_vi_amd import nifti
+    run = tmp_path / "run"
+    for stem in ("pt_baseline", "pt_hyperv"):
+        for suffix in ("_oef", "_dbv", "_r2p", "_logstds"):
+            assert (run / f"{stem}{suffix}.nii.gz").is_file()
+    for suffix, chans in (("_oef", 1), ("_dbv", 1), ("_r2p", 1), ("_logstds", 3), ("_likelihood", 1),
+                          ("_kl", 1), ("_residual", 1)):
+        im, _ = nifti.load(str(run / f"baseline{suffix}.nii.gz"))
+        assert im.shape == (nx, ny, 8, 2 * chans) and im.dtype == np.float32 and np.isfinite(im).all()
+    oef_map, _ = nifti.load(str(run / "baseline_oef.nii.gz"))
+    assert 0.04 < oef_map.min() and oef_map.max() < 0.84
+    kl_map, _ = nifti.load(str(run / "baseline_kl.nii.gz"))
+    assert (kl_map[0] == 0).all() and (kl_map[1:] != 0).any()   # the slab outside the brain mask
     # whole-volume prediction through the spatial path
     vol = torch.as_tensor(np.load(d / "baseline_ase.npy")[..., :11], device="cuda")
     o1, o2, sg = model.predict(vol)

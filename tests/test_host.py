@@ -163,3 +163,37 @@ def test_c_program_links_against_the_abi(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "abi ok" in r.stdout
+
+
+def test_nifti_writer_follows_the_nifti1_layout(tmp_path):
+    """The export format of save_predictions (model.py:790-801) without nibabel: field offsets per
+    the NIfTI-1.1 header definition, Fortran-ordered voxels, gzip container, round trip."""
+    import gzip
+    import struct
+    from qbold_vi_amd import nifti
+    rng = np.random.default_rng(0)
+    arr = rng.normal(size=(5, 4, 3, 2)).astype(np.float32)
+    path = tmp_path / "a.nii.gz"
+    nifti.save(arr, str(path))
+    raw = gzip.open(path, "rb").read()
+    assert struct.unpack_from("<i", raw, 0)[0] == 348 and raw[344:348] == b"n+1\0"
+    assert struct.unpack_from("<8h", raw, 40) == (4, 5, 4, 3, 2, 1, 1, 1)          # dim
+    assert struct.unpack_from("<hh", raw, 70) == (16, 32)                            # FLOAT32, bitpix
+    assert struct.unpack_from("<f", raw, 108)[0] == 352.0                            # vox_offset
+    assert struct.unpack_from("<hh", raw, 252) == (0, 0)                             # qform/sform codes
+    assert len(raw) == 352 + arr.size * 4
+    # x varies fastest on disk
+    vox = np.frombuffer(raw, "<f4", arr.size, 352)
+    assert vox[1] == arr[1, 0, 0, 0] and vox[5] == arr[0, 1, 0, 0]
+    back, hdr = nifti.load(str(path))
+    np.testing.assert_array_equal(back, arr)
+    # a template header donates orientation; dims / datatype are rewritten
+    tmpl = bytearray(hdr)
+    struct.pack_into("<hh", tmpl, 252, 1, 1)
+    struct.pack_into("<8f", tmpl, 76, 1.0, 2.0, 2.0, 3.0, 1.0, 1.0, 1.0, 1.0)
+    nifti.save(arr[..., 0].astype(np.float64), str(tmp_path / "b.nii"), bytes(tmpl))
+    b, hb = nifti.load(str(tmp_path / "b.nii"))
+    assert b.dtype == np.float64 and b.shape == (5, 4, 3)
+    assert struct.unpack_from("<hh", hb, 252) == (1, 1) and struct.unpack_from("<8f", hb, 76)[1:4] == (2.0, 2.0, 3.0)
+    with pytest.raises(ValueError):
+        nifti.save(arr.astype(np.complex64), str(tmp_path / "c.nii"))
