@@ -152,6 +152,15 @@ int qbold_posterior_moments(const qbold_ctx* ctx, const float* q, const float* z
 /* EncoderTrainer.normalise_data (model.py:97-113): x [N][T] -> log(clip(x)/clip(x)[se]) [N][T]. */
 int qbold_normalise(const qbold_ctx* ctx, const float* x, float* out, int64_t N, void* stream);
 
+/* loglinear.fit_wls (loglinear.py:68-105): the log-linear comparator.  Per voxel a weighted
+ * least-squares line ln S = c - R2' tau over the taus > tau_min (reference: 0.016) with weights
+ * 1/tau, in closed form; DBV = c - ln S(tau = 0), OEF = R2' / (DBV gamma 4/3 pi dchi hct B0);
+ * clipped to [0.01,0.8], [0.002,0.25], [1e-2,100].  signals [N][T] -> out [N][3] = (OEF, DBV, R2').
+ * The taus are rounded to 7 decimals in float32 as the reference does (:126-127); fails with
+ * QBOLD_ERR_ARG when no tau equals 0 or fewer than two taus exceed tau_min. */
+int qbold_wls_fit(const qbold_ctx* ctx, const float* signals, double tau_min, float* out, int64_t N,
+                  void* stream);
+
 /* Element-wise parameter transforms of EncoderTrainer / LogitMVN (model.py:288-316 =
  * logit_mvn.py:72-100).  The FORWARD/BACKWARDS ops act on interleaved (OEF, DBV) pairs. */
 typedef enum {

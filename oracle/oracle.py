@@ -359,3 +359,35 @@ def synth_inputs(N, params=None, seed=1, noise=True, oracle=None):
         std = sig.mean(0, keepdims=True) / snr
         sig = sig + rng.standard_normal(sig.shape).astype(np.float32) * std
     return sig.astype(np.float32), y
+
+
+def fit_wls(signals, params=None, tau_min=0.016):
+    """loglinear.fit_wls (loglinear.py:68-105) restated in numpy float64: per voxel the weighted
+    least-squares line through (tau, ln S) for taus > 0.016 with weights 1/tau -- what
+    sklearn.LinearRegression.fit(X, Y, sample_weight=w) solves -- then R2' = -slope,
+    DBV = intercept - ln S(tau=0), OEF = R2'/(DBV gamma 4/3 pi dchi hct B0), clipped.
+    taus: np.around(np.arange(start, end, step, dtype=float32), 7) as :126-127.
+    Returns (oef, dbv, r2p), each [..., 1]."""
+    P = dict(DEFAULT_PARAMS if params is None else params)
+    taus = np.around(np.arange(float(P["tau_start"]), float(P["tau_end"]), float(P["tau_step"]),
+                               dtype=np.float32), decimals=7)
+    signals = np.asarray(signals)
+    with np.errstate(all="ignore"):
+        ln_s = np.log(signals.astype(np.float64))
+    ln_s[np.isnan(ln_s)] = 0
+    ln_s[np.isinf(ln_s)] = 0
+    line = np.where(taus > np.float32(tau_min))[0]
+    x = taus[line].astype(np.float64)
+    w = (1 / taus[line]).astype(np.float64)
+    y = ln_s[..., line]
+    xm = (w * x).sum() / w.sum()
+    ym = (w * y).sum(-1, keepdims=True) / w.sum()
+    slope = (w * (x - xm) * (y - ym)).sum(-1, keepdims=True) / (w * (x - xm) ** 2).sum()
+    icpt = ym - slope * xm
+    s0 = np.where(taus == 0)[0]
+    r2p = -slope
+    dbv = icpt - ln_s[..., s0]
+    with np.errstate(all="ignore"):
+        oef = r2p / (dbv * float(P["gamma"]) * (4 / 3) * np.pi * float(P["dchi"]) * float(P["hct"])
+                     * float(P["b0"]))
+    return np.clip(oef, 0.01, 0.8), np.clip(dbv, 0.002, 0.25), np.clip(r2p, 1e-2, 100)

@@ -239,7 +239,101 @@ __global__ void add_noise_kernel(float* __restrict__ s, int T, int64_t V,
     }
 }
 
+// loglinear.fit_wls (loglinear.py:68-105) in closed form.  slope = sum_t a[t] y[t], intercept =
+// sum_t b[t] y[t] with a, b fixed by the taus and weights (host, float64); sum a = 0 and sum b = 1,
+// so y is taken relative to ln S(tau=0) to keep the float32 sums small.  One lane per voxel, row
+// loads through LDS so HBM sees full lines: 4T + 12 bytes per voxel, HBM-bound.
+struct WlsCoef {
+    float a[QB_MAX_T], b[QB_MAX_T];
+    int T, s0;
+    float oef_den;  // gamma 4/3 pi dchi hct b0
+};
+
+__device__ __forceinline__ float clip_keep_nan(float x, float lo, float hi) {
+    return x < lo ? lo : (x > hi ? hi : x);  // np.clip: NaN stays NaN
+}
+
+__global__ __launch_bounds__(256) void wls_kernel(WlsCoef c, const float* __restrict__ sig,
+                                                  float* __restrict__ out, int64_t N) {
+    extern __shared__ float rows[];  // [256][T]
+    const int T = c.T;
+    const int64_t nblk = (N + 255) / 256;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t v0 = blk * 256;
+        const int n = (int)min((int64_t)256, N - v0);
+        for (int i = threadIdx.x; i < n * T; i += 256) rows[i] = sig[v0 * T + i];
+        __syncthreads();
+        if ((int)threadIdx.x < n) {
+            const float* r = rows + threadIdx.x * T;
+            auto lnS = [](float s) {
+                const float y = logf(s);
+                return (isnan(y) || isinf(y)) ? 0.0f : y;  // loglinear.py:70-71
+            };
+            const float y0 = lnS(r[c.s0]);
+            float slope = 0.0f, icpt = 0.0f;
+            for (int t = 0; t < T; ++t) {
+                if (c.a[t] == 0.0f && c.b[t] == 0.0f) continue;  // taus outside the fit
+                const float d = lnS(r[t]) - y0;
+                slope = fmaf(c.a[t], d, slope);
+                icpt = fmaf(c.b[t], d, icpt);
+            }
+            const float r2p = -slope;
+            const float dbv = icpt;  // c - ln S(0)
+            const float oef = r2p / (dbv * c.oef_den);
+            const int64_t v = v0 + threadIdx.x;
+            out[v * 3 + 0] = clip_keep_nan(oef, 0.01f, 0.8f);
+            out[v * 3 + 1] = clip_keep_nan(dbv, 0.002f, 0.25f);
+            out[v * 3 + 2] = clip_keep_nan(r2p, 1e-2f, 100.0f);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
+
+extern "C" int qbold_wls_fit(const qbold_ctx* ctx, const float* signals, double tau_min, float* out,
+                             int64_t N, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    if (N == 0) return QBOLD_OK;
+    QB_REQUIRE(N > 0 && signals && out, "qbold_wls_fit: bad argument");
+    const int T = ctx->dev.T;
+    WlsCoef c{};
+    c.T = T;
+    c.s0 = -1;
+    // np.around(np.arange(..., dtype=float32), decimals=7) (loglinear.py:126-127): float32 arithmetic
+    double x[QB_MAX_T], w[QB_MAX_T];
+    int used = 0;
+    double sw = 0, swx = 0;
+    const float tmin = (float)tau_min;  // float32 array > python float compares in float32
+    for (int t = 0; t < T; ++t) {
+        const float r = rintf(ctx->dev.taus[t] * 1e7f) / 1e7f;
+        x[t] = (double)r;
+        if (r == 0.0f && c.s0 < 0) c.s0 = t;
+        w[t] = 0.0;
+        if (r > tmin) {
+            w[t] = (double)(1.0f / r);  // w = 1 / taus in float32 (loglinear.py:79)
+            sw += w[t];
+            swx += w[t] * x[t];
+            ++used;
+        }
+    }
+    QB_REQUIRE(c.s0 >= 0, "qbold_wls_fit: no tau equals 0 (loglinear.py:92 needs the spin-echo image)");
+    QB_REQUIRE(used >= 2, "qbold_wls_fit: fewer than two taus above tau_min");
+    const double xm = swx / sw;
+    double sxx = 0;
+    for (int t = 0; t < T; ++t) sxx += w[t] * (x[t] - xm) * (x[t] - xm);
+    for (int t = 0; t < T; ++t) {
+        const double a = w[t] * (x[t] - xm) / sxx;  // d slope / d y[t]
+        c.a[t] = (float)a;
+        c.b[t] = (float)(w[t] / sw - xm * a);       // d intercept / d y[t]
+    }
+    const qbold_consts& k = ctx->consts;
+    c.oef_den = (float)(k.gamma * (4.0 / 3.0) * M_PI * k.dchi * k.hct * k.b0);
+    hipLaunchKernelGGL(wls_kernel, dim3(ew_grid(ctx, N, 256)), dim3(256), sizeof(float) * 256 * T,
+                       (hipStream_t)stream, c, signals, out, N);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
 
 extern "C" int qbold_normalise(const qbold_ctx* ctx, const float* x, float* out, int64_t N,
                                void* stream) {

@@ -335,6 +335,16 @@ def transform(self, op, x):
 
 
 @_ctx_method
+def wls_fit(self, signals, tau_min=0.016):
+    """loglinear.fit_wls per voxel: signals [N,T] -> [N,3] = (OEF, DBV, R2'), clipped."""
+    x = _f32(signals, "signals", self.T)
+    out = torch.empty((x.shape[0], 3), dtype=torch.float32, device=x.device)
+    _lib.check(self.lib.qbold_wls_fit(self.handle, _ptr(x), float(tau_min), _ptr(out), x.shape[0], _stream()),
+               "qbold_wls_fit")
+    return out
+
+
+@_ctx_method
 def nll_fwd(self, x, mask, pred, sigma, S=1):
     """Per-row NLL (before masking): x [N,T], pred/sigma [N*S,T] -> [N*S]."""
     x = _f32(x, "x", self.T)

@@ -204,3 +204,42 @@ def test_logit_mvn(trainer, oracle32):
     got = mvn.logit_gaussian_mvg_log_prob(dev(y), dev(p)).cpu().numpy()
     ref = oracle32.logit_mvn_nlogp(y, p)
     assert np.max(np.abs(got - ref) / (np.abs(ref) + 1.0)) < 1e-4
+
+
+def test_fit_wls_matches_loglinear_restatement(oracle32, params, tmp_path, monkeypatch):
+    """loglinear.fit_wls (loglinear.py:68-105) on image-shaped data, as its __main__ calls it."""
+    import os
+    from oracle.oracle import fit_wls as fit_wls_ref
+    from qbold_vi_amd import loglinear, nifti
+    rng = np.random.default_rng(8)
+    shape = (3, 12, 10, 8)
+    n = int(np.prod(shape))
+    y = np.stack([rng.uniform(0.1, 0.75, n), rng.uniform(0.005, 0.15, n)], -1)
+    sig = (oracle32.signal_fwd(y) * rng.uniform(100, 500, (n, 1)) * (1 + 0.02 * rng.normal(size=(n, 11)))).astype(np.float32)
+    sig[5, 8] = 0.0       # ln -> -inf -> 0 (loglinear.py:70-71)
+    sig[6, 6] = -3.0      # ln -> nan -> 0
+    sig[7] = 0.0          # whole voxel empty: 0/0 -> NaN survives np.clip
+    sig = sig.reshape(shape + (11,))
+    monkeypatch.chdir(os.path.join(os.path.dirname(__file__), ".."))   # fit_wls reads ./config like the reference
+    oef, dbv, r2p = loglinear.fit_wls(sig)
+    assert oef.shape == dbv.shape == r2p.shape == shape + (1,)
+    ro, rd, rr = fit_wls_ref(sig, params)
+    o, d, r = (t.cpu().numpy().astype(np.float64) for t in (oef, dbv, r2p))
+    np.testing.assert_allclose(r, rr, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(d, rd, rtol=1e-4, atol=2e-6)
+    assert np.isnan(o.reshape(-1)[7]) and np.isnan(ro.reshape(-1)[7])
+    ok = ~np.isnan(ro)
+    # OEF divides by DBV: compare where the fit is not within rounding of a clip edge or a pole
+    stable = ok & (np.abs(rd) > 4e-3)
+    np.testing.assert_allclose(o[stable], ro[stable], rtol=2e-3, atol=1e-5)
+    assert (np.abs(o[ok] - ro[ok]) > 1e-3).mean() < 0.01
+    assert 0.2 < (ro[ok] < 0.8).mean()                       # a real mix of clipped / unclipped voxels
+    loglinear.save_predictions([oef, dbv, r2p], str(tmp_path / "wls"))
+    im, _ = nifti.load(str(tmp_path / "wls_dbv.nii.gz"))
+    assert im.shape == (12, 10, 8, 3)
+    np.testing.assert_array_equal(im[..., 1], dbv[1, ..., 0].cpu().numpy())
+    # a tau grid without tau = 0 is an error, as the reference's empty s0_id index would be
+    from qbold_vi_amd.ops import Context
+    bad = Context(dict(params, tau_start="-0.015"), True, True)
+    with pytest.raises(RuntimeError, match="no tau equals 0"):
+        bad.wls_fit(torch.ones(4, bad.T, device="cuda"))

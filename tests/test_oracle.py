@@ -282,6 +282,45 @@ def test_spatial_encoder_matches_scipy_correlate(params):
     np.testing.assert_allclose(o.smoothness_loss(q, mask), (dx.sum() + dy.sum()) / mask.sum(), rtol=1e-10)
 
 
+def test_wls_restatement_matches_sklearn(oracle32, params):
+    """loglinear.fit_wls calls sklearn.linear_model.LinearRegression per voxel (loglinear.py:80-91);
+    sklearn is installed here, so the closed form in oracle.fit_wls is pinned to the reference's own
+    dependency on the reference's own call pattern."""
+    from sklearn.linear_model import LinearRegression
+    from oracle.oracle import fit_wls
+    rng = np.random.default_rng(3)
+    y = np.stack([rng.uniform(0.1, 0.7, 40), rng.uniform(0.01, 0.12, 40)], -1)
+    sig = oracle32.signal_fwd(y).astype(np.float64) * 300.0 * (1 + 0.01 * rng.normal(size=(40, 11)))
+    sig[3, 7] = 0.0        # ln -> -inf -> 0
+    sig[4, 9] = -1.0       # ln -> nan -> 0
+    taus = np.around(np.arange(-0.016, 0.065, 0.008, dtype=np.float32), decimals=7)
+    line = np.where(taus > 0.016)
+    assert list(line[0]) == [5, 6, 7, 8, 9, 10]
+    w = 1 / taus[line]
+    with np.errstate(all="ignore"):
+        ln_s = np.log(sig)
+    ln_s[np.isnan(ln_s)] = 0
+    ln_s[np.isinf(ln_s)] = 0
+    p = np.zeros((40, 2))
+    for v in range(40):
+        X = np.vstack((taus[line], np.ones_like(taus[line]))).T
+        wls = LinearRegression()
+        wls.fit(X, np.squeeze(ln_s[v, line]), sample_weight=w)
+        p[v] = [wls.coef_[0], wls.intercept_]
+    r2p = -p[:, 0:1]
+    dbv = p[:, 1:] - ln_s[:, np.where(taus == 0)[0]]
+    k = float(params["gamma"]) * (4 / 3) * np.pi * float(params["dchi"]) * float(params["hct"]) * float(params["b0"])
+    oef = r2p / (dbv * k)
+    o, d, r = fit_wls(sig.reshape(5, 2, 2, 2, 11), params)
+    np.testing.assert_allclose(r.reshape(-1, 1), np.clip(r2p, 1e-2, 100), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(d.reshape(-1, 1), np.clip(dbv, 0.002, 0.25), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(o.reshape(-1, 1), np.clip(oef, 0.01, 0.8), rtol=2e-3, atol=1e-6)
+    # and the estimator is meaningful: noiseless R2' = dw * dbv recovered to ~20 %
+    o2, d2, r2 = fit_wls(oracle32.signal_fwd(y), params)
+    dw = float(params["gamma"]) * 4 / 3 * np.pi * float(params["dchi"]) * float(params["hct"]) * float(params["b0"]) * y[:, 0]
+    assert np.median(np.abs(r2[:, 0] / (dw * y[:, 1]) - 1)) < 0.25
+
+
 def test_moments_and_elbo_composition(oracle64):
     rng = np.random.default_rng(4)
     n, S, K = 30, 3, 5
