@@ -112,6 +112,14 @@ int qbold_ctx_table_eval(const qbold_ctx* ctx, const float* host_x, float* host_
  * oef_dbv [V][2] -> signal [V][T]. */
 int qbold_signal_fwd(const qbold_ctx* ctx, const float* oef_dbv, float* signal, int64_t V,
                      void* stream);
+/* The same with the options configurations/optimal.yaml disables (signals.py:64-96).  hct [V]:
+ * per-voxel haematocrit (variable_hct, :64-70) or NULL for the config's value.  Misalignment
+ * (:80-96) with its random draws made by the caller: images t > from_index[v] are computed from
+ * alt_oef_dbv[v] (the perturbed, clipped pair); from_index[v] >= T-1 leaves voxel v aligned.  Both
+ * NULL: no misalignment. */
+int qbold_signal_fwd_ex(const qbold_ctx* ctx, const float* oef_dbv, const float* hct,
+                        const float* alt_oef_dbv, const int32_t* from_index, float* signal, int64_t V,
+                        void* stream);
 /* Vector-Jacobian product of the above: grad_signal [V][T] -> grad_oef_dbv [V][2]
  * (what tf.GradientTape yields through signals.py:55-114). */
 int qbold_signal_bwd(const qbold_ctx* ctx, const float* oef_dbv, const float* grad_signal,

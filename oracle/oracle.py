@@ -206,6 +206,20 @@ class Oracle:
                                C.c_int64(x.size // T))
         return out
 
+    def signal_fwd_ex(self, oef_dbv, hct=None, alt=None, from_idx=None):
+        """signals.py:64-96 options: per-voxel hct, misalignment (alt [V,2], from_idx [V] int32)."""
+        y = self._a(oef_dbv, (-1, 2))
+        V = y.shape[0]
+        h = None if hct is None else self._a(hct, (V,))
+        a = None if alt is None else self._a(alt, (V, 2))
+        f = None if from_idx is None else np.ascontiguousarray(from_idx, np.int32).reshape(V)
+        out = np.empty((V, self.T), self.dtype)
+        self.lib.qbo_signal_fwd_ex(C.byref(self.phys), self._p(y), self._p(h) if h is not None else None,
+                                   self._p(a) if a is not None else None,
+                                   f.ctypes.data_as(C.c_void_p) if f is not None else None,
+                                   self._p(out), C.c_int64(V))
+        return out
+
     def encoder_fwd(self, w, x):
         x = self._a(x)
         T = x.shape[-1]

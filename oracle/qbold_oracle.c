@@ -227,6 +227,7 @@ typedef struct {
     int T;
     real taus[QBO_MAX_T];
     real dw_coef;  /* (4/3) pi gamma b0 dchi hct                signals.py:144 */
+    real dw_coef_nohct; /* the same without hct (variable_hct, signals.py:64-70) */
     real e_te_r2t; /* exp(-te*r2t)                              signals.py:172 */
     real m_bld_nb; /* m_bld * nb                                signals.py:102-107 */
     real g0_c1;    /* (4/45) hct (1-hct)                        signals.py:239 */
@@ -241,6 +242,7 @@ typedef struct {
 static void make_consts(const qbo_phys *P, fwd_consts *c) {
     c->T = qbo_taus(P, c->taus);
     c->dw_coef = R((4.0 / 3.0) * M_PI * P->gamma * P->b0 * P->dchi * P->hct);
+    c->dw_coef_nohct = R((4.0 / 3.0) * M_PI * P->gamma * P->b0 * P->dchi);
     c->e_te_r2t = r_exp(R(-P->te * P->r2t));
     c->r2t_te = R(-P->r2t * P->te);
     /* m_bld: tf.math.exp of python floats -> float32 scalars          signals.py:105 */
@@ -265,15 +267,19 @@ static void make_consts(const qbo_phys *P, fwd_consts *c) {
     }
 }
 
-static inline void signal_one(const qbo_phys *P, const fwd_consts *c, real oef, real dbv,
-                              real *out) {
-    real dw = c->dw_coef * oef;
+/* hct < 0: the fixed haematocrit of the config (python float folded into the constants,
+ * signals.py:46,78); otherwise a per-voxel float32 tensor (variable_hct, signals.py:64-70), which
+ * changes where the float64 constants are rounded: ((K * hct) * oef), ((4/45 * hct) * (1 - hct)). */
+static inline void signal_one_h(const qbo_phys *P, const fwd_consts *c, real oef, real dbv, real hct,
+                                real *out) {
+    real dw = hct < 0 ? c->dw_coef * oef : (c->dw_coef_nohct * hct) * oef;
+    real g0_c1 = hct < 0 ? c->g0_c1 : (R(4.0 / 45.0) * hct) * (R(1) - hct);
     real bw;
     real g = 0;
     if (P->include_blood) {
         bw = c->m_bld_nb * dbv;
         real t = c->g0_c2 * oef;
-        real g0 = c->g0_c1 * (t * t);
+        real g0 = g0_c1 * (t * t);
         g = (c->half_g2 * g0) * c->td2;
     } else {
         bw = dbv; /* signals.py:110 */
@@ -296,6 +302,32 @@ static inline void signal_one(const qbo_phys *P, const fwd_consts *c, real oef, 
         real blood = 0;
         if (P->include_blood) blood = c->e_r2b_te * r_exp(-g * c->blood_B[t]);
         out[t] = tw * tissue + bw * blood;
+    }
+}
+
+static inline void signal_one(const qbo_phys *P, const fwd_consts *c, real oef, real dbv,
+                              real *out) {
+    signal_one_h(P, c, oef, dbv, R(-1), out);
+}
+
+/* signals.py:64-96: optional per-voxel haematocrit and the misalignment augmentation with its
+ * random draws made explicit: images t > from_idx[v] come from alt[v] = the perturbed (OEF, DBV)
+ * (the reference blends with a 0/1 mask, :95-96, which selects exactly). */
+void qbo_signal_fwd_ex(const qbo_phys *P, const real *oef_dbv, const real *hct, const real *alt,
+                       const int32_t *from_idx, real *signal, int64_t V) {
+    fwd_consts c;
+    make_consts(P, &c);
+    init_nodes();
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < V; ++v) {
+        real h = hct ? hct[v] : R(-1);
+        real *out = signal + v * c.T;
+        signal_one_h(P, &c, oef_dbv[2 * v], oef_dbv[2 * v + 1], h, out);
+        if (alt && from_idx && from_idx[v] < c.T - 1) {
+            real tmp[QBO_MAX_T];
+            signal_one_h(P, &c, alt[2 * v], alt[2 * v + 1], h, tmp);
+            for (int t = from_idx[v] < 0 ? 0 : from_idx[v] + 1; t < c.T; ++t) out[t] = tmp[t];
+        }
     }
 }
 

@@ -90,6 +90,11 @@ real qbo_tissue_dF(real x);
 /* SignalGenerationLayer.call without noise/misalignment -- signals.py:55-114,137-138. */
 void qbo_signal_fwd(const qbo_phys *P, const real *oef_dbv /*[V][2]*/, real *signal /*[V][T]*/,
                     int64_t V);
+/* The same with the options optimal.yaml disables (signals.py:64-96): hct [V] per-voxel haematocrit
+ * (variable_hct) or NULL; misalignment with explicit draws -- images t > from_idx[v] are computed
+ * from alt[v] ([V][2], the perturbed and clipped (OEF, DBV)); from_idx >= T-1 or NULL: aligned. */
+void qbo_signal_fwd_ex(const qbo_phys *P, const real *oef_dbv, const real *hct, const real *alt,
+                       const int32_t *from_idx, real *signal, int64_t V);
 /* d signal[v][t] / d (oef, dbv): jac [V][T][2]. */
 void qbo_signal_jac(const qbo_phys *P, const real *oef_dbv, real *jac, int64_t V);
 

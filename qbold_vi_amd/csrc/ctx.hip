@@ -114,6 +114,7 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
     if (const char* dbg = getenv("QBOLD_DEBUG_SKIP")) d.debug_skip = atoi(dbg);
 
     d.dw_coef = (float)((4.0 / 3.0) * M_PI * P->gamma * P->b0 * P->dchi * P->hct);
+    d.dw_coef_nohct = (float)((4.0 / 3.0) * M_PI * P->gamma * P->b0 * P->dchi);
     d.e_te_r2t = expf((float)(-P->te * P->r2t));
     d.r2t_te = (float)(-P->r2t * P->te);
     {

@@ -20,6 +20,7 @@ struct QbDev {
     int multi_norm, predict_log, use_student_t, tissue_mode;
     int debug_skip;  // diagnostics only (env QBOLD_DEBUG_SKIP): 1 = no encoder MFMA, 2 = no sampling
     float dw_coef;   // (4/3) pi gamma b0 dchi hct                      signals.py:144
+    float dw_coef_nohct;  // the same without hct (variable_hct)        signals.py:64-70
     float e_te_r2t;  // exp(-te*r2t)                                    signals.py:172
     float r2t_te;    // -r2t*te                                         signals.py:204
     float m_bld_nb;  // m_bld * nb                                      signals.py:102-107
@@ -344,6 +345,23 @@ __device__ __forceinline__ FwdVox fwd_vox(const QbDev& c, float oef, float dbv) 
         v.bw = c.m_bld_nb * dbv;
         float t = c.g0_c2 * oef;
         v.g = (c.half_g2 * (c.g0_c1 * (t * t))) * c.td2;
+    } else {
+        v.bw = dbv;
+        v.g = 0.0f;
+    }
+    v.tw = 1.0f - v.bw;
+    return v;
+}
+// variable_hct (signals.py:64-70): hct is a float32 tensor, so the float64 constants round before it
+// multiplies: ((K * hct) * oef) and ((4/45 * hct) * (1 - hct)).
+__device__ __forceinline__ FwdVox fwd_vox_hct(const QbDev& c, float oef, float dbv, float hct) {
+    FwdVox v;
+    v.dw = (c.dw_coef_nohct * hct) * oef;
+    v.dbv = dbv;
+    if (c.include_blood) {
+        v.bw = c.m_bld_nb * dbv;
+        float t = c.g0_c2 * oef;
+        v.g = (c.half_g2 * (((float)(4.0 / 45.0) * hct) * (1.0f - hct) * (t * t))) * c.td2;
     } else {
         v.bw = dbv;
         v.g = 0.0f;

@@ -15,11 +15,15 @@ namespace {
 
 constexpr int kBlock = 256;
 
-template <bool LITERAL>
+// EX: the options optimal.yaml disables (signals.py:64-96) -- per-voxel haematocrit and the
+// misalignment augmentation (images t > from_idx[v] come from alt[v]); any of the three may be null.
+template <bool LITERAL, bool EX>
 __global__ __launch_bounds__(kBlock) void signal_fwd_kernel(QbDev c, const float4* __restrict__ g_tab,
                                                             const float2* __restrict__ oef_dbv,
                                                             float* __restrict__ signal, int64_t V,
-                                                            int vec_ok) {
+                                                            int vec_ok, const float* __restrict__ hct,
+                                                            const float2* __restrict__ alt,
+                                                            const int* __restrict__ from_idx) {
     extern __shared__ __align__(16) unsigned char smem[];
     qb::FwdLds* L = reinterpret_cast<qb::FwdLds*>(smem);
     float* stage = reinterpret_cast<float*>(smem + sizeof(qb::FwdLds));  // [kBlock][T]
@@ -33,9 +37,18 @@ __global__ __launch_bounds__(kBlock) void signal_fwd_kernel(QbDev c, const float
         const int64_t v = v0 + threadIdx.x;
         if (v < V) {
             const float2 p = oef_dbv[v];
-            const qb::FwdVox fv = qb::fwd_vox(c, p.x, p.y);
-            for (int t = 0; t < T; ++t)
-                stage[threadIdx.x * T + t] = qb::fwd_signal<LITERAL>(L, c, fv, t);
+            if constexpr (!EX) {
+                const qb::FwdVox fv = qb::fwd_vox(c, p.x, p.y);
+                for (int t = 0; t < T; ++t)
+                    stage[threadIdx.x * T + t] = qb::fwd_signal<LITERAL>(L, c, fv, t);
+            } else {
+                const int split = (alt && from_idx) ? from_idx[v] : T;
+                const float2 p2 = split < T - 1 ? alt[v] : p;
+                const qb::FwdVox fa = hct ? qb::fwd_vox_hct(c, p.x, p.y, hct[v]) : qb::fwd_vox(c, p.x, p.y);
+                const qb::FwdVox fb = hct ? qb::fwd_vox_hct(c, p2.x, p2.y, hct[v]) : qb::fwd_vox(c, p2.x, p2.y);
+                for (int t = 0; t < T; ++t)
+                    stage[threadIdx.x * T + t] = qb::fwd_signal<LITERAL>(L, c, t > split ? fb : fa, t);
+            }
         }
         __syncthreads();
         // rows v0 .. v0+n-1 are contiguous in global memory: n*T floats from signal + v0*T
@@ -141,11 +154,37 @@ extern "C" int qbold_signal_fwd(const qbold_ctx* ctx, const float* oef_dbv, floa
     QB_REQUIRE(reinterpret_cast<uintptr_t>(oef_dbv) % 8 == 0, "qbold_signal_fwd: oef_dbv must be 8-byte aligned");
     const int vec_ok = reinterpret_cast<uintptr_t>(signal) % 16 == 0;
     if (ctx->dev.tissue_mode == QBOLD_TISSUE_LITERAL)
-        hipLaunchKernelGGL(signal_fwd_kernel<true>, dim3(grid_for(ctx, V, 8)), dim3(kBlock), smem, s,
-                           ctx->dev, ctx->d_tab, in, signal, V, vec_ok);
+        hipLaunchKernelGGL((signal_fwd_kernel<true, false>), dim3(grid_for(ctx, V, 8)), dim3(kBlock), smem, s,
+                           ctx->dev, ctx->d_tab, in, signal, V, vec_ok, nullptr, nullptr, nullptr);
     else
-        hipLaunchKernelGGL(signal_fwd_kernel<false>, dim3(grid_for(ctx, V, 8)), dim3(kBlock), smem, s,
-                           ctx->dev, ctx->d_tab, in, signal, V, vec_ok);
+        hipLaunchKernelGGL((signal_fwd_kernel<false, false>), dim3(grid_for(ctx, V, 8)), dim3(kBlock), smem, s,
+                           ctx->dev, ctx->d_tab, in, signal, V, vec_ok, nullptr, nullptr, nullptr);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
+extern "C" int qbold_signal_fwd_ex(const qbold_ctx* ctx, const float* oef_dbv, const float* hct,
+                                   const float* alt_oef_dbv, const int32_t* from_index, float* signal,
+                                   int64_t V, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    QB_REQUIRE(V >= 0, "qbold_signal_fwd_ex: negative V");
+    if (V == 0) return QBOLD_OK;
+    QB_REQUIRE(oef_dbv && signal, "qbold_signal_fwd_ex: null buffer");
+    QB_REQUIRE((alt_oef_dbv == nullptr) == (from_index == nullptr),
+               "qbold_signal_fwd_ex: alt_oef_dbv and from_index come together");
+    QB_REQUIRE(reinterpret_cast<uintptr_t>(oef_dbv) % 8 == 0 && reinterpret_cast<uintptr_t>(alt_oef_dbv) % 8 == 0,
+               "qbold_signal_fwd_ex: (OEF, DBV) buffers must be 8-byte aligned");
+    const size_t smem = sizeof(qb::FwdLds) + sizeof(float) * kBlock * ctx->dev.T;
+    hipStream_t s = (hipStream_t)stream;
+    const float2* in = reinterpret_cast<const float2*>(oef_dbv);
+    const float2* alt = reinterpret_cast<const float2*>(alt_oef_dbv);
+    const int vec_ok = reinterpret_cast<uintptr_t>(signal) % 16 == 0;
+    if (ctx->dev.tissue_mode == QBOLD_TISSUE_LITERAL)
+        hipLaunchKernelGGL((signal_fwd_kernel<true, true>), dim3(grid_for(ctx, V, 8)), dim3(kBlock), smem, s,
+                           ctx->dev, ctx->d_tab, in, signal, V, vec_ok, hct, alt, from_index);
+    else
+        hipLaunchKernelGGL((signal_fwd_kernel<false, true>), dim3(grid_for(ctx, V, 8)), dim3(kBlock), smem, s,
+                           ctx->dev, ctx->d_tab, in, signal, V, vec_ok, hct, alt, from_index);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }

@@ -181,6 +181,27 @@ class Context:
                    "qbold_signal_fwd")
         return out
 
+    def signal_fwd_ex(self, oef_dbv, hct=None, alt=None, from_index=None):
+        """signals.py:64-96 options: per-voxel hct [V], misalignment (alt [V,2], from_index [V] int32)."""
+        x = _f32(oef_dbv, "oef_dbv", 2)
+        V = x.numel() // 2
+        h = a = f = None
+        if hct is not None:
+            h = _f32(hct, "hct")
+            if h.numel() != V:
+                raise ValueError("hct must hold one value per (OEF, DBV) pair")
+        if (alt is None) != (from_index is None):
+            raise ValueError("alt and from_index come together")
+        if alt is not None:
+            a = _f32(alt, "alt", 2)
+            f = from_index.to(device=x.device, dtype=torch.int32).contiguous()
+            if a.numel() != 2 * V or f.numel() != V:
+                raise ValueError("alt [V,2] and from_index [V] must match oef_dbv")
+        out = torch.empty(x.shape[:-1] + (self.T,), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.qbold_signal_fwd_ex(self.handle, _ptr(x), _ptr(h), _ptr(a), _ptr(f), _ptr(out), V,
+                                                _stream()), "qbold_signal_fwd_ex")
+        return out
+
     def signal_bwd(self, oef_dbv, grad_signal):
         x = _f32(oef_dbv, "oef_dbv", 2)
         g = _f32(grad_signal, "grad_signal", self.T)

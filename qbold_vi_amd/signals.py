@@ -46,13 +46,8 @@ class SignalGenerationLayer:
         self._simulate_noise = p['simulate_noise'] == 'True'
         self._weighted_noise = p['tau_weighted'] == 'True'
         self._snr = int(p['snr'])
-        if variable_hct:
-            raise NotImplementedError("variable_hct (signals.py:64-70) is disabled in optimal.yaml and "
-                                      "not part of the accelerated path")
-        if misaligned_prob > 0.0:
-            raise NotImplementedError("misaligned_prob > 0 (signals.py:80-96) is disabled in "
-                                      "optimal.yaml and not part of the accelerated path")
-        self.hct = float(p['hct'])
+        if not variable_hct:  # signals.py:45-46
+            self.hct = float(p['hct'])
         # full_model / include_blood arrive as the strings 'True' / 'False' from the reference's
         # __main__ (signals.py:330); any non-empty string is truthy there as well
         self._full_model = bool(full_model)
@@ -71,10 +66,35 @@ class SignalGenerationLayer:
     def __call__(self, input, *args, **kwargs):
         return self.call(input, *args, **kwargs)
 
+    def _misalignment(self, y):
+        """The random draws of signals.py:80-93 (torch generator on the device; every call fresh):
+        -> (alt [V,2], from_index [V] int32 with T for the aligned voxels)."""
+        T, V = self._ctx.T, y.shape[0]
+        g = torch.Generator(device=y.device)
+        g.manual_seed(self._seed + 104723 * (self._calls + 1))
+        misaligned = torch.rand(V, generator=g, device=y.device) < self._misaligned_prob
+        from_index = torch.randint(4, T - 1, (V,), generator=g, device=y.device, dtype=torch.int32)
+        from_index = torch.where(misaligned, from_index, torch.full_like(from_index, T))
+        noise = torch.randn(V, 2, generator=g, device=y.device)
+        alt = torch.stack([torch.clamp(noise[:, 0] * 0.15 + y[:, 0], 0.05, 0.8),
+                           torch.clamp(noise[:, 1] * 0.05 + y[:, 1], 0.002, 0.3)], -1)
+        return alt, from_index
+
     def call(self, input, *args, **kwargs):
-        if input.shape[-1] != 2:
+        if self._variable_hct:
+            if input.shape[-1] != 3:
+                raise AssertionError('Input should have 3 elements in last dimension, OEF, DBV and hct')
+        elif input.shape[-1] != 2:
             raise AssertionError('Input should have 2 elements in last dimension, OEF and DBV')
-        signal = self._ctx.signal_fwd(input)
+        if self._variable_hct or self._misaligned_prob > 0.0:
+            flat = input.reshape(-1, input.shape[-1])
+            y = flat[:, :2].contiguous()
+            hct = flat[:, 2].contiguous() if self._variable_hct else None
+            alt, from_index = self._misalignment(y) if self._misaligned_prob > 0.0 else (None, None)
+            signal = self._ctx.signal_fwd_ex(y, hct, alt, from_index).reshape(
+                tuple(input.shape[:-1]) + (self._ctx.T,))
+        else:
+            signal = self._ctx.signal_fwd(input)
         if self._simulate_noise:
             flat = signal.reshape(-1, signal.shape[-1])
             # every call draws fresh noise, as tf.random does (signals.py:124,128)
@@ -85,6 +105,9 @@ class SignalGenerationLayer:
 
     def gradient(self, input, grad_output):
         """Vector-Jacobian product of call() (noise-free part), what tf.GradientTape returns."""
+        if self._variable_hct or self._misaligned_prob > 0.0:
+            raise NotImplementedError("gradients through variable_hct / misalignment: these options only "
+                                      "occur in synthetic-data generation (signals.py:251-300)")
         return self._ctx.signal_bwd(input, grad_output)
 
     @staticmethod
@@ -130,11 +153,14 @@ def create_synthetic_dataset(params, full_model, use_blood, misaligned_prob, var
     xx, yy = torch.meshgrid(torch.as_tensor(oefs, dtype=torch.float32, device=dev),
                             torch.as_tensor(dbvs, dtype=torch.float32, device=dev), indexing='ij')
     train_y = torch.stack([xx.reshape(-1), yy.reshape(-1)], dim=1)
+    if variable_hct:  # tf.random.uniform(minval=0.34, maxval=0.34): a constant column (signals.py:273-276)
+        train_y = torch.cat([train_y, torch.full_like(train_y[:, :1], 0.34)], dim=-1)
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     train_y = train_y[torch.randperm(train_y.shape[0], generator=g, device=dev)]  # tf.random.shuffle
     chunk = train_y.shape[0] // 10  # "break into chunks" -- the noise std uses per-chunk means
     train_x = torch.cat([sig_layer(train_y[i * chunk:(i + 1) * chunk].contiguous()) for i in range(10)])
     train_y = train_y[:train_x.shape[0]]
-    r2p = sig_layer.calculate_r2p(train_y[:, 0], train_y[:, 1], sig_layer.hct)
-    return train_x, torch.cat([train_y, r2p[:, None]], dim=-1)
+    hct = train_y[:, 2] if variable_hct else sig_layer.hct
+    r2p = sig_layer.calculate_r2p(train_y[:, 0], train_y[:, 1], hct)
+    return train_x, torch.cat([train_y[:, :2], r2p[:, None]], dim=-1)

@@ -98,6 +98,49 @@ def test_signal_loglinear_and_no_blood(params, oracle32):
         assert rel(c.signal_fwd(dev(y)).cpu().numpy(), o.signal_fwd(y)) < 1e-5
 
 
+def test_signal_variable_hct_and_misalignment(params, oracle32):
+    """The two options of SignalGenerationLayer that optimal.yaml switches off (signals.py:64-96)."""
+    from oracle.oracle import Oracle
+    from qbold_vi_amd.ops import Context
+    from qbold_vi_amd.signals import SignalGenerationLayer
+    rng = np.random.default_rng(12)
+    V = 5000
+    y = grid_oef_dbv(V, seed=4)
+    hct = rng.uniform(0.25, 0.5, V).astype(np.float32)
+    alt = np.stack([np.clip(y[:, 0] + 0.15 * rng.standard_normal(V), 0.05, 0.8),
+                    np.clip(y[:, 1] + 0.05 * rng.standard_normal(V), 0.002, 0.3)], -1).astype(np.float32)
+    idx = np.where(rng.uniform(size=V) < 0.4, rng.integers(4, 10, V), 11).astype(np.int32)
+    for full, blood in ((True, True), (False, True), (True, False)):
+        c = Context(params, full_model=full, include_blood=blood)
+        o = Oracle("f32", params, full_model=full, include_blood=blood)
+        for kw in (dict(hct=hct), dict(alt=alt, from_idx=idx), dict(hct=hct, alt=alt, from_idx=idx)):
+            want = o.signal_fwd_ex(y, **kw)
+            got = c.signal_fwd_ex(dev(y), None if "hct" not in kw else dev(hct),
+                                  None if "alt" not in kw else dev(alt),
+                                  None if "alt" not in kw else dev(idx)).cpu().numpy()
+            assert rel(got, want) < 1e-5, (full, blood, list(kw))
+    # the config's haematocrit as a tensor reproduces the plain model to rounding of the constants
+    o = oracle32
+    same = o.signal_fwd_ex(y, hct=np.full(V, float(params["hct"]), np.float32))
+    assert rel(same, o.signal_fwd(y)) < 1e-6
+    # misaligned images are exactly the images of the perturbed parameters, the others untouched
+    mis = o.signal_fwd_ex(y, alt=alt, from_idx=idx)
+    plain, other = o.signal_fwd(y), o.signal_fwd(alt)
+    t = np.arange(11)[None, :]
+    np.testing.assert_array_equal(mis, np.where(t > idx[:, None], other, plain))
+    # the layer draws the augmentation itself: ~prob of the voxels change, only in images 5..10
+    layer = SignalGenerationLayer(dict(params, simulate_noise='False'), True, True, misaligned_prob=0.3)
+    out = layer(dev(y)).cpu().numpy()
+    changed = out != Context(params, True, True).signal_fwd(dev(y)).cpu().numpy()
+    assert not changed[:, :5].any()
+    assert 0.22 < changed.any(-1).mean() < 0.36
+    with pytest.raises(AssertionError):
+        SignalGenerationLayer(dict(params, simulate_noise='False'), True, True, variable_hct=True)(dev(y))
+    vh = SignalGenerationLayer(dict(params, simulate_noise='False'), True, True, variable_hct=True)
+    got = vh(dev(np.concatenate([y, hct[:, None]], -1))).cpu().numpy()
+    assert rel(got, o.signal_fwd_ex(y, hct=hct)) < 1e-5
+
+
 def test_signal_bwd_matches_oracle_jacobian(ctx, oracle32):
     y = grid_oef_dbv(4096, seed=3)
     rng = np.random.default_rng(5)
