@@ -335,6 +335,57 @@ def test_vi_fwd_sharding_invariance(ctx, weights, oracle32):
     assert torch.allclose(a + b, full, rtol=1e-12)
 
 
+def test_full_size_properties_one_million_voxels(ctx, weights, oracle32, params):
+    """BASELINE config 2 at its full size (1,048,576 voxels x 11 tau, S=32, K=70), through the
+    properties that do not need the oracle on every voxel: determinism, shard additivity, masking,
+    the sums as a checksum of the per-voxel outputs -- and the oracle on a window in the middle."""
+    from qbold_vi_amd.signals import SignalGenerationLayer
+    w, ew = weights
+    N, S, K, seed = 1 << 20, 32, 70, 11
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    y = torch.stack([torch.rand(N, generator=g, device="cuda") * 0.7 + 0.08,
+                     torch.rand(N, generator=g, device="cuda") * 0.1 + 0.005], -1)
+    x = SignalGenerationLayer(dict(params, simulate_noise='True'), True, True)(y)
+    prior = ctx.encoder_fwd(ew, x, want=("out1",))[0]
+    mask = (torch.rand(N, generator=g, device="cuda") > 0.25).float()
+    sums, q, nk = ctx.vi_fwd(ew, x, mask, prior, S, K, seed=seed)
+    sums2, q2, nk2 = ctx.vi_fwd(ew, x, mask, prior, S, K, seed=seed)
+    assert torch.equal(sums, sums2) and torch.equal(nk, nk2) and torch.equal(q, q2)   # bitwise repeatable
+    assert bool(torch.isfinite(nk).all()) and bool(torch.isfinite(sums).all())
+    # sums are the masked checksum of the per-voxel outputs
+    nkd, md = nk.double(), mask.double()
+    assert abs(float((nkd[:, 0] * md).sum()) / float(sums[0]) - 1) < 1e-9
+    assert abs(float(nkd[:, 1][mask > 0].sum()) / float(sums[1]) - 1) < 1e-9
+    assert float(sums[2]) == float(md.sum())
+    # four shards keyed by their first global voxel == the whole batch
+    parts, acc = [], torch.zeros_like(sums)
+    for r in range(4):
+        sl = slice(r * (N // 4), (r + 1) * (N // 4))
+        s_r, _, nk_r = ctx.vi_fwd(ew, x[sl], mask[sl], prior[sl], S, K, seed=seed, voxel0=sl.start)
+        parts.append(nk_r)
+        acc += s_r
+    assert torch.equal(torch.cat(parts), nk)
+    assert torch.allclose(acc, sums, rtol=1e-9, atol=0)   # reduction order differs across shards
+    # an all-zero mask contributes nothing; no mask == mask of ones
+    z, _, _ = ctx.vi_fwd(ew, x[:4096], torch.zeros(4096, device="cuda"), prior[:4096], S, K, seed=seed)
+    assert z.tolist() == [0.0, 0.0, 0.0]
+    a, _, _ = ctx.vi_fwd(ew, x[:4096], None, prior[:4096], S, K, seed=seed)
+    b, _, _ = ctx.vi_fwd(ew, x[:4096], torch.ones(4096, device="cuda"), prior[:4096], S, K, seed=seed)
+    assert torch.equal(a, b)
+    # the oracle on a 2048-voxel window keyed by its global position
+    v0, n = 777_000, 2048
+    xs, ms, ps = (t[v0:v0 + n].cpu().numpy() for t in (x, mask, prior))
+    _, q_want, sigma = oracle32.encoder_fwd(w, xs)
+    want = oracle32.elbo(xs, ms, q_want, ps, sigma, oracle32.philox_normals(seed, 0, v0, n, S),
+                         oracle32.philox_normals(seed, 1, v0, n, K))
+    got = nk[v0:v0 + n].cpu().numpy()
+    assert rel(got[:, 0], want["nll_v"], 1.0) < 5e-4
+    assert np.max(np.abs(got[:, 1] - want["kl_v"]) / (np.abs(want["kl_v"]) + 1.0)) < 5e-4
+    elbo = (float((got[:, 0].astype(np.float64) * ms).sum()) + float(got[:, 1].astype(np.float64)[ms > 0].sum())) / ms.sum()
+    assert abs(elbo - want["elbo"]) / abs(want["elbo"]) < 1e-4
+
+
 def test_24_tau_protocol(params):
     """The reference's second acquisition protocol (24 taus from -0.028 s in 4 ms steps,
     signals.py:120-121): forward model, encoder, fused ELBO and head gradients."""
