@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--tissue", choices=["table", "literal"], default="table")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3],
                     help="BASELINE.json config: 2 = 11 tau / width 60 (headline), 3 = 64 tau / width 256")
+    ap.add_argument("--encoder_precision", choices=["f32", "bf16"], default="f32",
+                    help="f32 (headline): float32-grade split-f16 MFMA; bf16: BASELINE config 5's "
+                         "'bf16 forward / fp32 ELBO accum' (encoder products on bf16 operands)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_budget_s", type=float, default=15.0)
     args = ap.parse_args()
@@ -158,7 +161,9 @@ def main():
     ctx.set_tissue_mode(args.tissue)
     w = init_encoder_weights(T=T, U=U, L=L, channelwise_gating=True, resid_init_std=0.05,
                              im_loss_sigma=0.05, seed=1)
-    ew = EncoderWeights(ctx, T, U, L, True, -3.0).set_from_arrays(w)
+    if args.encoder_precision == "bf16" and args.config != 2:
+        raise SystemExit("--encoder_precision bf16 applies to the fused kernel (config 2)")
+    ew = EncoderWeights(ctx, T, U, L, True, -3.0, precision=args.encoder_precision).set_from_arrays(w)
     mask = torch.ones(n, device=device)
     prior, _, _ = ctx.encoder_fwd(ew, x, want=("out1",))  # prior = stream-1 output (train.py:26-31)
     out = (torch.empty(3, dtype=torch.float64, device=device),
@@ -216,10 +221,13 @@ def main():
             "metric": "voxel-ELBO evals/sec", "value": value, "unit": "voxel-ELBO evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.encoder_precision == "f32" else "bf16 encoder products / f32 accumulate, sampling and ELBO",
+            "data": "synthetic",
             "config": {"workload": f"{n} synthetic voxels/GPU x {T} tau, S={S} likelihood draws, "
                                    f"K={K} KL draws, optimal.yaml encoder (U={U}, L={L}), fused "
-                                   f"qbold_vi_fwd, tissue integral: {args.tissue}",
+                                   f"qbold_vi_fwd, tissue integral: {args.tissue}, encoder arithmetic: "
+                                   f"{args.encoder_precision}",
                        "global_voxels": total_vox, "parallelism": f"voxel-shard x{world}",
                        "collective": "all_reduce(3 x f64)/step" if world > 1 else "none"},
             "neg_elbo": neg_elbo,

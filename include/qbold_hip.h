@@ -63,6 +63,13 @@ typedef enum {
     QBOLD_TISSUE_LITERAL = 1  /* the 129-node Simpson sum with Cephes j0f, per (voxel, tau) */
 } qbold_tissue_mode;
 
+/* Arithmetic of the fused voxel-wise encoder kernels (qbold_encoder_fwd, qbold_vi_fwd). */
+typedef enum {
+    QBOLD_ENC_F32 = 0,  /* float32-grade: operands split into two f16 halves, three MFMAs per tile */
+    QBOLD_ENC_BF16 = 1  /* operands rounded to bfloat16, float32 accumulate (BASELINE config 5:
+                           "bf16 forward / fp32 ELBO accum"); sampling and ELBO stay float32 */
+} qbold_encoder_precision;
+
 /* Voxel-wise encoder geometry (model.py:122-223; 3x3x1 convolutions act through their centre
  * tap on (N,1,1,1,T) voxel batches). */
 typedef struct {
@@ -73,6 +80,8 @@ typedef struct {
     float gate_offset;          /* model.py:169 */
     int32_t spatial_taps;       /* 1: Wr1/Wr2 hold the centre tap [U][U] only (voxel batches);
                                    9: full 3x3x1 kernels [3][3][U][U] in Keras order (model.py:152-157) */
+    int32_t precision;          /* qbold_encoder_precision; the packed image (qbold_encoder_pack) and the
+                                   kernels that read it must be given the same value */
 } qbold_encoder_shape;
 
 /* Image-crop geometry of a [B][X][Y][Z][C] batch (train.py:17-72): voxel v = ((b X + x) Y + y) Z + z.

@@ -152,6 +152,10 @@ class Oracle:
     def _p(self, a):
         return a.ctypes.data_as(self.preal)
 
+    def set_encoder_bf16(self, on):
+        """Process-global test hook: bf16-rounded operands in the voxel-wise encoder's products."""
+        self.lib.qbo_set_encoder_bf16(int(bool(on)))
+
     def set_threads(self, n):
         self.lib.qbo_set_threads(int(n))
 

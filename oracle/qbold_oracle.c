@@ -416,11 +416,28 @@ static inline real sigmoidr(real v) { return R(1) / (R(1) + r_exp(-v)); }
 #define MIN_DBV R(0.001)
 
 /* y[o] = act(sum_i x[i] W[i][o] + b[o]) ; W is [nin][nout] (Keras kernel orientation). */
+/* Test hook for the reduced-precision encoder mode (BASELINE config 5, "bf16 forward / fp32 ELBO
+ * accum"): both operands of every dense product are rounded to bfloat16 (round-to-nearest-even),
+ * products and sums stay in `real`; biases, activations functions and heads stay in `real`. */
+static int g_encoder_bf16 = 0;
+void qbo_set_encoder_bf16(int on) { g_encoder_bf16 = on; }
+static inline real bf16_round(real v) {
+    if (!g_encoder_bf16) return v;
+    float f = (float)v;
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return v; /* inf / nan */
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&f, &u, 4);
+    return (real)f;
+}
+
 static void dense(const real *x, const real *W, const real *b, real *y, int nin, int nout,
                   int relu) {
     for (int o = 0; o < nout; ++o) {
         real acc = 0;
-        for (int i = 0; i < nin; ++i) acc += x[i] * W[(int64_t)i * nout + o];
+        for (int i = 0; i < nin; ++i) acc += bf16_round(x[i]) * bf16_round(W[(int64_t)i * nout + o]);
         acc += b[o];
         y[o] = relu ? (acc > 0 ? acc : 0) : acc;
     }

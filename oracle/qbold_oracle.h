@@ -73,6 +73,9 @@ void qbo_set_threads(int n);
 /* float64 test hook: evaluate F(x) with Simpson node 0 removed (float32 reference semantics). */
 void qbo_set_node0_zero(int on);
 
+/* test hook: round both operands of every encoder dense product to bfloat16 (voxel-wise encoder). */
+void qbo_set_encoder_bf16(int on);
+
 /* tf.math.special.bessel_j0 for float32 = Eigen generic_j0<float> = Cephes j0f. */
 real qbo_j0(real x);
 real qbo_j1(real x);

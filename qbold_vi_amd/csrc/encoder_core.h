@@ -91,17 +91,35 @@ __device__ __forceinline__ f32x4 load4(const float* __restrict__ p) {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define QB_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define QB_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 #define QB_LO_SCALE 2048.0f
 #define QB_LO_UNSCALE (1.0f / 2048.0f)
 
+// Reduced-precision mode (qbold_encoder_shape.precision = QBOLD_ENC_BF16; BASELINE config 5, "bf16
+// forward / fp32 ELBO accum"): BF = true everywhere below means ONE v_mfma_f32_16x16x32_bf16 per
+// tile on bfloat16-rounded operands (round-to-nearest-even) with float32 accumulation, instead of
+// the three split-f16 MFMAs.  The `hi` slots of the weight image then hold bf16 bit patterns and the
+// `lo` slots are unused; fragments travel as f16x8 (16 raw bytes) and are reinterpreted at the MFMA.
+__device__ __forceinline__ bf16x8 as_bf16(const f16x8& v) { return __builtin_bit_cast(bf16x8, v); }
+
 // hi / lo halves of eight float32 values as the B fragment of one K = 32 step.
+template <bool BF = false>
 __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
+    if constexpr (BF) {
+        bf16x8 b;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const _Float16 h = (_Float16)v[j];
-        hi[j] = h;
-        lo[j] = (_Float16)((v[j] - (float)h) * QB_LO_SCALE);
+        for (int j = 0; j < 8; ++j) b[j] = (__bf16)v[j];
+        hi = __builtin_bit_cast(f16x8, b);
+        lo = hi;  // unused
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const _Float16 h = (_Float16)v[j];
+            hi[j] = h;
+            lo[j] = (_Float16)((v[j] - (float)h) * QB_LO_SCALE);
+        }
     }
 }
 
@@ -109,13 +127,14 @@ __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo
 struct ActFrag {
     f16x8 hi[2], lo[2];
 };
+template <bool BF = false>
 __device__ __forceinline__ ActFrag split_act(const f32x4 (&in)[4]) {
     ActFrag f;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const float v[8] = {in[2 * s][0], in[2 * s][1], in[2 * s][2], in[2 * s][3],
                             in[2 * s + 1][0], in[2 * s + 1][1], in[2 * s + 1][2], in[2 * s + 1][3]};
-        split8(v, f.hi[s], f.lo[s]);
+        split8<BF>(v, f.hi[s], f.lo[s]);
     }
     return f;
 }
@@ -127,7 +146,7 @@ __device__ __forceinline__ f16x8 lds_frag(const float* __restrict__ A, int idx, 
 }
 
 // out[0..MT-1] = W in + bias over KS k-steps of 32.  A: LDS image [s][m][part][lane][8], bias: f32.
-template <int MT, int KS>
+template <int MT, int KS, bool BF = false>
 __device__ __forceinline__ void dense_f16x3(const float* __restrict__ A,
                                             const float* __restrict__ bias, const f16x8 (&bhi)[KS],
                                             const f16x8 (&blo)[KS], f32x4 (&out)[MT], int lane) {
@@ -140,6 +159,21 @@ __device__ __forceinline__ void dense_f16x3(const float* __restrict__ A,
     }
     // Fragments are fetched one (k-step, tile) ahead of the MFMAs that consume them; the
     // sched_barrier keeps the scheduler from hoisting all 2*KS*MT reads to the top (64 VGPRs).
+    if constexpr (BF) {
+        f16x8 whi = lds_frag(A, 0, lane);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int nxt = s * MT + m + 1;
+                f16x8 nhi = whi;
+                if (nxt < KS * MT) nhi = lds_frag(A, nxt * 2, lane);
+                out[m] = QB_MFMA_BF16(as_bf16(whi), as_bf16(bhi[s]), out[m]);
+                whi = nhi;
+            }
+        }
+        return;
+    }
     f16x8 whi = lds_frag(A, 0, lane), wlo = lds_frag(A, 1, lane);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -167,19 +201,20 @@ __device__ __forceinline__ void dense_f16x3(const float* __restrict__ A,
 }
 
 // 64 -> 64 layer on an activation tensor
+template <bool BF = false>
 __device__ __forceinline__ void dense64(const float* __restrict__ A, const float* __restrict__ bias,
                                         const f32x4 (&in)[4], f32x4 (&out)[4], int lane) {
-    const ActFrag f = split_act(in);
-    dense_f16x3<4, 2>(A, bias, f.hi, f.lo, out, lane);
+    const ActFrag f = split_act<BF>(in);
+    dense_f16x3<4, 2, BF>(A, bias, f.hi, f.lo, out, lane);
 }
 
 // heads: HT (1 or 2) 16-row output tiles from a 64-unit input.
-template <int HT>
+template <int HT, bool BF = false>
 __device__ __forceinline__ void dense_head(const float* __restrict__ A,
                                            const float* __restrict__ bias, const f32x4 (&in)[4],
                                            f32x4 (&out)[HT], int lane) {
-    const ActFrag f = split_act(in);
-    dense_f16x3<HT, 2>(A, bias, f.hi, f.lo, out, lane);
+    const ActFrag f = split_act<BF>(in);
+    dense_f16x3<HT, 2, BF>(A, bias, f.hi, f.lo, out, lane);
 }
 
 // normalise_data -- model.py:97-113; n[t] for this lane's voxel.
@@ -203,7 +238,7 @@ __device__ __forceinline__ void normalise(const QbDev& c, const float (&x)[T], f
 }
 
 // First layer: T -> 64 with relu.  One K = 32 step; k-slot 8 group + j carries n[8 group + j].
-template <int T>
+template <int T, bool BF = false>
 __device__ __forceinline__ void dense_first(const float* __restrict__ A,
                                             const float* __restrict__ bias, const float (&n)[T],
                                             f32x4 (&out)[4], int lane) {
@@ -219,27 +254,28 @@ __device__ __forceinline__ void dense_first(const float* __restrict__ A,
         v[j] = x;
     }
     f16x8 hi[1], lo[1];
-    split8(v, hi[0], lo[0]);
-    dense_f16x3<4, 1>(A, bias, hi, lo, out, lane);
+    split8<BF>(v, hi[0], lo[0]);
+    dense_f16x3<4, 1, BF>(A, bias, hi, lo, out, lane);
 #pragma unroll
     for (int m = 0; m < 4; ++m) out[m] = relu4(out[m]);
 }
 
 // One create_block step of stream 2 (gated residual), in place -- model.py:147-172.
+template <bool BF = false>
 __device__ __forceinline__ void block_stream2(const float* __restrict__ W, f32x4 (&b)[4],
                                               int lane) {
     f32x4 skip[4], t[4], r[4];
-    dense64(W + BLK_WC_A, W + BLK_WC_B, b, skip, lane);  // shared 1x1x1 conv as skip, :148
+    dense64<BF>(W + BLK_WC_A, W + BLK_WC_B, b, skip, lane);  // shared 1x1x1 conv as skip, :148
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         skip[m] = relu4(skip[m]);
         b[m] = relu4(b[m]);  // Activation before the first 3x3x1 conv, :151
     }
-    dense64(W + BLK_R1_A, W + BLK_R1_B, b, t, lane);  // :152
+    dense64<BF>(W + BLK_R1_A, W + BLK_R1_B, b, t, lane);  // :152
 #pragma unroll
     for (int m = 0; m < 4; ++m) t[m] = relu4(t[m]);   // :155
-    dense64(W + BLK_R2_A, W + BLK_R2_B, t, r, lane);  // :156
-    dense64(W + BLK_G_A, W + BLK_G_B, r, t, lane);    // gating logits (+ gate_offset in bias), :164
+    dense64<BF>(W + BLK_R2_A, W + BLK_R2_B, t, r, lane);  // :156
+    dense64<BF>(W + BLK_G_A, W + BLK_G_B, r, t, lane);    // gating logits (+ gate_offset in bias), :164
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -251,10 +287,11 @@ __device__ __forceinline__ void block_stream2(const float* __restrict__ W, f32x4
 }
 
 // One create_block step of stream 1 -- model.py:144-145.
+template <bool BF = false>
 __device__ __forceinline__ void block_stream1(const float* __restrict__ W, f32x4 (&a)[4],
                                               int lane) {
     f32x4 o[4];
-    dense64(W + BLK_WC_A, W + BLK_WC_B, a, o, lane);
+    dense64<BF>(W + BLK_WC_A, W + BLK_WC_B, a, o, lane);
 #pragma unroll
     for (int m = 0; m < 4; ++m) a[m] = relu4(o[m]);
 }

@@ -23,14 +23,19 @@ __device__ __forceinline__ float wval(const float* W, int nin, int nout, int in,
 }
 
 // One element of a dense op's f16 image: fragment (s, m_out, part), lane, j.
-__device__ __forceinline__ _Float16 split_part(float w, int part) {
+// bf16 mode: the hi slot carries the bfloat16 bit pattern of w, the lo slot is unused.
+__device__ __forceinline__ _Float16 split_part(float w, int part, bool bf) {
+    if (bf) {
+        const __bf16 b = (__bf16)w;
+        return part == 0 ? __builtin_bit_cast(_Float16, b) : (_Float16)0.0f;
+    }
     const _Float16 hi = (_Float16)w;
     return part == 0 ? hi : (_Float16)((w - (float)hi) * QB_LO_SCALE);
 }
 __device__ __forceinline__ int frag_unit(int s, int g, int j) { return 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3); }
 
 // packed image, addressed in HALVES for the A pieces (2 per float slot) and floats for biases
-__global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset,
+__global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset, bool bf,
                             const float* __restrict__ w, float* __restrict__ packed) {
     const int U = c.U, T = c.T, G = c.G;
     _Float16* ph = reinterpret_cast<_Float16*>(packed);
@@ -39,7 +44,7 @@ __global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset,
         if (pf < e.first_b) {   // first-layer A: [m][part][lane][j], k-slot 8g + j = input 8g + j
             const int j = p & 7, lane = (p >> 3) & 63, part = (p >> 9) & 1, m = p >> 10;
             const int in = 8 * (lane >> 4) + j;
-            ph[p] = split_part(wval(w + c.W0, T, U, in, 16 * m + (lane & 15)), part);
+            ph[p] = split_part(wval(w + c.W0, T, U, in, 16 * m + (lane & 15)), part, bf);
         } else if (pf < e.blk0) {  // first-layer bias [m][g][r] (float: written by the even half)
             if (p & 1) continue;
             const int q = pf - e.first_b, r = q & 3, g = (q >> 2) & 3, m = q >> 4;
@@ -60,7 +65,7 @@ __global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset,
                 const int in = frag_unit(s, lane >> 4, j);
                 int out = 16 * m + (lane & 15);
                 if (piece == 3 && G == 1) out = out < U ? 0 : U;  // shared gate broadcast to all units
-                ph[p] = split_part(wval(wb + Aoff, U, nout, in, out), part);
+                ph[p] = split_part(wval(wb + Aoff, U, nout, in, out), part, bf);
             } else {
                 if (p & 1) continue;
                 const int qq = oo - 4096, r = qq & 3, g = (qq >> 2) & 3, m = qq >> 4;
@@ -82,7 +87,7 @@ __global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset,
             float v = 0.0f;
             if (row < 5) v = wval(w + c.Wf, U, 5, in, row);
             else if (row < 5 + T) v = wval(w + c.Ws, U, T, in, row - 5);
-            ph[p] = split_part(v, part);
+            ph[p] = split_part(v, part, bf);
         } else if (pf < e.head_b + 16 * e.head_tiles) {  // head bias [mh][g][r]
             if (p & 1) continue;
             const int q = pf - e.head_b, r = q & 3, g = (q >> 2) & 3, mh = q >> 4;
@@ -99,7 +104,7 @@ __global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset,
 
 constexpr int kEncBlock = 1024;
 
-template <int T, int NL>
+template <int T, int NL, bool BF>
 __global__ __launch_bounds__(kEncBlock) void encoder_fwd_kernel(
     QbDev c, const float* __restrict__ packed, const float* __restrict__ x,
     float* __restrict__ out1, float* __restrict__ out2, float* __restrict__ sigma, int64_t N) {
@@ -122,13 +127,13 @@ __global__ __launch_bounds__(kEncBlock) void encoder_fwd_kernel(
         for (int t = 0; t < T; ++t) xv[t] = x[vc * T + t];
         qb::normalise<T>(c, xv, nv);
         f32x4 a[4];
-        qb::dense_first<T>(lds_w + e.first_A, lds_w + e.first_b, nv, a, lane);
+        qb::dense_first<T, BF>(lds_w + e.first_A, lds_w + e.first_b, nv, a, lane);
         if (out2 || sigma) {
             f32x4 b[4] = {a[0], a[1], a[2], a[3]};  // net2 = net1, model.py:185
 #pragma unroll
-            for (int l = 0; l < NL; ++l) qb::block_stream2(lds_w + e.blk0 + l * e.blk_stride, b, lane);
+            for (int l = 0; l < NL; ++l) qb::block_stream2<BF>(lds_w + e.blk0 + l * e.blk_stride, b, lane);
             f32x4 hd[HT];
-            qb::dense_head<HT>(lds_w + e.head_A, lds_w + e.head_b, b, hd, lane);
+            qb::dense_head<HT, BF>(lds_w + e.head_A, lds_w + e.head_b, b, hd, lane);
             float o[5 + T];
             qb::gather_head<5 + T, HT>(hd, o);
             if (v < N) {
@@ -144,9 +149,9 @@ __global__ __launch_bounds__(kEncBlock) void encoder_fwd_kernel(
         }
         if (out1) {
 #pragma unroll
-            for (int l = 0; l < NL; ++l) qb::block_stream1(lds_w + e.blk0 + l * e.blk_stride, a, lane);
+            for (int l = 0; l < NL; ++l) qb::block_stream1<BF>(lds_w + e.blk0 + l * e.blk_stride, a, lane);
             f32x4 hd[HT];
-            qb::dense_head<HT>(lds_w + e.head_A, lds_w + e.head_b, a, hd, lane);
+            qb::dense_head<HT, BF>(lds_w + e.head_A, lds_w + e.head_b, a, hd, lane);
             float o[5];
             qb::gather_head<5, 1>(reinterpret_cast<f32x4(&)[1]>(hd[0]), o);
             if (v < N && g == 2) {
@@ -163,6 +168,10 @@ namespace qb {
 int check_encoder_shape(const qbold_ctx* ctx, const qbold_encoder_shape* s) {
     if (!s) { set_error("encoder shape is null"); return QBOLD_ERR_INVALID; }
     if (s->T != ctx->dev.T) { set_error("encoder shape T differs from the context's tau grid"); return QBOLD_ERR_INVALID; }
+    if (s->precision != QBOLD_ENC_F32 && s->precision != QBOLD_ENC_BF16) {
+        set_error("encoder shape: precision must be QBOLD_ENC_F32 or QBOLD_ENC_BF16");
+        return QBOLD_ERR_INVALID;
+    }
     if (s->U < 1 || s->U > 64 || s->L < 1 || s->L > 2 || s->T > 27) {
         set_error("encoder kernels are built for U <= 64, L <= 2, T <= 27 (LDS-resident weights)");
         return QBOLD_ERR_UNSUPPORTED;
@@ -191,7 +200,7 @@ extern "C" int qbold_encoder_pack(const qbold_ctx* ctx, const qbold_encoder_shap
     const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating,
                                              shape->spatial_taps);
     hipLaunchKernelGGL(pack_kernel, dim3((2 * e.total + 255) / 256), dim3(256), 0, (hipStream_t)stream, e,
-                       c, shape->gate_offset, weights, packed);
+                       c, shape->gate_offset, shape->precision == QBOLD_ENC_BF16, weights, packed);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }
@@ -212,7 +221,8 @@ extern "C" int qbold_encoder_fwd(const qbold_ctx* ctx, const qbold_encoder_shape
     const int grid = (int)(nblk < ctx->num_cus ? nblk : ctx->num_cus);
 #define QB_LAUNCH_ENC(TT, NL)                                                                      \
     do {                                                                                           \
-        auto k = encoder_fwd_kernel<TT, NL>;                                                       \
+        auto k = shape->precision == QBOLD_ENC_BF16 ? encoder_fwd_kernel<TT, NL, true>             \
+                                                    : encoder_fwd_kernel<TT, NL, false>;           \
         QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                               \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));        \
         hipLaunchKernelGGL(k, dim3(grid), dim3(kEncBlock), smem, (hipStream_t)stream, ctx->dev,    \

@@ -34,7 +34,7 @@ using qb::f32x4;
 constexpr int kBlock = 1024;
 constexpr int kWaves = kBlock / 64;
 
-template <int T, int NL, int SE, bool FAST, bool LITERAL>
+template <int T, int NL, int SE, bool FAST, bool LITERAL, bool BF>
 __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
     QbDev c, const float4* __restrict__ g_tab, const float* __restrict__ packed,
     const float* __restrict__ x, const float* __restrict__ mask, const float* __restrict__ prior,
@@ -67,12 +67,12 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
             for (int t = 0; t < T; ++t) xv[t] = x[vc * T + t];
             qb::normalise<T>(c, xv, nv);
             f32x4 b[4];
-            qb::dense_first<T>(lds_w + e.first_A, lds_w + e.first_b, nv, b, lane);
+            qb::dense_first<T, BF>(lds_w + e.first_A, lds_w + e.first_b, nv, b, lane);
             if (!(c.debug_skip & 1))
 #pragma unroll
-                for (int l = 0; l < NL; ++l) qb::block_stream2(lds_w + e.blk0 + l * e.blk_stride, b, lane);
+                for (int l = 0; l < NL; ++l) qb::block_stream2<BF>(lds_w + e.blk0 + l * e.blk_stride, b, lane);
             f32x4 hd[HT];
-            qb::dense_head<HT>(lds_w + e.head_A, lds_w + e.head_b, b, hd, lane);
+            qb::dense_head<HT, BF>(lds_w + e.head_A, lds_w + e.head_b, b, hd, lane);
             qb::gather_head<5 + T, HT>(hd, o);
         }
         if (v < N && !(c.debug_skip & 2)) {
@@ -132,9 +132,15 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     const int grid = (int)(nblk < ctx->num_cus ? (nblk > 0 ? nblk : 1) : ctx->num_cus);
     const bool lit = ctx->dev.tissue_mode == QBOLD_TISSUE_LITERAL;
     float2* out = reinterpret_cast<float2*>(nll_kl);
+    const bool bf = shape->precision == QBOLD_ENC_BF16;
+    // the reduced-precision encoder is built for the table-mode fast path (the bench / training
+    // configuration); the literal and generic paths exist to reproduce float32 semantics
+    QB_REQUIRE(!bf || qb::elbo_fast_path(ctx),
+               "qbold_vi_fwd: QBOLD_ENC_BF16 needs the table-mode Gaussian fast path");
 #define QB_LAUNCH_VI(TT, NL, SE, FAST, LIT)                                                          \
     do {                                                                                          \
-        auto k = vi_fwd_kernel<TT, NL, SE, FAST, LIT>;                                             \
+        auto k = vi_fwd_kernel<TT, NL, SE, FAST, LIT, false>;                                      \
+        if constexpr (FAST) { if (bf) k = vi_fwd_kernel<TT, NL, SE, FAST, LIT, true>; }            \
         QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                              \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));       \
         hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), smem, s, ctx->dev, ctx->d_tab, packed,    \

@@ -43,10 +43,14 @@ class EncoderWeights:
 
     NAMES = ("W0", "b0", "Wc", "bc", "Wr1", "br1", "Wr2", "br2", "Wg", "bg", "Wf", "bf", "Ws", "bs")
 
-    def __init__(self, ctx, T, U, L, channelwise_gating=True, gate_offset=0.0, spatial_taps=1):
+    PRECISIONS = {"f32": 0, "bf16": 1}   # qbold_encoder_precision
+
+    def __init__(self, ctx, T, U, L, channelwise_gating=True, gate_offset=0.0, spatial_taps=1,
+                 precision="f32"):
         self.ctx = ctx
         self.shape = EncoderShape(int(T), int(U), int(L), int(bool(channelwise_gating)),
-                                  float(gate_offset), 9 if spatial_taps == 9 else 1)
+                                  float(gate_offset), 9 if spatial_taps == 9 else 1,
+                                  self.PRECISIONS[precision])
         lib = _lib.load()
         self.num_params = int(lib.qbold_encoder_num_params(C.byref(self.shape)))
         self.flat = torch.zeros(self.num_params, dtype=torch.float32, device=ctx.device)
@@ -99,6 +103,13 @@ class EncoderWeights:
 
     def mark_dirty(self):
         self._dirty = True
+
+    def set_precision(self, precision):
+        """'f32' (split-f16 MFMA, float32-grade) or 'bf16' (single bf16 MFMA pass) for the fused
+        voxel kernels; the MFMA-ordered image is rebuilt on next use."""
+        self.shape.precision = self.PRECISIONS[precision]
+        self._dirty = True
+        return self
 
     def packed_ptr(self):
         if self._dirty:

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Times one fine-tuning step (encoder forward with saved activations, ELBO backward, encoder
+backward, AdamW) on a voxel batch and on a crop batch.  Not the headline bench (bench.py); used
+with `rocprofv3 --kernel-trace --stats` to see where a training step goes."""
+import argparse
+import json
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from qbold_vi_amd.init import init_encoder_weights  # noqa: E402
+from qbold_vi_amd.ops import Context, EncoderWeights, TrainState  # noqa: E402
+from qbold_vi_amd.training import get_params  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--voxels", type=int, default=1 << 20)
+    ap.add_argument("--crops", type=int, nargs=4, default=[38, 25, 25, 8], metavar=("B", "X", "Y", "Z"))
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--S", type=int, default=1)
+    ap.add_argument("--K", type=int, default=70)
+    a = ap.parse_args()
+    os.chdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    params = get_params("config")
+    ctx = Context(params, True, True)
+    w = init_encoder_weights(T=ctx.T, U=60, L=2, channelwise_gating=True, resid_init_std=0.05,
+                             im_loss_sigma=0.05, seed=1, spatial_taps=9)
+    ew = EncoderWeights(ctx, ctx.T, 60, 2, True, -3.0, spatial_taps=9).set_from_arrays(w)
+    st = TrainState(ctx, ew)
+    out = {}
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / a.steps
+
+    N = a.voxels
+    y = torch.stack([torch.rand(N, device="cuda") * 0.7 + 0.08, torch.rand(N, device="cuda") * 0.1 + 0.005], -1)
+    x = ctx.signal_fwd(y)
+    prior = ctx.encoder_fwd(ew, x, want=("out1",))[0]
+    mask = torch.ones(N, device="cuda")
+
+    def voxel_step():
+        q, ls = st.forward(x, 2)
+        sums, gq, gls, _ = ctx.elbo_bwd(x, mask, q, prior, ls, a.S, a.K, seed=st.step)
+        st.backward(2, gq, gls, sums)
+        st.adamw(5e-3, 2e-4, 0.9, 0.9, 1e-7)
+
+    ms = timed(voxel_step)
+    out["voxel_batch"] = dict(voxels=N, ms_per_step=ms, voxels_per_s=N / ms * 1e3)
+
+    B, X, Y, Z = a.crops
+    V = B * X * Y * Z
+    x5 = x[:V].reshape(B, X, Y, Z, ctx.T).contiguous()
+    m5 = torch.ones(B, X, Y, Z, device="cuda")
+    p5 = prior[:V].contiguous()
+
+    def crop_step():
+        q, ls = st.forward_spatial(x5)
+        sums, gq, gls, _ = ctx.elbo_bwd(x5.reshape(V, -1), m5.reshape(V), q, p5, ls, a.S, a.K, seed=st.step)
+        ctx.smoothness(q.reshape(B, X, Y, Z, 5), m5, weight=5.0, g_q=gq)
+        st.backward_spatial(gq, gls, sums)
+        st.adamw(5e-3, 2e-4, 0.9, 0.9, 1e-7)
+
+    ms = timed(crop_step)
+    out["crop_batch"] = dict(crops=[B, X, Y, Z], voxels=V, ms_per_step=ms, voxels_per_s=V / ms * 1e3)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

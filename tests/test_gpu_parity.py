@@ -386,6 +386,58 @@ def test_full_size_properties_one_million_voxels(ctx, weights, oracle32, params)
     assert abs(elbo - want["elbo"]) / abs(want["elbo"]) < 1e-4
 
 
+def test_bf16_encoder_mode(ctx, weights, oracle32):
+    """BASELINE config 5 ("bf16 forward / fp32 ELBO accum, tolerance re-stated"): the encoder's
+    matrix products on bfloat16-rounded operands with float32 accumulation; sampling, forward
+    signal model and ELBO sums stay float32.
+    Tolerances (re-stated for this mode):
+      * vs the oracle with the same bf16 operand rounding: |dq| < 2e-3 (an activation within an
+        accumulation-order ulp of a bf16 rounding boundary may round the other way), ELBO 1e-4 rel
+        given identical q / sigma;
+      * vs the float32 path: |dq| < 0.03 in logit units, sigma within 1e-2 rel (bf16 carries 8
+        mantissa bits through five 64-wide layers; measured 5e-3 / 2e-3), ELBO within 1e-3 rel
+        (measured 7e-5)."""
+    from oracle.oracle import synth_inputs
+    from qbold_vi_amd.ops import EncoderWeights
+    w, ew32 = weights
+    ew = EncoderWeights(ctx, 11, 60, 2, True, w["gate_offset"], precision="bf16").set_from_arrays(w)
+    n, S, K, seed = 4096, 32, 70, 3
+    x, _ = synth_inputs(n, seed=9, oracle=oracle32)
+    xd = dev(x)
+    o1, o2, sg = (t.cpu().numpy() for t in ctx.encoder_fwd(ew, xd))
+    oracle32.set_encoder_bf16(True)
+    try:
+        w1, w2, wsg = oracle32.encoder_fwd(w, x)
+    finally:
+        oracle32.set_encoder_bf16(False)
+    f1, f2, fsg = oracle32.encoder_fwd(w, x)
+    print("bf16 kernel vs bf16 oracle:", np.abs(o2 - w2).max(), " bf16 vs f32:", np.abs(o2 - f2).max(),
+          np.abs(sg / fsg - 1).max())
+    assert np.abs(o1 - w1).max() < 2e-3 and np.abs(o2 - w2).max() < 2e-3
+    assert np.abs(sg / wsg - 1).max() < 2e-3
+    assert 1e-5 < np.abs(o2 - f2).max() < 0.03         # it really is a different arithmetic
+    assert np.abs(sg / fsg - 1).max() < 1e-2
+    # fused ELBO: float32 sampling on the bf16 encoder's outputs
+    prior = dev(f1)
+    sums, q, nk = ctx.vi_fwd(ew, xd, None, prior, S, K, seed=seed)
+    assert np.abs(q.cpu().numpy() - o2).max() < 1e-6    # same encoder arithmetic as encoder_fwd
+    want = oracle32.elbo(x, np.ones(n, np.float32), q.cpu().numpy(), f1, sg,
+                         oracle32.philox_normals(seed, 0, 0, n, S), oracle32.philox_normals(seed, 1, 0, n, K))
+    elbo = float((sums[0] + sums[1]) / sums[2])
+    assert abs(elbo - want["elbo"]) / abs(want["elbo"]) < 1e-4
+    s32, _, _ = ctx.vi_fwd(ew32, xd, None, prior, S, K, seed=seed)
+    elbo32 = float((s32[0] + s32[1]) / s32[2])
+    print("ELBO bf16", elbo, "f32", elbo32, "rel", abs(elbo / elbo32 - 1))
+    assert abs(elbo / elbo32 - 1) < 1e-3
+    # the literal / generic paths reproduce float32 semantics only
+    ctx.set_tissue_mode("literal")
+    try:
+        with pytest.raises(RuntimeError, match="QBOLD_ENC_BF16"):
+            ctx.vi_fwd(ew, xd[:64], None, prior[:64], 1, 1, seed=seed)
+    finally:
+        ctx.set_tissue_mode("table")
+
+
 def test_24_tau_protocol(params):
     """The reference's second acquisition protocol (24 taus from -0.028 s in 4 ms steps,
     signals.py:120-121): forward model, encoder, fused ELBO and head gradients."""
