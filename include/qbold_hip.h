@@ -150,6 +150,21 @@ int qbold_encoder_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, co
                       const float* x, float* out1, float* out2, float* sigma, int64_t N,
                       void* stream);
 
+/* The same encoder for widths beyond the LDS-resident kernels (BASELINE config 3: 64 taus,
+ * no_units 256): one weight-streaming split-f16 MFMA GEMM per layer over activations in HBM, with
+ * bias / relu / gate / head fused into the epilogues.  Built for U = 128 or 256, L <= 8, T <= 64,
+ * channel-wise gating, QBOLD_ENC_F32.  *_packed_floats / *_workspace_floats return the sizes (in
+ * floats) of the image and of the caller-owned activation workspace for N voxels, or a negative
+ * qbold_status.  stream_sel = 1: out_q = stream-1 parameters (model.py:199), out_log_sigma unused;
+ * 2: out_q = stream-2 parameters (:208), out_log_sigma [N][T] = log of the sigma head (:211-214). */
+int64_t qbold_encoder_wide_packed_floats(const qbold_encoder_shape* shape);
+int64_t qbold_encoder_wide_workspace_floats(const qbold_encoder_shape* shape, int64_t N);
+int qbold_encoder_wide_pack(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* weights,
+                            float* packed, void* stream);
+int qbold_encoder_wide_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* packed,
+                           const float* x, int stream_sel, float* workspace, float* out_q,
+                           float* out_log_sigma, int64_t N, void* stream);
+
 /* ---- logit-Normal pieces -------------------------------------------------------------------- */
 /* ReparamTrickLayer.call + forward_transform (model.py:15-50, 299-305): q [N][5], z [N][2] ->
  * oef_dbv [N][2]. */

@@ -89,6 +89,10 @@ SIGNATURES = {
                                             _P, _P]),
     "qbold_encoder_spatial_bwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, C.POINTER(Geometry), _P, _P, _P,
                                             _P, _P, _P]),
+    "qbold_encoder_wide_packed_floats": (C.c_int64, [C.POINTER(EncoderShape)]),
+    "qbold_encoder_wide_workspace_floats": (C.c_int64, [C.POINTER(EncoderShape), C.c_int64]),
+    "qbold_encoder_wide_pack": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, _P]),
+    "qbold_encoder_wide_fwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, C.c_int, _P, _P, _P, C.c_int64, _P]),
     "qbold_signal_fwd_ex": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "qbold_wls_fit": (C.c_int, [_P, _P, C.c_double, _P, C.c_int64, _P]),
     "qbold_smoothness": (C.c_int, [_P, _P, _P, C.POINTER(Geometry), C.c_float, _P, _P, _P]),

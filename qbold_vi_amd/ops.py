@@ -57,6 +57,13 @@ class EncoderWeights:
         self.packed = torch.zeros(int(lib.qbold_encoder_packed_floats(C.byref(self.shape))),
                                   dtype=torch.float32, device=ctx.device)
         self._dirty = True
+        # weight-streaming image for widths beyond the LDS-resident kernels (U = 128 / 256)
+        n_wide = int(lib.qbold_encoder_wide_packed_floats(C.byref(self.shape)))
+        self.wide = n_wide > 0 and not Context.fits_fused(self.shape)
+        self.wide_packed = (torch.zeros(n_wide, dtype=torch.float32, device=ctx.device)
+                            if self.wide else None)
+        self._wide_ws = None
+        self._wide_ws_n = 0
 
     # canonical blob views -------------------------------------------------------------------
     def _slices(self):
@@ -110,6 +117,21 @@ class EncoderWeights:
         self.shape.precision = self.PRECISIONS[precision]
         self._dirty = True
         return self
+
+    def wide_ptr(self):
+        if self._dirty:
+            _lib.check(_lib.load().qbold_encoder_wide_pack(self.ctx.handle, C.byref(self.shape), _ptr(self.flat),
+                                                           _ptr(self.wide_packed), _stream()),
+                       "qbold_encoder_wide_pack")
+            self._dirty = False
+        return _ptr(self.wide_packed)
+
+    def wide_workspace(self, N):
+        if self._wide_ws is None or self._wide_ws_n < N:
+            n = int(_lib.load().qbold_encoder_wide_workspace_floats(C.byref(self.shape), int(N)))
+            self._wide_ws = torch.empty(n, dtype=torch.float32, device=self.flat.device)
+            self._wide_ws_n = N
+        return self._wide_ws
 
     def packed_ptr(self):
         if self._dirty:
@@ -235,6 +257,23 @@ class Context:
         x = _f32(x, "x", self.T)
         N = x.numel() // self.T
         lead = x.shape[:-1]
+        if weights.wide:  # weight-streaming MFMA GEMM per layer (wide_kernels.hip)
+            x2 = x.reshape(N, self.T)
+            o1 = o2 = sg = None
+            for sel, wanted in ((1, "out1" in want), (2, "out2" in want or "sigma" in want)):
+                if not wanted:
+                    continue
+                q = torch.empty((N, 5), dtype=torch.float32, device=x.device)
+                ls = torch.empty((N, self.T), dtype=torch.float32, device=x.device) if sel == 2 else None
+                _lib.check(self.lib.qbold_encoder_wide_fwd(self.handle, C.byref(weights.shape), weights.wide_ptr(),
+                                                           _ptr(x2), sel, _ptr(weights.wide_workspace(N)), _ptr(q),
+                                                           _ptr(ls), N, _stream()), "qbold_encoder_wide_fwd")
+                if sel == 1:
+                    o1 = q.reshape(lead + (5,))
+                else:
+                    o2 = q.reshape(lead + (5,)) if "out2" in want else None
+                    sg = self.transform("exp", ls).reshape(lead + (self.T,)) if "sigma" in want else None
+            return o1, o2, sg
         if not self.fits_fused(weights.shape):
             st = getattr(weights, "_layerwise_state", None)
             if st is None:  # activation workspace is kept with the weights, not re-allocated per call

@@ -470,9 +470,38 @@ def test_24_tau_protocol(params):
     assert torch.allclose(nk3, nk2, rtol=1e-4, atol=1e-4) and bool(torch.isfinite(gq).all())
 
 
+def test_wide_encoder_shapes_and_edges(params, oracle32):
+    """The weight-streaming encoder on the 11-tau grid (one padded K chunk in the first layer), with
+    voxel counts around its 128- / 256-voxel block passes, and its argument checks."""
+    from oracle.oracle import init_weights, synth_inputs
+    from qbold_vi_amd.ops import Context, EncoderWeights
+    ctx = Context(params, True, True)
+    for U, L, ns in ((256, 1, (1, 127, 129, 1000)), (128, 2, (31, 256, 257))):
+        w = init_weights(T=11, U=U, L=L, seed=U + 1)
+        rb = np.random.default_rng(U)
+        for nm in ("b0", "bc", "br1", "br2", "bg", "bf"):
+            w[nm] = (rb.standard_normal(w[nm].shape) * 0.1).astype(np.float32)
+        w["gate_offset"] = 0.5
+        ew = EncoderWeights(ctx, 11, U, L, True, 0.5).set_from_arrays(w)
+        assert ew.wide
+        for n in ns:
+            x, _ = synth_inputs(n, seed=n, oracle=oracle32)
+            want = oracle32.encoder_fwd(w, x)
+            got = ctx.encoder_fwd(ew, dev(x))
+            for a, b, tol in zip(got, want, (5e-5, 5e-5, None)):
+                if tol is None:
+                    assert rel(a.cpu().numpy(), b) < 5e-5
+                else:
+                    assert np.max(np.abs(a.cpu().numpy() - b)) < tol
+    # shared (non channel-wise) gating is not built for the streaming path: falls back to layer-wise
+    ew1 = EncoderWeights(ctx, 11, 128, 1, False, 0.0)
+    assert not ew1.wide
+
+
 def test_config3_wide_encoder_64_taus(params):
     """BASELINE config 3 shapes (T = 64 taus, encoder width 256, SURVEY H6 tau grid) through the
-    layer-wise GEMM encoder and the any-T ELBO kernel, against the oracle at small N."""
+    weight-streaming MFMA encoder (U = 256 / 128; other widths take the layer-wise f32 GEMMs) and
+    the any-T ELBO kernel, against the oracle at small N."""
     from oracle.oracle import Oracle, init_weights, synth_inputs
     from qbold_vi_amd.ops import Context, EncoderWeights
     p = dict(params, tau_start="-0.015", tau_end="0.065", tau_step="0.00125")
@@ -484,10 +513,14 @@ def test_config3_wide_encoder_64_taus(params):
     x = (x * (1 + 0.01 * np.random.default_rng(1).standard_normal(x.shape))).astype(np.float32)
     assert rel(ctx.signal_fwd(dev(synth_inputs(50, p, seed=1, noise=False, oracle=orc)[1])).cpu().numpy(),
                orc.signal_fwd(synth_inputs(50, p, seed=1, noise=False, oracle=orc)[1])) < 1e-5
-    for U, L in ((256, 2), (100, 3)):
+    for U, L in ((256, 2), (128, 3), (100, 3)):
         w = init_weights(T=64, U=U, L=L, seed=U)
+        rb = np.random.default_rng(U)
+        for nm in ("b0", "bc", "br1", "br2", "bg", "bf"):
+            w[nm] = (rb.standard_normal(w[nm].shape) * 0.1).astype(np.float32)
         w["gate_offset"] = -3.0
         ew = EncoderWeights(ctx, 64, U, L, True, -3.0).set_from_arrays(w)
+        assert ew.wide == (U in (128, 256))
         prior, q_want, sigma = orc.encoder_fwd(w, x)
         o1, o2, sg = ctx.encoder_fwd(ew, dev(x))
         assert np.max(np.abs(o1.cpu().numpy() - prior)) < 5e-5
@@ -509,4 +542,5 @@ def test_config3_wide_encoder_64_taus(params):
         # 64 residuals at sigma ~ 0.05 with an untrained posterior: |r| ~ 4, so the table's ~2e-6
         # signal error is amplified to a few 1e-4 of a per-voxel NLL of order 1e3
         assert rel(nk2.cpu().numpy()[:, 0], want2["nll_v"], 1.0) < 5e-4
-        assert np.max(np.abs(nk2.cpu().numpy()[:, 1] - want2["kl_v"]) / (np.abs(want2["kl_v"]) + 1.0)) < 1e-4
+        # per-voxel KL = mean of log q - log p, two O(10) terms that cancel to O(0.1): float32 noise
+        assert np.max(np.abs(nk2.cpu().numpy()[:, 1] - want2["kl_v"]) / (np.abs(want2["kl_v"]) + 1.0)) < 5e-4
