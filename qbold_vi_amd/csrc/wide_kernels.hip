@@ -12,10 +12,12 @@
 //     2 x 8 x (out, cross) accumulators = 128 VGPRs.  Every weight fragment read from LDS feeds
 //     two voxel tiles, which keeps the LDS read rate (2 KiB per six MFMAs) under the 128 B/clk port;
 //   * a 512-thread block = 4 voxel groups x 2 output halves = 128 voxels x 256 outputs per pass;
-//   * K runs in chunks of 32: the chunk's weight image (32 KiB: [tile][hi, lo][lane][8 halves], one
-//     ds_read_b128 per fragment, conflict-free) is double-buffered in LDS, the next chunk's global
-//     loads (weights: L2-resident; activations: 32 contiguous bytes per lane, four lanes per 128-byte
-//     line) are issued before the current chunk's MFMAs, one __syncthreads per chunk;
+//   * K runs in LDS tiles of 64 (two k-steps of 32): the tile's weight image (64 KiB:
+//     [k-step][out tile][hi, lo][lane][8 halves], one conflict-free ds_read_b128 per fragment) is
+//     double-buffered in LDS and filled by LDS-direct loads (global_load_lds_dwordx4, 1 KiB per
+//     wave-instruction, no staging registers) issued a tile ahead; activations go straight to
+//     registers a k-step ahead (32 contiguous bytes per lane, four lanes per 128-byte line); one
+//     __syncthreads per tile;
 //   * bias, relu / sigmoid-gate / head scatter are fused into the epilogue, relu on the input side
 //     into the operand load -- no separate element-wise passes over [N][U].
 //
@@ -127,13 +129,29 @@ __global__ void wide_pack_kernel(OpImage o, const float* __restrict__ W, const f
 
 __device__ __forceinline__ f16x8 as_frag(const uint4& u) { return __builtin_bit_cast(f16x8, u); }
 
+// Stage one LDS tile (KC k-steps of the image, contiguous) with LDS-direct loads: every wave-instruction
+// moves one 1 KiB fragment (64 lanes x 16 B, lane-linear on both sides), no staging registers.
+template <int FRAGS>
+__device__ __forceinline__ void stage_tile(const uint4* __restrict__ src, uint4* dst, int wave, int lane) {
+#pragma unroll
+    for (int f0 = 0; f0 < FRAGS; f0 += kWB / 64) {
+        const int f = f0 + wave;
+        if (FRAGS % (kWB / 64) == 0 || f < FRAGS)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + f * 64 + lane),
+                (__attribute__((address_space(3))) void*)(dst + f * 64), 16, 0, 0);
+    }
+}
+
 template <int KS, int MTW, int NSPLIT, bool RELU_IN, int EPI>
 __global__ __launch_bounds__(kWB) void wide_dense_kernel(WideArgs a) {
     extern __shared__ __align__(16) uint4 wlds[];
     constexpr int MT = MTW * NSPLIT;
-    constexpr int CH = MT * 2 * 64;                 // 16-byte fragments-of-a-lane per chunk
-    constexpr int NST = (CH + kWB - 1) / kWB;       // staging registers (uint4) per thread
-    constexpr int VPB = (kWB / 64 / NSPLIT) * 32;   // voxels per block pass
+    constexpr int KC = (KS % 2 == 0) ? 2 : 1;      // k-steps (of 32) per LDS tile: BK = 64 where K allows
+    constexpr int NT = KS / KC;                    // LDS tiles per pass
+    constexpr int CHS = MT * 2 * 64;               // 16-byte lane-fragments per k-step
+    constexpr int CHT = CHS * KC;                  // ... per LDS tile
+    constexpr int VPB = (kWB / 64 / NSPLIT) * 32;  // voxels per block pass
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
     const int osplit = wave % NSPLIT, vgrp = wave / NSPLIT;
@@ -149,69 +167,58 @@ __global__ __launch_bounds__(kWB) void wide_dense_kernel(WideArgs a) {
         for (int m = 0; m < MTW; ++m) {
             out[0][m] = out[1][m] = cross[0][m] = cross[1][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
-        uint4 st[NST];
-#pragma unroll
-        for (int n = 0; n < NST; ++n) {
-            const int idx = threadIdx.x + n * kWB;
-            if (idx < CH) st[n] = a.W[idx];
-        }
+        // the previous pass ended on a barrier after its last reads of buffer 0
+        stage_tile<MT * 2 * KC>(a.W, wlds, wave, lane);
         float4 ra0 = *reinterpret_cast<const float4*>(xa), ra1 = *reinterpret_cast<const float4*>(xa + 4);
         float4 rb0 = *reinterpret_cast<const float4*>(xb), rb1 = *reinterpret_cast<const float4*>(xb + 4);
-        // the previous pass ended on a barrier after its last reads of buffer 0
-#pragma unroll
-        for (int n = 0; n < NST; ++n) {
-            const int idx = threadIdx.x + n * kWB;
-            if (idx < CH) wlds[idx] = st[n];
-        }
-        __syncthreads();
+        __syncthreads();  // (drains the LDS-direct loads: the compiler waits vmcnt(0) here)
 #pragma unroll 1
-        for (int s = 0; s < KS; ++s) {
-            const uint4* buf = wlds + (s & 1) * CH;
-            float4 na0 = ra0, na1 = ra1, nb0 = rb0, nb1 = rb1;
-            if (s + 1 < KS) {
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
-                for (int n = 0; n < NST; ++n) {
-                    const int idx = threadIdx.x + n * kWB;
-                    if (idx < CH) st[n] = a.W[(int64_t)(s + 1) * CH + idx];
+            for (int kk = 0; kk < KC; ++kk) {
+                const int s = t * KC + kk;
+                float fa[8] = {ra0.x, ra0.y, ra0.z, ra0.w, ra1.x, ra1.y, ra1.z, ra1.w};
+                float fb[8] = {rb0.x, rb0.y, rb0.z, rb0.w, rb1.x, rb1.y, rb1.z, rb1.w};
+                if (RELU_IN) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        fa[j] = fmaxf(fa[j], 0.0f);
+                        fb[j] = fmaxf(fb[j], 0.0f);
+                    }
                 }
-                na0 = *reinterpret_cast<const float4*>(xa + 32 * (s + 1));
-                na1 = *reinterpret_cast<const float4*>(xa + 32 * (s + 1) + 4);
-                nb0 = *reinterpret_cast<const float4*>(xb + 32 * (s + 1));
-                nb1 = *reinterpret_cast<const float4*>(xb + 32 * (s + 1) + 4);
-            }
-            float fa[8] = {ra0.x, ra0.y, ra0.z, ra0.w, ra1.x, ra1.y, ra1.z, ra1.w};
-            float fb[8] = {rb0.x, rb0.y, rb0.z, rb0.w, rb1.x, rb1.y, rb1.z, rb1.w};
-            if (RELU_IN) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    fa[j] = fmaxf(fa[j], 0.0f);
-                    fb[j] = fmaxf(fb[j], 0.0f);
+                f16x8 ah, al, bh, bl;
+                qb::split8(fa, ah, al);
+                qb::split8(fb, bh, bl);
+                // next tile's weights (other buffer: last read before the previous barrier) and the next
+                // k-step's activations are requested only now, after this k-step's operands have been
+                // consumed from their registers: a wait on those would also wait on the new requests
+                if (kk == 0 && t + 1 < NT)
+                    stage_tile<MT * 2 * KC>(a.W + (int64_t)(t + 1) * CHT, wlds + ((t + 1) & 1) * CHT, wave, lane);
+                if (s + 1 < KS) {
+                    ra0 = *reinterpret_cast<const float4*>(xa + 32 * (s + 1));
+                    ra1 = *reinterpret_cast<const float4*>(xa + 32 * (s + 1) + 4);
+                    rb0 = *reinterpret_cast<const float4*>(xb + 32 * (s + 1));
+                    rb1 = *reinterpret_cast<const float4*>(xb + 32 * (s + 1) + 4);
                 }
-            }
-            f16x8 ah, al, bh, bl;
-            qb::split8(fa, ah, al);
-            qb::split8(fb, bh, bl);
+                const uint4* buf = wlds + (t & 1) * CHT + kk * CHS + (osplit * MTW * 2) * 64 + lane;
+                // fragments are fetched one output tile ahead of the MFMAs that consume them
+                f16x8 whi = as_frag(buf[0]), wlo = as_frag(buf[64]);
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                const int t = osplit * MTW + m;
-                const f16x8 whi = as_frag(buf[(t * 2 + 0) * 64 + lane]);
-                const f16x8 wlo = as_frag(buf[(t * 2 + 1) * 64 + lane]);
-                out[0][m] = QB_MFMA_F16(whi, ah, out[0][m]);
-                out[1][m] = QB_MFMA_F16(whi, bh, out[1][m]);
-                cross[0][m] = QB_MFMA_F16(whi, al, cross[0][m]);
-                cross[1][m] = QB_MFMA_F16(whi, bl, cross[1][m]);
-                cross[0][m] = QB_MFMA_F16(wlo, ah, cross[0][m]);
-                cross[1][m] = QB_MFMA_F16(wlo, bh, cross[1][m]);
-            }
-            if (s + 1 < KS) {
-                // buffer (s+1)&1 was last read in chunk s-1; every wave has passed that chunk's barrier
-                uint4* nbuf = wlds + ((s + 1) & 1) * CH;
-#pragma unroll
-                for (int n = 0; n < NST; ++n) {
-                    const int idx = threadIdx.x + n * kWB;
-                    if (idx < CH) nbuf[idx] = st[n];
+                for (int m = 0; m < MTW; ++m) {
+                    f16x8 nhi = whi, nlo = wlo;
+                    if (m + 1 < MTW) {
+                        nhi = as_frag(buf[((m + 1) * 2 + 0) * 64]);
+                        nlo = as_frag(buf[((m + 1) * 2 + 1) * 64]);
+                    }
+                    out[0][m] = QB_MFMA_F16(whi, ah, out[0][m]);
+                    out[1][m] = QB_MFMA_F16(whi, bh, out[1][m]);
+                    cross[0][m] = QB_MFMA_F16(whi, al, cross[0][m]);
+                    cross[1][m] = QB_MFMA_F16(whi, bl, cross[1][m]);
+                    cross[0][m] = QB_MFMA_F16(wlo, ah, cross[0][m]);
+                    cross[1][m] = QB_MFMA_F16(wlo, bh, cross[1][m]);
+                    whi = nhi;
+                    wlo = nlo;
                 }
-                ra0 = na0; ra1 = na1; rb0 = nb0; rb1 = nb1;
             }
             __syncthreads();
         }
@@ -283,9 +290,10 @@ __global__ void wide_normalise_kernel(QbDev c, const float* __restrict__ x, floa
 
 template <int KS, int MTW, int NSPLIT, bool RELU_IN, int EPI>
 int launch_one(const qbold_ctx* ctx, const WideArgs& a, hipStream_t s) {
-    constexpr int CH = MTW * NSPLIT * 2 * 64;
+    constexpr int KC = (KS % 2 == 0) ? 2 : 1;
+    constexpr int CHT = MTW * NSPLIT * 2 * 64 * KC;
     constexpr int VPB = (kWB / 64 / NSPLIT) * 32;
-    const size_t smem = sizeof(uint4) * 2 * CH;
+    const size_t smem = sizeof(uint4) * 2 * CHT;
     auto k = wide_dense_kernel<KS, MTW, NSPLIT, RELU_IN, EPI>;
     QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)smem));
