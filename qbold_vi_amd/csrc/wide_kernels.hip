@@ -12,12 +12,15 @@
 //     2 x 8 x (out, cross) accumulators = 128 VGPRs.  Every weight fragment read from LDS feeds
 //     two voxel tiles, which keeps the LDS read rate (2 KiB per six MFMAs) under the 128 B/clk port;
 //   * a 512-thread block = 4 voxel groups x 2 output halves = 128 voxels x 256 outputs per pass;
-//   * K runs in LDS tiles of 64 (two k-steps of 32): the tile's weight image (64 KiB:
-//     [k-step][out tile][hi, lo][lane][8 halves], one conflict-free ds_read_b128 per fragment) is
-//     double-buffered in LDS and filled by LDS-direct loads (global_load_lds_dwordx4, 1 KiB per
-//     wave-instruction, no staging registers) issued a tile ahead; activations go straight to
-//     registers a k-step ahead (32 contiguous bytes per lane, four lanes per 128-byte line); one
-//     __syncthreads per tile;
+//   * K runs in steps of 32.  Everything reaches LDS by LDS-direct loads (global_load_lds_dwordx4,
+//     1 KiB per wave-instruction, no staging registers): the step's weight image (32 KiB:
+//     [out tile][hi, lo][lane][8 halves], one conflict-free ds_read_b128 per fragment, L2-resident)
+//     double-buffered one step ahead; the step's activations (16 KiB: 128 voxels x 32 k float32, full
+//     128-byte lines, shared by the two output-half waves) in a ring of five slots, four steps
+//     ahead -- HBM latency under load is several thousand cycles, one k-step of MFMAs is ~1500;
+//   * the two streams are issued by different waves so that each wave's in-order vmcnt counter follows
+//     one prefetch distance; steps are separated by a raw s_barrier after a counted s_waitcnt, so the
+//     activation stream is never drained (a __syncthreads would wait vmcnt(0));
 //   * bias, relu / sigmoid-gate / head scatter are fused into the epilogue, relu on the input side
 //     into the operand load -- no separate element-wise passes over [N][U].
 //
@@ -129,138 +132,236 @@ __global__ void wide_pack_kernel(OpImage o, const float* __restrict__ W, const f
 
 __device__ __forceinline__ f16x8 as_frag(const uint4& u) { return __builtin_bit_cast(f16x8, u); }
 
-// Stage one LDS tile (KC k-steps of the image, contiguous) with LDS-direct loads: every wave-instruction
-// moves one 1 KiB fragment (64 lanes x 16 B, lane-linear on both sides), no staging registers.
-template <int FRAGS>
-__device__ __forceinline__ void stage_tile(const uint4* __restrict__ src, uint4* dst, int wave, int lane) {
-#pragma unroll
-    for (int f0 = 0; f0 < FRAGS; f0 += kWB / 64) {
-        const int f = f0 + wave;
-        if (FRAGS % (kWB / 64) == 0 || f < FRAGS)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(src + f * 64 + lane),
-                (__attribute__((address_space(3))) void*)(dst + f * 64), 16, 0, 0);
+__device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
+    // LDS-direct load: lane l's 16 bytes at src land at lds_dst + 16 l (lds_dst is wave-uniform)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// LDS reads of the staged images go through inline asm: the compiler orders an LDS load it can see
+// behind EVERY LDS-direct load in flight (s_waitcnt vmcnt(0): it cannot tell the ring slots apart),
+// which would drain the activation stream at every k-step.  An asm read is invisible to that
+// bookkeeping, so its completion is waited for explicitly (lds_wait ties the s_waitcnt to the
+// registers, which keeps consumers behind it).
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // one VGPR quad (asm "v" operand)
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read16(uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read_b128 immediate offset is 16 bits");
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+// s_waitcnt vmcnt(4 n): at most n steps' worth of this wave's four-instruction groups still in flight
+template <int PER>
+__device__ __forceinline__ void wait_groups(int n) {
+    static_assert(PER * 4 <= 63, "vmcnt is a 6-bit counter");
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PER) : "memory"); break;
     }
 }
 
+// Output tiles M .. MTW-1 of one k-step: the fragments of tile M+1 are requested before tile M's six
+// MFMAs and waited for after them.  (Recursive template: the LDS offsets are instruction immediates.)
+template <int M, int MTW>
+__device__ __forceinline__ void mfma_tiles(uint32_t buf, u32x4 whi, u32x4 wlo, const f16x8& ah, const f16x8& al,
+                                           const f16x8& bh, const f16x8& bl, f32x4 (&out)[2][MTW],
+                                           f32x4 (&cross)[2][MTW]) {
+    if constexpr (M < MTW) {
+        u32x4 nhi = whi, nlo = wlo;
+        if constexpr (M + 1 < MTW) {
+            nhi = lds_read16<((M + 1) * 2 + 0) * 1024>(buf);
+            nlo = lds_read16<((M + 1) * 2 + 1) * 1024>(buf);
+        }
+        const f16x8 h = __builtin_bit_cast(f16x8, whi), l = __builtin_bit_cast(f16x8, wlo);
+        out[0][M] = QB_MFMA_F16(h, ah, out[0][M]);
+        out[1][M] = QB_MFMA_F16(h, bh, out[1][M]);
+        cross[0][M] = QB_MFMA_F16(h, al, cross[0][M]);
+        cross[1][M] = QB_MFMA_F16(h, bl, cross[1][M]);
+        cross[0][M] = QB_MFMA_F16(l, ah, cross[0][M]);
+        cross[1][M] = QB_MFMA_F16(l, bh, cross[1][M]);
+        if constexpr (M + 1 < MTW) lds_wait(nhi, nlo);
+        mfma_tiles<M + 1, MTW>(buf, nhi, nlo, ah, al, bh, bl, out, cross);
+    }
+}
+
+// One dense layer.  The block walks a flat sequence of k-steps q = pass * KS + s over its voxel passes.
+// Waves 0-3 also stage the weights of step q+1 (L2-resident, one step ahead, two LDS buffers); waves
+// 4-7 also stage the activations of step q+D (HBM, D = R-1 steps ahead, a ring of R LDS slots) --
+// two loader roles so that each wave's in-order vmcnt counter tracks ONE prefetch distance, and the
+// activation stream stays D steps deep in flight across the per-step barrier (raw s_barrier with a
+// counted s_waitcnt, never vmcnt(0) on the activation waves), including across pass boundaries and
+// under the epilogue's stores.
 template <int KS, int MTW, int NSPLIT, bool RELU_IN, int EPI>
 __global__ __launch_bounds__(kWB) void wide_dense_kernel(WideArgs a) {
     extern __shared__ __align__(16) uint4 wlds[];
     constexpr int MT = MTW * NSPLIT;
-    constexpr int KC = (KS % 2 == 0) ? 2 : 1;      // k-steps (of 32) per LDS tile: BK = 64 where K allows
-    constexpr int NT = KS / KC;                    // LDS tiles per pass
-    constexpr int CHS = MT * 2 * 64;               // 16-byte lane-fragments per k-step
-    constexpr int CHT = CHS * KC;                  // ... per LDS tile
-    constexpr int VPB = (kWB / 64 / NSPLIT) * 32;  // voxels per block pass
+    constexpr int NVG = (kWB / 64) / NSPLIT;       // 32-voxel groups per block pass
+    constexpr int VPB = NVG * 32;                  // voxels per block pass
+    constexpr int WFR = MT * 2;                    // 1 KiB weight fragments per k-step
+    constexpr int AFR = NVG * 4;                   // 1 KiB activation fragments per k-step
+    constexpr int R = NSPLIT == 2 ? 5 : 3;         // activation ring slots
+    constexpr int D = R - 1;                       // activation prefetch distance (k-steps)
+    constexpr int APW = AFR / 4;                   // activation fragments per loader wave per step
+    constexpr int VGW = NVG / 4;                   // voxel groups per activation-loader wave
+    uint4* wbuf = wlds;                            // [2][WFR][64]
+    uint4* abuf = wlds + 2 * WFR * 64;             // [R][AFR][64]
+    float* lbias = reinterpret_cast<float*>(abuf + R * AFR * 64);  // [16 MT]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
     const int osplit = wave % NSPLIT, vgrp = wave / NSPLIT;
+    const bool wloader = wave < 4;
     const int64_t nblk = (a.N + VPB - 1) / VPB;
-    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const int64_t v0 = blk * VPB + (int64_t)vgrp * 32;
-        const int64_t va = v0 + i, vb = v0 + 16 + i;
-        // clamp: every lane takes part in the MFMAs; stores are predicated
-        const float* xa = a.X + (va < a.N ? va : a.N - 1) * a.ldx + 8 * g;
-        const float* xb = a.X + (vb < a.N ? vb : a.N - 1) * a.ldx + 8 * g;
-        f32x4 out[2][MTW], cross[2][MTW];
+    const int np = (int)((nblk - blockIdx.x + gridDim.x - 1) / gridDim.x);  // passes of this block (>= 1)
+    const int Q = np * KS;
+
+    for (int k = threadIdx.x; k < 16 * MT; k += kWB) lbias[k] = a.bias[k];
+
+    auto issue_w = [&](int q) {
+        const int s = q % KS;
+        const uint4* src = a.W + (int64_t)s * WFR * 64 + lane;
+        uint4* dst = wbuf + (q & 1) * WFR * 64;
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-            out[0][m] = out[1][m] = cross[0][m] = cross[1][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int f0 = 0; f0 < WFR; f0 += 4) {
+            const int f = f0 + wave;
+            if (WFR % 4 == 0 || f < WFR) glds16(src + f * 64, dst + f * 64);
         }
-        // the previous pass ended on a barrier after its last reads of buffer 0
-        stage_tile<MT * 2 * KC>(a.W, wlds, wave, lane);
-        float4 ra0 = *reinterpret_cast<const float4*>(xa), ra1 = *reinterpret_cast<const float4*>(xa + 4);
-        float4 rb0 = *reinterpret_cast<const float4*>(xb), rb1 = *reinterpret_cast<const float4*>(xb + 4);
-        __syncthreads();  // (drains the LDS-direct loads: the compiler waits vmcnt(0) here)
+    };
+    auto issue_a = [&](int q) {
+        const int s = q % KS;
+        const int64_t blk = blockIdx.x + (int64_t)(q / KS) * gridDim.x;
+        uint4* slot = abuf + (q % R) * AFR * 64;
+#pragma unroll
+        for (int k = 0; k < VGW; ++k) {
+            const int vg = (wave - 4) * VGW + k;
+#pragma unroll
+            for (int vt = 0; vt < 2; ++vt) {
+                int64_t v = blk * VPB + vg * 32 + vt * 16 + i;
+                v = v < a.N ? v : a.N - 1;  // clamp: every lane takes part in the MFMAs; stores are predicated
+                const float* src = a.X + v * a.ldx + 32 * s + 8 * g;
+                glds16(src, slot + ((vg * 2 + vt) * 2 + 0) * 64);
+                glds16(src + 4, slot + ((vg * 2 + vt) * 2 + 1) * 64);
+            }
+        }
+    };
+
+    if (wloader) {
+        issue_w(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        const int pre = D < Q ? D : Q;
+        for (int q = 0; q < pre; ++q) issue_a(q);
+        wait_groups<APW>(pre - 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the bias copy
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 out[2][MTW], cross[2][MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        out[0][m] = out[1][m] = cross[0][m] = cross[1][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
 #pragma unroll 1
-        for (int t = 0; t < NT; ++t) {
+    for (int q = 0; q < Q; ++q) {
+        // slots / buffers written here were last read in step q-1, which every wave left through a barrier
+        if (wloader) {
+            if (q + 1 < Q) issue_w(q + 1);
+        } else if (q + D < Q) {
+            issue_a(q + D);
+        }
+        const uint32_t as = lds_addr(abuf + (q % R) * AFR * 64 + (vgrp * 4) * 64 + lane);
+        u32x4 a0 = lds_read16<0>(as), a1 = lds_read16<1024>(as), b0 = lds_read16<2048>(as), b1 = lds_read16<3072>(as);
+        const uint32_t buf = lds_addr(wbuf + (q & 1) * WFR * 64 + (osplit * MTW * 2) * 64 + lane);
+        // weight fragments are fetched one output tile ahead of the MFMAs that consume them
+        u32x4 whi = lds_read16<0>(buf), wlo = lds_read16<1024>(buf);
+        lds_wait(a0, a1, b0, b1);
+        float fa[8], fb[8];
+        {
+            const float4 x0 = __builtin_bit_cast(float4, a0), x1 = __builtin_bit_cast(float4, a1);
+            const float4 y0 = __builtin_bit_cast(float4, b0), y1 = __builtin_bit_cast(float4, b1);
+            fa[0] = x0.x; fa[1] = x0.y; fa[2] = x0.z; fa[3] = x0.w; fa[4] = x1.x; fa[5] = x1.y; fa[6] = x1.z; fa[7] = x1.w;
+            fb[0] = y0.x; fb[1] = y0.y; fb[2] = y0.z; fb[3] = y0.w; fb[4] = y1.x; fb[5] = y1.y; fb[6] = y1.z; fb[7] = y1.w;
+        }
+        if (RELU_IN) {
 #pragma unroll
-            for (int kk = 0; kk < KC; ++kk) {
-                const int s = t * KC + kk;
-                float fa[8] = {ra0.x, ra0.y, ra0.z, ra0.w, ra1.x, ra1.y, ra1.z, ra1.w};
-                float fb[8] = {rb0.x, rb0.y, rb0.z, rb0.w, rb1.x, rb1.y, rb1.z, rb1.w};
-                if (RELU_IN) {
+            for (int j = 0; j < 8; ++j) {
+                fa[j] = fmaxf(fa[j], 0.0f);
+                fb[j] = fmaxf(fb[j], 0.0f);
+            }
+        }
+        f16x8 ah, al, bh, bl;
+        qb::split8(fa, ah, al);
+        qb::split8(fb, bh, bl);
+        lds_wait(whi, wlo);
+        mfma_tiles<0, MTW>(buf, whi, wlo, ah, al, bh, bl, out, cross);
+        if (q % KS == KS - 1) {
+            // epilogue: lane (g, i) holds output rows 16 t + 4 g + 0..3 of voxels va (tile 0), vb (tile 1)
+            const int64_t blk = blockIdx.x + (int64_t)(q / KS) * gridDim.x;
+            const int64_t va = blk * VPB + vgrp * 32 + i, vb = va + 16;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        fa[j] = fmaxf(fa[j], 0.0f);
-                        fb[j] = fmaxf(fb[j], 0.0f);
-                    }
-                }
-                f16x8 ah, al, bh, bl;
-                qb::split8(fa, ah, al);
-                qb::split8(fb, bh, bl);
-                // next tile's weights (other buffer: last read before the previous barrier) and the next
-                // k-step's activations are requested only now, after this k-step's operands have been
-                // consumed from their registers: a wait on those would also wait on the new requests
-                if (kk == 0 && t + 1 < NT)
-                    stage_tile<MT * 2 * KC>(a.W + (int64_t)(t + 1) * CHT, wlds + ((t + 1) & 1) * CHT, wave, lane);
-                if (s + 1 < KS) {
-                    ra0 = *reinterpret_cast<const float4*>(xa + 32 * (s + 1));
-                    ra1 = *reinterpret_cast<const float4*>(xa + 32 * (s + 1) + 4);
-                    rb0 = *reinterpret_cast<const float4*>(xb + 32 * (s + 1));
-                    rb1 = *reinterpret_cast<const float4*>(xb + 32 * (s + 1) + 4);
-                }
-                const uint4* buf = wlds + (t & 1) * CHT + kk * CHS + (osplit * MTW * 2) * 64 + lane;
-                // fragments are fetched one output tile ahead of the MFMAs that consume them
-                f16x8 whi = as_frag(buf[0]), wlo = as_frag(buf[64]);
+            for (int vt = 0; vt < 2; ++vt) {
+                const int64_t v = vt ? vb : va;
 #pragma unroll
                 for (int m = 0; m < MTW; ++m) {
-                    f16x8 nhi = whi, nlo = wlo;
-                    if (m + 1 < MTW) {
-                        nhi = as_frag(buf[((m + 1) * 2 + 0) * 64]);
-                        nlo = as_frag(buf[((m + 1) * 2 + 1) * 64]);
+                    const int col = 16 * (osplit * MTW + m) + 4 * g;
+                    u32x4 braw = lds_read16<0>(lds_addr(lbias + col)), bdummy = braw;
+                    lds_wait(braw, bdummy);
+                    const float4 bi = __builtin_bit_cast(float4, braw);
+                    float y[4] = {fmaf(cross[vt][m][0], QB_LO_UNSCALE, out[vt][m][0]) + bi.x,
+                                  fmaf(cross[vt][m][1], QB_LO_UNSCALE, out[vt][m][1]) + bi.y,
+                                  fmaf(cross[vt][m][2], QB_LO_UNSCALE, out[vt][m][2]) + bi.z,
+                                  fmaf(cross[vt][m][3], QB_LO_UNSCALE, out[vt][m][3]) + bi.w};
+                    out[vt][m] = cross[vt][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (v >= a.N) continue;
+                    if (EPI == EPI_HEAD) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = col + r;
+                            if (row < 5) a.q[v * 5 + row] = y[r];
+                            else if (row < 5 + a.T && a.ls) a.ls[v * a.T + (row - 5)] = y[r];
+                        }
+                        continue;
                     }
-                    out[0][m] = QB_MFMA_F16(whi, ah, out[0][m]);
-                    out[1][m] = QB_MFMA_F16(whi, bh, out[1][m]);
-                    cross[0][m] = QB_MFMA_F16(whi, al, cross[0][m]);
-                    cross[1][m] = QB_MFMA_F16(whi, bl, cross[1][m]);
-                    cross[0][m] = QB_MFMA_F16(wlo, ah, cross[0][m]);
-                    cross[1][m] = QB_MFMA_F16(wlo, bh, cross[1][m]);
-                    whi = nhi;
-                    wlo = nlo;
+                    if (EPI == EPI_RELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.0f);
+                    }
+                    if (EPI == EPI_GATE) {
+                        const float4 sk = *reinterpret_cast<const float4*>(a.skip + v * a.ldy + col);
+                        const float4 rr = *reinterpret_cast<const float4*>(a.r + v * a.ldy + col);
+                        const float s4[4] = {sk.x, sk.y, sk.z, sk.w}, r4[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float gate = qb::sigmoidf_(y[r]);                  // model.py:169
+                            y[r] = s4[r] * (1.0f - gate) + r4[r] * gate;             // model.py:170
+                        }
+                    }
+                    *reinterpret_cast<float4*>(a.Y + v * a.ldy + col) = make_float4(y[0], y[1], y[2], y[3]);
                 }
             }
-            __syncthreads();
         }
-        // epilogue: lane (g, i) holds output rows 16 t + 4 g + 0..3 of voxels va (tile 0) and vb (tile 1)
-#pragma unroll
-        for (int vt = 0; vt < 2; ++vt) {
-            const int64_t v = vt ? vb : va;
-            if (v >= a.N) continue;
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                const int col = 16 * (osplit * MTW + m) + 4 * g;
-                const float4 bi = *reinterpret_cast<const float4*>(a.bias + col);
-                float y[4] = {fmaf(cross[vt][m][0], QB_LO_UNSCALE, out[vt][m][0]) + bi.x,
-                              fmaf(cross[vt][m][1], QB_LO_UNSCALE, out[vt][m][1]) + bi.y,
-                              fmaf(cross[vt][m][2], QB_LO_UNSCALE, out[vt][m][2]) + bi.z,
-                              fmaf(cross[vt][m][3], QB_LO_UNSCALE, out[vt][m][3]) + bi.w};
-                if (EPI == EPI_HEAD) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = col + r;
-                        if (row < 5) a.q[v * 5 + row] = y[r];
-                        else if (row < 5 + a.T && a.ls) a.ls[v * a.T + (row - 5)] = y[r];
-                    }
-                    continue;
-                }
-                if (EPI == EPI_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.0f);
-                }
-                if (EPI == EPI_GATE) {
-                    const float4 sk = *reinterpret_cast<const float4*>(a.skip + v * a.ldy + col);
-                    const float4 rr = *reinterpret_cast<const float4*>(a.r + v * a.ldy + col);
-                    const float s4[4] = {sk.x, sk.y, sk.z, sk.w}, r4[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float gate = qb::sigmoidf_(y[r]);                  // model.py:169
-                        y[r] = s4[r] * (1.0f - gate) + r4[r] * gate;             // model.py:170
-                    }
-                }
-                *reinterpret_cast<float4*>(a.Y + v * a.ldy + col) = make_float4(y[0], y[1], y[2], y[3]);
-            }
+        // publish step q+1: each loader waits for ITS loads of that step, then everyone meets
+        if (wloader) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const int ahead = Q - 2 - q;  // steps beyond q+1 already requested (capped at D-1)
+            wait_groups<APW>(ahead < 0 ? 0 : (ahead < D - 1 ? ahead : D - 1));
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 }
 
@@ -290,10 +391,9 @@ __global__ void wide_normalise_kernel(QbDev c, const float* __restrict__ x, floa
 
 template <int KS, int MTW, int NSPLIT, bool RELU_IN, int EPI>
 int launch_one(const qbold_ctx* ctx, const WideArgs& a, hipStream_t s) {
-    constexpr int KC = (KS % 2 == 0) ? 2 : 1;
-    constexpr int CHT = MTW * NSPLIT * 2 * 64 * KC;
-    constexpr int VPB = (kWB / 64 / NSPLIT) * 32;
-    const size_t smem = sizeof(uint4) * 2 * CHT;
+    constexpr int MT = MTW * NSPLIT, NVG = (kWB / 64) / NSPLIT, R = NSPLIT == 2 ? 5 : 3;
+    constexpr int VPB = NVG * 32;
+    const size_t smem = sizeof(uint4) * (2 * MT * 2 * 64 + R * NVG * 4 * 64) + sizeof(float) * 16 * MT;
     auto k = wide_dense_kernel<KS, MTW, NSPLIT, RELU_IN, EPI>;
     QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)smem));
