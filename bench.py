@@ -231,7 +231,7 @@ def main():
                        "global_voxels": total_vox, "parallelism": f"voxel-shard x{world}",
                        "collective": "all_reduce(3 x f64)/step" if world > 1 else "none"},
             "neg_elbo": neg_elbo,
-            "roofline": {"kernel": "vi_fwd_kernel" if args.config == 2 else "layer-wise xw_kernel + elbo_fwd_generic_kernel", "bound": "mfma", "achieved": ach_tf,
+            "roofline": {"kernel": "vi_fwd_kernel" if args.config == 2 else "wide_dense_kernel (one launch per layer) + elbo_fwd_generic_kernel", "bound": "mfma", "achieved": ach_tf,
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "kernel_ms": kernel_ms,

@@ -51,6 +51,8 @@ struct WideArgs {
     float* q;         // EPI_HEAD: rows 0-4 -> q [N][5], rows 5..5+T-1 -> log sigma [N][T]
     float* ls;
     int T;
+    int dbg;          // QBOLD_DEBUG_SKIP ablation bits (timing experiments only): 16 no MFMA, 32 no activation
+                      // loads, 64 no stores, 128 no weight loads
     int64_t N;
 };
 
@@ -278,8 +280,8 @@ __global__ __launch_bounds__(kWB) void wide_dense_kernel(WideArgs a) {
     for (int q = 0; q < Q; ++q) {
         // slots / buffers written here were last read in step q-1, which every wave left through a barrier
         if (wloader) {
-            if (q + 1 < Q) issue_w(q + 1);
-        } else if (q + D < Q) {
+            if (q + 1 < Q && !(a.dbg & 128)) issue_w(q + 1);
+        } else if (q + D < Q && !(a.dbg & 32)) {
             issue_a(q + D);
         }
         const uint32_t as = lds_addr(abuf + (q % R) * AFR * 64 + (vgrp * 4) * 64 + lane);
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(kWB) void wide_dense_kernel(WideArgs a) {
         qb::split8(fa, ah, al);
         qb::split8(fb, bh, bl);
         lds_wait(whi, wlo);
-        mfma_tiles<0, MTW>(buf, whi, wlo, ah, al, bh, bl, out, cross);
+        if (!(a.dbg & 16)) mfma_tiles<0, MTW>(buf, whi, wlo, ah, al, bh, bl, out, cross);
         if (q % KS == KS - 1) {
             // epilogue: lane (g, i) holds output rows 16 t + 4 g + 0..3 of voxels va (tile 0), vb (tile 1)
             const int64_t blk = blockIdx.x + (int64_t)(q / KS) * gridDim.x;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(kWB) void wide_dense_kernel(WideArgs a) {
                                   fmaf(cross[vt][m][2], QB_LO_UNSCALE, out[vt][m][2]) + bi.z,
                                   fmaf(cross[vt][m][3], QB_LO_UNSCALE, out[vt][m][3]) + bi.w};
                     out[vt][m] = cross[vt][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    if (v >= a.N) continue;
+                    if (v >= a.N || (a.dbg & 64)) continue;
                     if (EPI == EPI_HEAD) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -520,6 +522,7 @@ extern "C" int qbold_encoder_wide_fwd(const qbold_ctx* ctx, const qbold_encoder_
         a.bias = packed + o.b;
         a.Y = Y; a.ldy = U;
         a.T = T; a.N = N;
+        a.dbg = ctx->dev.debug_skip;
         return a;
     };
     float* cur = bufs[0];
