@@ -191,8 +191,11 @@ def test_disabled_branches_fail_loudly(params):
         EncoderTrainer(params, use_population_prior=True, activation_type='relu')
     with pytest.raises(NotImplementedError):
         EncoderTrainer(params, use_population_prior=False, activation_type='gelu')
+    # misalignment / variable_hct are built (test_signal_variable_hct_and_misalignment); their
+    # gradient is not -- they only occur in synthetic-data generation (signals.py:251-300)
+    layer = SignalGenerationLayer(dict(params, simulate_noise='False'), True, True, misaligned_prob=0.1)
     with pytest.raises(NotImplementedError):
-        SignalGenerationLayer(params, True, True, misaligned_prob=0.1)
+        layer.gradient(torch.zeros(4, 2, device="cuda"), torch.zeros(4, 11, device="cuda"))
 
 
 def test_logit_mvn(trainer, oracle32):
