@@ -224,13 +224,13 @@ def test_posterior_moments(ctx, oracle32):
     wm, wv = oracle32.moments(q, z)
     assert np.max(np.abs(m.cpu().numpy()[:, :2] - wm[:, :2])) < 1e-5
     assert rel(m.cpu().numpy()[:, 2], wm[:, 2], 1e-3) < 1e-4
-    assert rel(v.cpu().numpy(), wv, 1e-7) < 1e-3
+    assert rel(v.cpu().numpy(), wv, 1e-12) < 1e-4      # SURVEY 8(d) gate: variances 1e-4 rel (measured 1e-5)
     # Philox stream: integer part bit-identical to the oracle's, normals to a few ulp
     m2, v2 = ctx.posterior_moments(dev(q), 20, seed=11, voxel0=123)
     zp = oracle32.philox_normals(11, 2, 123, n, 20)
     wm2, wv2 = oracle32.moments(q, zp)
     assert np.max(np.abs(m2.cpu().numpy()[:, :2] - wm2[:, :2])) < 1e-5
-    assert rel(v2.cpu().numpy(), wv2, 1e-7) < 1e-3
+    assert rel(v2.cpu().numpy(), wv2, 1e-12) < 1e-3    # 20 draws, normals equal to a few ulp only
 
 
 # ---------------------------------------------------------------------------------------------
