@@ -51,6 +51,8 @@ class EncoderWeights:
         self.shape = EncoderShape(int(T), int(U), int(L), int(bool(channelwise_gating)),
                                   float(gate_offset), 9 if spatial_taps == 9 else 1,
                                   self.PRECISIONS[precision])
+        if precision != "f32" and not Context.fits_fused(self.shape):
+            raise ValueError("precision='bf16' exists for the fused voxel kernels (U <= 64, L <= 2, T in {11, 24})")
         lib = _lib.load()
         self.num_params = int(lib.qbold_encoder_num_params(C.byref(self.shape)))
         self.flat = torch.zeros(self.num_params, dtype=torch.float32, device=ctx.device)
@@ -114,6 +116,8 @@ class EncoderWeights:
     def set_precision(self, precision):
         """'f32' (split-f16 MFMA, float32-grade) or 'bf16' (single bf16 MFMA pass) for the fused
         voxel kernels; the MFMA-ordered image is rebuilt on next use."""
+        if precision != "f32" and not Context.fits_fused(self.shape):
+            raise ValueError("precision='bf16' exists for the fused voxel kernels (U <= 64, L <= 2, T in {11, 24})")
         self.shape.precision = self.PRECISIONS[precision]
         self._dirty = True
         return self
