@@ -361,3 +361,18 @@ def test_restatement_goldens_have_not_drifted(oracle32, oracle64):
     np.testing.assert_allclose(e["nll_v"], g["nll_v"], rtol=1e-5)
     assert abs(e["elbo"] - float(g["elbo"])) < 1e-6 * abs(float(g["elbo"]))
     np.testing.assert_allclose(oracle32.philox_normals(1, 0, 5, 8, 6), g["philox_z"], rtol=1e-6, atol=1e-7)
+    # widening rows: crops, signal-model options, WLS
+    from oracle.oracle import fit_wls
+    w9 = {k: g["w9_" + k] for k in WEIGHT_NAMES}
+    w9["meta"] = dict(T=11, U=12, L=2, channelwise_gating=True, taps=9)
+    w9["gate_offset"] = -1.0
+    sp_q, sp_sigma = oracle32.encoder_fwd_spatial(w9, g["crop"])
+    np.testing.assert_allclose(sp_q, g["sp_q"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sp_sigma, g["sp_sigma"], rtol=1e-5)
+    assert abs(oracle32.smoothness_loss(g["sp_q"], g["crop_mask"]) - float(g["tv"])) < 1e-6 * float(g["tv"])
+    np.testing.assert_allclose(oracle32.signal_fwd_ex(g["ex_y"], hct=g["ex_hct"], alt=g["ex_alt"], from_idx=g["ex_idx"]),
+                               g["ex_sig"], rtol=1e-6)
+    wo, wd, wr = fit_wls(g["x"][:32].astype(np.float64) * 200.0)
+    np.testing.assert_allclose(wo, g["wls_oef"], rtol=1e-9)
+    np.testing.assert_allclose(wd, g["wls_dbv"], rtol=1e-9)
+    np.testing.assert_allclose(wr, g["wls_r2p"], rtol=1e-9)
