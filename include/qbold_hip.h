@@ -303,11 +303,13 @@ int qbold_smoothness(const qbold_ctx* ctx, const float* q, const float* mask, co
 int qbold_encoder_train_bwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* weights,
                             int stream_sel, float* workspace, const float* g_q, const float* g_log_sigma,
                             const double* sums, float* grad, int64_t N, void* stream);
-/* synthetic_data_loss (model.py:449-514; use_mvg, no r2p / inverse-gamma terms) per voxel and its
- * gradient: y_true rows of ld_y floats (OEF, DBV first), q [N][5] -> loss_v [N] (may be NULL),
- * g_q [N][5] = scale * d loss_v / d q. */
+/* synthetic_data_loss (model.py:449-514; use_mvg, no r2p term) per voxel and its gradient: y_true
+ * rows of ld_y floats (OEF, DBV first), q [N][5] -> loss_v [N] (may be NULL), g_q [N][5] =
+ * scale * d loss_v / d q.  inv_gamma_alpha * inv_gamma_beta > 0 adds the inverse-gamma prior on the
+ * two marginal variances (:492-507: - log IG(exp(s_o)^2) - log IG(exp(s_d)^2 + q[4]^2)). */
 int qbold_synth_loss_bwd(const qbold_ctx* ctx, const float* y_true, int ld_y, const float* q, float* g_q,
-                         float* loss_v, float scale, int64_t N, void* stream);
+                         float* loss_v, float scale, double inv_gamma_alpha, double inv_gamma_beta,
+                         int64_t N, void* stream);
 /* One tfa.optimizers.AdamW step (train.py:308-310, 382-385) on a flat blob: decoupled decay
  * var -= weight_decay * var, Keras Adam moments and bias correction at step t >= 1, eps 1e-7. */
 int qbold_adamw_step(const qbold_ctx* ctx, float* params, const float* grads, float* m, float* v,

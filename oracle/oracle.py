@@ -133,6 +133,7 @@ class Oracle:
         L.qbo_tissue_dF.restype = self.creal
         L.qbo_tissue_dF.argtypes = [self.creal]
         L.qbo_synthetic_data_loss.restype = C.c_double
+        L.qbo_synthetic_data_loss_ig.restype = C.c_double
         if threads:
             L.qbo_set_threads(int(threads))
         # NB process-global in the C library: use one policy per precision within a test session
@@ -275,10 +276,11 @@ class Oracle:
         self.lib.qbo_logit_mvn_nlogp(self._p(y), self._p(p), self._p(out), C.c_int64(y.shape[0]))
         return out
 
-    def synthetic_data_loss(self, y_true, q):
+    def synthetic_data_loss(self, y_true, q, inv_gamma_alpha=0.0, inv_gamma_beta=0.0):
         y = self._a(y_true, (-1, 3))
         q = self._a(q, (-1, 5))
-        return self.lib.qbo_synthetic_data_loss(self._p(y), self._p(q), C.c_int64(y.shape[0]))
+        return self.lib.qbo_synthetic_data_loss_ig(self._p(y), self._p(q), C.c_double(inv_gamma_alpha),
+                                                   C.c_double(inv_gamma_beta), C.c_int64(y.shape[0]))
 
     def nll(self, x, mask, pred, sigma):
         x = self._a(x)

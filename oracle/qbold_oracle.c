@@ -647,6 +647,27 @@ double qbo_synthetic_data_loss(const real *y_true, const real *q, int64_t N) {
     return acc / (double)N;
 }
 
+/* ... with the inverse-gamma prior on the marginal variances (model.py:492-507, use_mvg branch, fixed
+ * alpha / beta): oef_var = exp(oef_log_std)^2, dbv_var = exp(dbv_log_std)^2 + y_pred[:,4]^2 (the raw
+ * fifth parameter, :499); loss = nlogp - IG(a,b).log_prob(oef_var) - IG(a,b).log_prob(dbv_var) with
+ * tfp InverseGamma.log_prob(x) = a log b - lgamma(a) - (a + 1) log x - b / x. */
+double qbo_synthetic_data_loss_ig(const real *y_true, const real *q, double alpha, double beta,
+                                  int64_t N) {
+    if (!(alpha * beta > 0.0)) return qbo_synthetic_data_loss(y_true, q, N);
+    double acc = 0;
+    const real a = R(alpha), b = R(beta);
+    const real c0 = R(alpha * log(beta) - lgamma(alpha));
+    for (int64_t i = 0; i < N; ++i) {
+        const real *p = q + 5 * i;
+        real so = R(3) * r_tanh(p[1]) - R(1), sd = R(3) * r_tanh(p[3]) - R(1); /* transform_std */
+        real eo = r_exp(so), ed = r_exp(sd);
+        real xo = eo * eo, xd = ed * ed + p[4] * p[4];
+        real lp = (c0 - (a + R(1)) * r_log(xo) - b / xo) + (c0 - (a + R(1)) * r_log(xd) - b / xd);
+        acc += nlogp_one(y_true[3 * i], y_true[3 * i + 1], p) - lp;
+    }
+    return acc / (double)N;
+}
+
 /* ------------------------------------------------------------------------------------------
  * NLL -- fine_tune_loss_fn, model.py:527-568 (per voxel, before the mask multiply :564).
  * ---------------------------------------------------------------------------------------- */

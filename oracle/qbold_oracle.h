@@ -127,6 +127,8 @@ void qbo_logit_mvn_nlogp(const real *y /*[N][2]*/, const real *p /*[N][5]*/, rea
                          int64_t N);
 /* synthetic_data_loss (use_mvg, no r2p loss, no inv-gamma) -- model.py:449-514. */
 double qbo_synthetic_data_loss(const real *y_true /*[N][3]*/, const real *q /*[N][5]*/, int64_t N);
+/* ... plus the fixed inverse-gamma prior on the marginal variances -- model.py:492-507. */
+double qbo_synthetic_data_loss_ig(const real *y_true, const real *q, double alpha, double beta, int64_t N);
 
 /* fine_tune_loss_fn per voxel (return_mean=False, before masking) -- model.py:527-563. */
 void qbo_nll(const qbo_loss_cfg *C, const real *x /*[N][T]*/, const real *mask /*[N]*/,

@@ -252,9 +252,12 @@ __global__ void relu_copy_kernel(const float* __restrict__ in, float* __restrict
 }
 
 // synthetic_data_loss (model.py:449-514) and its gradient: loss_v = -log p(y_true; q)
+// Optional inverse-gamma prior on the two marginal variances (model.py:492-507, use_mvg branch):
+// loss -= log IG(exp(s_o)^2; a, b) + log IG(exp(s_d)^2 + q[4]^2; a, b) -- the RAW fifth parameter, as
+// the reference writes it (:499).  ig_a = 0 switches it off; ig_c0 = lgamma(a) - a log b.
 __global__ void nlogp_bwd_kernel(const float* __restrict__ y_true, int ldy, const float* __restrict__ q,
                                  float* __restrict__ g_q, int ldg, float* __restrict__ loss, float scale,
-                                 int64_t N) {
+                                 float ig_a, float ig_b, float ig_c0, int64_t N) {
     for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < N;
          v += (int64_t)gridDim.x * blockDim.x) {
         float p[5];
@@ -264,15 +267,31 @@ __global__ void nlogp_bwd_kernel(const float* __restrict__ y_true, int ldy, cons
         const qb::LogitObs o = qb::make_obs(y_true[v * ldy], y_true[v * ldy + 1]);
         const float r0 = o.l0 - m.mu_o, r1 = o.l1 - m.mu_d;
         const float w0 = r0 * m.i_so, w1 = r1 * m.i_sd + r0 * m.i_bl;
-        if (loss) loss[v] = 1.8378770664093453f + (m.s_o + m.s_d) + 0.5f * (w0 * w0 + w1 * w1) + o.jac;
+        float lv = 1.8378770664093453f + (m.s_o + m.s_d) + 0.5f * (w0 * w0 + w1 * w1) + o.jac;
         const float th1 = (m.s_o + 1.0f) * (1.0f / 3.0f), th3 = (m.s_d + 1.0f) * (1.0f / 3.0f);
         const float th4 = m.c * 7.38905609893065f;
+        float g1 = (1.0f - w0 * w0 - w1 * r0 * m.i_bl) * 3.0f * (1.0f - th1 * th1);
+        float g3 = (1.0f - w1 * w1) * 3.0f * (1.0f - th3 * th3);
+        float g4 = (w1 * -r0 * m.i_so * m.i_sd) * 0.1353352832366127f * (1.0f - th4 * th4);
+        if (ig_a > 0.0f) {
+            const float xo = 1.0f / (m.i_so * m.i_so);               // exp(s_o)^2
+            const float ed = 1.0f / (m.i_sd * m.i_sd);               // exp(s_d)^2
+            const float xd = ed + p[4] * p[4];
+            // -log IG(x) = lgamma(a) - a log b + (a + 1) log x + b / x
+            lv += 2.0f * ig_c0 + (ig_a + 1.0f) * (logf(xo) + logf(xd)) + ig_b / xo + ig_b / xd;
+            const float do_ = (ig_a + 1.0f) / xo - ig_b / (xo * xo);  // d / d x_o
+            const float dd = (ig_a + 1.0f) / xd - ig_b / (xd * xd);   // d / d x_d
+            g1 += do_ * 2.0f * xo * 3.0f * (1.0f - th1 * th1);
+            g3 += dd * 2.0f * ed * 3.0f * (1.0f - th3 * th3);
+            g4 += dd * 2.0f * p[4];
+        }
+        if (loss) loss[v] = lv;
         float* g = g_q + v * ldg;
         g[0] = scale * -(w0 * m.i_so + w1 * m.i_bl);
-        g[1] = scale * (1.0f - w0 * w0 - w1 * r0 * m.i_bl) * 3.0f * (1.0f - th1 * th1);
+        g[1] = scale * g1;
         g[2] = scale * -(w1 * m.i_sd);
-        g[3] = scale * (1.0f - w1 * w1) * 3.0f * (1.0f - th3 * th3);
-        g[4] = scale * (w1 * -r0 * m.i_so * m.i_sd) * 0.1353352832366127f * (1.0f - th4 * th4);
+        g[3] = scale * g3;
+        g[4] = scale * g4;
     }
 }
 
@@ -652,16 +671,21 @@ extern "C" int qbold_smoothness(const qbold_ctx* ctx, const float* q, const floa
     return QBOLD_OK;
 }
 
-// synthetic_data_loss (model.py:449-514, use_mvg, no r2p / inverse-gamma terms) and its gradient
-// with respect to q: loss_v [N] (may be NULL), g_q [N][5] = scale * d loss_v / d q.
+// synthetic_data_loss (model.py:449-514, use_mvg, no r2p term) and its gradient with respect to q:
+// loss_v [N] (may be NULL), g_q [N][5] = scale * d loss_v / d q.
 extern "C" int qbold_synth_loss_bwd(const qbold_ctx* ctx, const float* y_true, int ld_y, const float* q,
-                                    float* g_q, float* loss_v, float scale, int64_t N, void* stream) {
+                                    float* g_q, float* loss_v, float scale, double inv_gamma_alpha,
+                                    double inv_gamma_beta, int64_t N, void* stream) {
     QB_NEED_DEVICE(ctx);
     QB_REQUIRE(N > 0 && y_true && q && g_q && ld_y >= 2, "qbold_synth_loss_bwd: bad argument");
+    QB_REQUIRE(inv_gamma_alpha >= 0.0 && inv_gamma_beta >= 0.0, "qbold_synth_loss_bwd: negative inverse-gamma parameter");
+    const bool ig = inv_gamma_alpha * inv_gamma_beta > 0.0;  // model.py:492
+    const float ig_a = ig ? (float)inv_gamma_alpha : 0.0f, ig_b = ig ? (float)inv_gamma_beta : 0.0f;
+    const float ig_c0 = ig ? (float)(lgamma(inv_gamma_alpha) - inv_gamma_alpha * log(inv_gamma_beta)) : 0.0f;
     int64_t nb = (N + 255) / 256;
     int64_t cap = (int64_t)ctx->num_cus * 8;
     hipLaunchKernelGGL(nlogp_bwd_kernel, dim3((int)(nb < cap ? nb : cap)), dim3(256), 0,
-                       (hipStream_t)stream, y_true, ld_y, q, g_q, 5, loss_v, scale, N);
+                       (hipStream_t)stream, y_true, ld_y, q, g_q, 5, loss_v, scale, ig_a, ig_b, ig_c0, N);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }

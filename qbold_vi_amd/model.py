@@ -19,6 +19,19 @@ from .init import init_encoder_weights
 from .ops import Context, EncoderWeights
 
 
+def _synth_loss(ctx, y, q, alpha, beta):
+    """Per-voxel pre-training loss through qbold_synth_loss_bwd (the gradient output is discarded)."""
+    from . import _lib
+    from .ops import _ptr, _stream
+    import ctypes as C  # noqa: F401
+    N = q.shape[0]
+    gq = torch.empty((N, 5), dtype=torch.float32, device=q.device)
+    lv = torch.empty(N, dtype=torch.float32, device=q.device)
+    _lib.check(ctx.lib.qbold_synth_loss_bwd(ctx.handle, _ptr(y), int(y.shape[-1]), _ptr(q), _ptr(gq), _ptr(lv),
+                                            1.0, float(alpha), float(beta), N, _stream()), "qbold_synth_loss_bwd")
+    return lv
+
+
 def _flat(t, c):
     return t.reshape(-1, c)
 
@@ -314,12 +327,18 @@ class EncoderTrainer:
 
     def synthetic_data_loss(self, y_true_orig, y_pred_orig, use_r2p_loss=False, inv_gamma_alpha=0.0,
                             inv_gamma_beta=0.0):
-        """Pre-training loss (model.py:449-514): mean negative log density of the true (OEF, DBV)."""
-        if use_r2p_loss or inv_gamma_alpha * inv_gamma_beta > 0.0:
-            raise NotImplementedError("use_r2p_loss / inverse-gamma prior (model.py:475-507) are "
-                                      "disabled in optimal.yaml")
-        y = y_true_orig.reshape(-1, 3)
-        return self._ctx.logit_mvn_nlogp(y[:, :2], _flat(y_pred_orig, 5)).mean()
+        """Pre-training loss (model.py:449-514): mean negative log density of the true (OEF, DBV),
+        plus the inverse-gamma prior on the marginal variances when alpha * beta > 0 (:492-507)."""
+        if use_r2p_loss:
+            raise NotImplementedError("use_r2p_loss (model.py:475-490) is disabled in optimal.yaml")
+        if self._infer_inv_gamma:
+            raise NotImplementedError("infer_inv_gamma (model.py:493-496) is disabled in optimal.yaml")
+        y = y_true_orig.reshape(-1, 3).contiguous()
+        q = _flat(y_pred_orig, 5)
+        if inv_gamma_alpha * inv_gamma_beta > 0.0:
+            lv = _synth_loss(self._ctx, y, q, inv_gamma_alpha, inv_gamma_beta)
+            return lv.mean()
+        return self._ctx.logit_mvn_nlogp(y[:, :2], q).mean()
 
     def calculate_dw(self, oef):  # model.py:516-522
         from .signals import SignalGenerationLayer

@@ -580,8 +580,9 @@ class TrainState:
                    "qbold_encoder_spatial_bwd")
         return self.grad
 
-    def synth_loss_bwd(self, y_true, q):
-        """Pre-training loss (mean over voxels) and its head gradient (already divided by N)."""
+    def synth_loss_bwd(self, y_true, q, inv_gamma_alpha=0.0, inv_gamma_beta=0.0):
+        """Pre-training loss per voxel and its head gradient (already divided by N); optional
+        inverse-gamma prior on the marginal variances (model.py:492-507)."""
         ctx = self.ctx
         y = _f32(y_true, "y_true")
         ld = y.shape[-1]
@@ -589,7 +590,8 @@ class TrainState:
         gq = torch.empty((N, 5), dtype=torch.float32, device=q.device)
         lv = torch.empty(N, dtype=torch.float32, device=q.device)
         _lib.check(ctx.lib.qbold_synth_loss_bwd(ctx.handle, _ptr(y), int(ld), _ptr(q), _ptr(gq), _ptr(lv),
-                                                1.0 / N, N, _stream()), "qbold_synth_loss_bwd")
+                                                1.0 / N, float(inv_gamma_alpha), float(inv_gamma_beta), N, _stream()),
+                   "qbold_synth_loss_bwd")
         return lv, gq
 
     def adamw(self, lr, weight_decay, beta1=0.9, beta2=0.999, eps=1e-7):

@@ -148,6 +148,8 @@ def create_and_train_on_synthetic_data(config_dict, params, log=None, sample_siz
     g.manual_seed(1)
     n = tx.shape[0]
     steps = 0
+    ig_a = float(_get(config_dict, "inv_gamma_alpha", 0.0) or 0.0)   # train.py:131-135
+    ig_b = float(_get(config_dict, "inv_gamma_beta", 0.0) or 0.0)
     for epoch in range(int(_get(config_dict, "no_pt_epochs"))):
         perm = torch.randperm(n, generator=g, device=tx.device)
         losses = []
@@ -156,7 +158,7 @@ def create_and_train_on_synthetic_data(config_dict, params, log=None, sample_siz
             a, b = qd.shard_range(idx.numel(), rank, world)
             xb, yb = tx[idx[a:b]], ty[idx[a:b]]
             q1, _ = state.forward(xb, 1)
-            lv, gq = state.synth_loss_bwd(yb, q1)
+            lv, gq = state.synth_loss_bwd(yb, q1, ig_a, ig_b)
             state.backward(1, gq)
             qd.allreduce_mean_(state.grad)
             state.adamw(lr, wd, 0.9, 0.999, 1e-7)
@@ -169,7 +171,7 @@ def create_and_train_on_synthetic_data(config_dict, params, log=None, sample_siz
         out1 = model.predict(vx, want=("out1",))[0] if vx.shape[0] else None
         metrics = {"epoch": epoch, "loss": loss}
         if out1 is not None:
-            metrics["val_loss"] = float(trainer.synthetic_data_loss(vy, out1))
+            metrics["val_loss"] = float(trainer.synthetic_data_loss(vy, out1, False, ig_a, ig_b))
             metrics["val_oef_metric"] = float(trainer.oef_metric(vy, out1))
             metrics["val_dbv_metric"] = float(trainer.dbv_metric(vy, out1))
             metrics["val_r2p_metric"] = float(trainer.r2p_metric(vy, out1))

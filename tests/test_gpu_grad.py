@@ -150,6 +150,49 @@ def test_training_forward_matches_inference_and_oracle(ctx, oracle32, U, L, cw):
     assert torch.allclose(o2, q2, atol=2e-5) and torch.allclose(o1, q1, atol=2e-5)
 
 
+def test_inverse_gamma_prior_loss_and_head_gradient(ctx, oracle32, oracle64):
+    """synthetic_data_loss with inv_gamma_alpha * inv_gamma_beta > 0 (model.py:492-507; the sweep
+    configuration of the reference uses it): value against the oracle, head gradient against central
+    differences of the float64 oracle."""
+    from qbold_vi_amd.ops import EncoderWeights, TrainState
+    rng = np.random.default_rng(21)
+    n, a, b = 400, 3.0, 0.15
+    q = (rng.normal(size=(n, 5)) * 0.5).astype(np.float32)
+    y3 = np.stack([rng.uniform(0.1, 0.7, n), rng.uniform(0.01, 0.15, n), np.ones(n)], -1).astype(np.float32)
+    st = TrainState(ctx, EncoderWeights(ctx, 11, 60, 2, True, -3.0), optimiser_state=False)
+    lv, gq = st.synth_loss_bwd(dev(y3), dev(q), a, b)
+    want = oracle32.synthetic_data_loss(y3, q, a, b)
+    assert abs(float(lv.double().mean()) - want) < 1e-5 * abs(want)
+    lv0, gq0 = st.synth_loss_bwd(dev(y3), dev(q))
+    assert abs(float(lv0.double().mean()) - oracle32.synthetic_data_loss(y3, q)) < 1e-5 * abs(want)
+    assert float((lv - lv0).abs().max()) > 1e-3      # the prior term is there
+    g = gq.cpu().numpy().astype(np.float64) * n       # per-voxel d loss_v / d q
+    q64 = q.astype(np.float64)
+    eps = 1e-5
+    for k in range(5):
+        d = np.zeros((n, 5)); d[:, k] = eps
+        # per-voxel losses are independent: N * d(mean)/dq_v,k via one-voxel-at-a-time is the same as
+        # perturbing all voxels at once and differencing the per-voxel terms
+        lp = np.array([oracle64.synthetic_data_loss(y3[i:i + 1], q64[i:i + 1] + d[i:i + 1], a, b) for i in range(0, n, 8)])
+        lm = np.array([oracle64.synthetic_data_loss(y3[i:i + 1], q64[i:i + 1] - d[i:i + 1], a, b) for i in range(0, n, 8)])
+        fd = (lp - lm) / (2 * eps)
+        got = g[::8, k]
+        assert np.max(np.abs(got - fd) / (np.abs(fd) + 1e-2)) < 2e-3, k
+    # API level: the trainer's loss takes the same arguments as the reference's
+    from qbold_vi_amd import EncoderTrainer
+    import configparser, os
+    cp = configparser.ConfigParser()
+    cp.read(os.path.join(os.path.dirname(__file__), "..", "config"))
+    tr = EncoderTrainer(system_params=dict(cp["DEFAULT"]), no_units=60, use_layer_norm=False, dropout_rate=0.0,
+                        no_intermediate_layers=2, student_t_df=200, initial_im_sigma=0.05, activation_type='relu',
+                        multi_image_normalisation=False, channelwise_gating=True, infer_inv_gamma=False,
+                        use_population_prior=False, use_mvg=True, predict_log_data=False)
+    got = float(tr.synthetic_data_loss(dev(y3).reshape(n, 1, 1, 1, 3), dev(q).reshape(n, 1, 1, 1, 5), False, a, b))
+    assert abs(got - want) < 1e-5 * abs(want)
+    with pytest.raises(NotImplementedError):
+        tr.synthetic_data_loss(dev(y3), dev(q), True, 0.0, 0.0)
+
+
 @pytest.mark.parametrize("U,L,cw", [(60, 2, True), (24, 1, False)])
 def test_pretraining_weight_gradient_directional(ctx, oracle32, oracle64, U, L, cw):
     """d/dw mean_v -log p(y_v; q1(x_v; w)) against central differences of the float64 oracle along

@@ -321,6 +321,21 @@ def test_wls_restatement_matches_sklearn(oracle32, params):
     assert np.median(np.abs(r2[:, 0] / (dw * y[:, 1]) - 1)) < 0.25
 
 
+def test_inverse_gamma_prior_term(oracle64):
+    """model.py:492-507 with fixed alpha / beta against scipy.stats.invgamma (= tfp InverseGamma)."""
+    rng = np.random.default_rng(11)
+    n = 50
+    q = rng.normal(size=(n, 5)) * 0.5
+    y = np.stack([rng.uniform(0.1, 0.7, n), rng.uniform(0.01, 0.15, n), np.ones(n)], -1)
+    base = oracle64.synthetic_data_loss(y, q)
+    assert oracle64.synthetic_data_loss(y, q, 3.0, 0.0) == base       # alpha * beta > 0 gates the term
+    a, b = 3.0, 0.15
+    so, sd = np.tanh(q[:, 1]) * 3 - 1, np.tanh(q[:, 3]) * 3 - 1
+    oef_var, dbv_var = np.exp(so) ** 2, np.exp(sd) ** 2 + q[:, 4] ** 2
+    prior = st.invgamma.logpdf(oef_var, a, scale=b) + st.invgamma.logpdf(dbv_var, a, scale=b)
+    np.testing.assert_allclose(oracle64.synthetic_data_loss(y, q, a, b), base - prior.mean(), rtol=1e-12)
+
+
 def test_moments_and_elbo_composition(oracle64):
     rng = np.random.default_rng(4)
     n, S, K = 30, 3, 5
