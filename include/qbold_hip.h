@@ -269,7 +269,8 @@ int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const f
  *   g_q [N][5], g_log_sigma [N][T]:  m_v * d nll_v/d. + [m_v > 0] * d kl_v/d.   (NOT divided by
  *   sum(m): the caller scales the weight gradient once)
  *   nll_kl, sums, workspace: as qbold_elbo_fwd (same Philox stream -> same loss values).
- * Built for the optimal.yaml configuration (table mode, Gaussian likelihood, linear data). */
+ * Built for the full signal model in table mode; Gaussian or Student-t likelihood, linear or log
+ * data, one- or three-image normalisation (the switches of qbold_loss_cfg). */
 int qbold_elbo_bwd(const qbold_ctx* ctx, const float* x, const float* mask, const float* q,
                    const float* prior, const float* log_sigma, int S, int K, uint64_t seed,
                    int64_t voxel0, float* g_q, float* g_log_sigma, float* nll_kl, double* sums,

@@ -123,10 +123,22 @@ __global__ __launch_bounds__(kBlock) void elbo_bwd_kernel(
                     float gy[T];
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
-                        const float r = fmaf(-sig[t], inv_np, lik.yt[t]) * lik.inv_s[t];
-                        acc = fmaf(r, r, acc);
-                        gls[t] += 1.0f - r * r;          // d/d log sigma_t of log s + r^2 / 2
-                        gy[t] = -r * lik.inv_s[t];       // d nll / d yhat_t
+                        float yp = sig[t] * inv_np, dyp = 1.0f;   // yhat_t and d yp / d yhat_t
+                        if (c.predict_log) {                      // model.py:547-549
+                            dyp = m > 0.0f ? qb::rcpf_(yp) : 0.0f;
+                            yp = m > 0.0f ? __logf(yp) : 0.0f;
+                        }
+                        const float r = (lik.yt[t] - yp) * lik.inv_s[t];
+                        float dr = r;                             // d nll_t / d r
+                        if (c.use_student_t) {                    // -StudentT(df, 0, sigma).log_prob, :557-559
+                            const float w = (c.st_df + 1.0f) * qb::rcpf_(fmaf(r, r, c.st_df));
+                            acc += (c.st_df + 1.0f) * log1pf(r * r * qb::rcpf_(c.st_df)) - 2.0f * c.st_const;
+                            dr = w * r;
+                        } else {
+                            acc = fmaf(r, r, acc);
+                        }
+                        gls[t] += 1.0f - dr * r;                  // d/d log sigma_t of log sigma_t + nll_t(r)
+                        gy[t] = -dr * lik.inv_s[t] * dyp;         // d nll / d yhat_t
                         a1 = fmaf(gy[t], sig[t], a1);
                     }
                     nll_sum += acc;
@@ -246,9 +258,9 @@ extern "C" int qbold_elbo_bwd(const qbold_ctx* ctx, const float* x, const float*
     QB_REQUIRE(sums && workspace, "qbold_elbo_bwd: null sums/workspace");
     QB_REQUIRE(N == 0 || (x && q && prior && log_sigma && g_q && g_log_sigma),
                "qbold_elbo_bwd: null buffer");
-    if (!qb::elbo_fast_path(ctx)) {
-        qb::set_error("qbold_elbo_bwd: gradients are built for the optimal.yaml configuration "
-                      "(full model from the table, Gaussian likelihood on linear data)");
+    if (!(ctx->dev.full_model && ctx->dev.tissue_mode == QBOLD_TISSUE_TABLE)) {
+        qb::set_error("qbold_elbo_bwd: gradients are built for the full signal model in table mode "
+                      "(Gaussian or Student-t likelihood, linear or log data, either normalisation)");
         return QBOLD_ERR_UNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream;

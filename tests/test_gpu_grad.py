@@ -89,6 +89,51 @@ def test_elbo_head_gradients_vs_oracle_fd(ctx, oracle32, oracle64, S, K):
         assert np.max(np.abs(gls[:, t] - fd)) / scale < 2e-3, t
 
 
+@pytest.mark.parametrize("variant", [dict(student_t_df=2.0, multi_image_normalisation=True),
+                                     dict(predict_log_data=True),
+                                     dict(student_t_df=5.0, predict_log_data=True, multi_image_normalisation=True)])
+def test_elbo_head_gradients_loss_variants(params, oracle64, variant):
+    """The likelihood switches of EncoderTrainer (model.py:527-568): Student-t (df < 50; the reference's
+    sweep configuration uses df = 2), log data, three-image normalisation -- forward value against the
+    float32 oracle, head gradients against central differences of the float64 oracle."""
+    from oracle.oracle import Oracle
+    from qbold_vi_amd.ops import Context
+    c = Context(params, True, True, **variant)
+    c.set_grad_node0(False)
+    o32 = Oracle("f32", params, **variant)
+    o64 = Oracle("f64", params, node0_zero=True, **variant)
+    n, S, K, seed = 40, 3, 6, 9
+    x, mask, q, prior, sigma = _case(o32, n, 6)
+    ls = np.log(sigma.astype(np.float64))
+    zs = o32.philox_normals(seed, 0, 0, n, S)
+    zk = o32.philox_normals(seed, 1, 0, n, K)
+    q64 = q.astype(np.float64)
+
+    def loss_v(qq, lss):
+        e = o64.elbo(x, mask, qq, prior, np.exp(lss), zs, zk)
+        return e["nll_v"] * mask + np.where(mask > 0, kl_stopgrad(o64, qq, q64, prior, zk), 0.0)
+
+    sums, gq, gls, nk = c.elbo_bwd(dev(x), dev(mask), dev(q), dev(prior), dev(ls.astype(np.float32)), S, K, seed=seed)
+    want = o32.elbo(x, mask, q, prior, sigma, zs, zk)
+    assert abs((sums[0] + sums[1]).item() / sums[2].item() - want["elbo"]) < 1e-4 * abs(want["elbo"])
+    gq, gls = gq.cpu().numpy(), gls.cpu().numpy()
+    h = 1e-4
+    for k in range(5):
+        d = np.zeros_like(q64)
+        d[:, k] = h
+        fd = (loss_v(q64 + d, ls) - loss_v(q64 - d, ls)) / (2 * h)
+        scale = np.abs(fd).max() + 1e-3
+        assert np.max(np.abs(gq[:, k] - fd)) / scale < 2e-3, (variant, k)
+    for t in (0, 2, 3, 10):
+        d = np.zeros_like(ls)
+        d[:, t] = h
+        fd = (loss_v(q64, ls + d) - loss_v(q64, ls - d)) / (2 * h)
+        scale = np.abs(fd).max() + 1e-3
+        assert np.max(np.abs(gls[:, t] - fd)) / scale < 2e-3, (variant, t)
+    # masked-out voxels carry no gradient
+    assert np.abs(gq[mask == 0]).max() == 0.0 and np.abs(gls[mask == 0]).max() == 0.0
+
+
 def test_elbo_gradient_kl_only_is_exact(ctx, oracle32, oracle64):
     """With the likelihood switched off numerically (huge sigma) the gradient is the KL's, which has
     no Simpson artefact: tight agreement."""
