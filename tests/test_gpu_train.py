@@ -66,6 +66,24 @@ def test_two_phase_training_and_phase_skipping(tmp_path, monkeypatch):
     assert mb.weight_status == training.WeightStatus.PRE_TRAINED
 
 
+def test_sweep_style_configuration_trains(tmp_path, monkeypatch):
+    """The hyper-parameters the reference's sweep file fixes (configurations/sweep_prior.yaml):
+    Student-t likelihood with df = 2, three-image normalisation, an inverse-gamma prior on the
+    pre-training variances, 30 units -- every switch off the optimal.yaml path, through both phases."""
+    from qbold_vi_amd import training
+    monkeypatch.chdir(ROOT)
+    cfg = small_config(tmp_path, no_units=30, student_t_df=2, multi_image_normalisation=True,
+                       inv_gamma_alpha=3.0, inv_gamma_beta=0.15, no_pt_epochs=40, no_ft_epochs=3)
+    model, trainer, hist = training.train_model(cfg, pt_sample_size=200)
+    pt = [h for h in hist if "val_oef_metric" in h]
+    ft = [h for h in hist if "val_elbo" in h]
+    assert len(pt) == 40 and len(ft) == 3
+    assert all(np.isfinite(h["loss"]) for h in hist)
+    assert pt[-1]["loss"] < pt[0]["loss"] - 5.0
+    assert ft[-1]["loss"] < ft[0]["loss"]
+    assert trainer.context.lib is not None and trainer._student_t_df == 2
+
+
 def test_missing_real_data_directory_raises(tmp_path, monkeypatch):
     from qbold_vi_amd import training
     monkeypatch.chdir(ROOT)
