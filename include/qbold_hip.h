@@ -220,6 +220,13 @@ int qbold_kl_fwd(const qbold_ctx* ctx, const float* q, const float* prior, const
 /* mvg_kl closed form, use_population_prior = False (model.py:612-652) -> kl [N]. */
 int qbold_kl_closed(const qbold_ctx* ctx, const float* q, const float* prior, float* kl, int64_t N,
                     void* stream);
+/* kl_loss of the DIAGONAL family (use_mvg = False, use_population_prior = False; model.py:686-721):
+ * tfp LogitNormal.kl_divergence per dimension, closed form.  q, prior [N][5] (columns 0-3 used).
+ * kl_v [N] or NULL; g_q [N][5] or NULL: [m_v > 0] d kl_v / d q is ADDED to columns 0-3 (analytic
+ * KL: no stop-gradient); sums: DEVICE double[3] = (0, sum [m > 0] kl, sum m); workspace as
+ * qbold_elbo_fwd. */
+int qbold_kl_diag(const qbold_ctx* ctx, const float* q, const float* prior, const float* mask, float* kl_v,
+                  float* g_q, double* sums, void* workspace, int64_t N, void* stream);
 
 /* The counter-based normal stream the fused kernels consume: z [N][n][2] for global voxels
  * voxel0 .. voxel0+N-1; stream_id 0 = likelihood draws, 1 = KL draws, 2 = moments, 3 = noise.

@@ -276,6 +276,20 @@ class Oracle:
         self.lib.qbo_logit_mvn_nlogp(self._p(y), self._p(p), self._p(out), C.c_int64(y.shape[0]))
         return out
 
+    def kl_diag(self, q, prior):
+        q = self._a(q, (-1, 5))
+        prior = self._a(prior, (-1, 5))
+        out = np.empty(q.shape[0], self.dtype)
+        self.lib.qbo_kl_diag(self._p(q), self._p(prior), self._p(out), C.c_int64(q.shape[0]))
+        return out
+
+    def logit_gaussian_nlogp(self, y, p):
+        y = self._a(y, (-1, 2))
+        p = self._a(p, (-1, 5))
+        out = np.empty(y.shape[0], self.dtype)
+        self.lib.qbo_logit_gaussian_nlogp(self._p(y), self._p(p), self._p(out), C.c_int64(y.shape[0]))
+        return out
+
     def synthetic_data_loss(self, y_true, q, inv_gamma_alpha=0.0, inv_gamma_beta=0.0):
         y = self._a(y_true, (-1, 3))
         q = self._a(q, (-1, 5))

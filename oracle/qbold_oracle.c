@@ -767,6 +767,47 @@ void qbo_kl_closed(const real *q, const real *prior, real *kl, int64_t N) {
     }
 }
 
+/* kl_loss, diagonal family (use_mvg = False, no population prior) -- model.py:686-716:
+ * tfp LogitNormal(loc, scale=exp(log_std)).kl_divergence = tfp kl_normal_normal of the base Normals:
+ *   b_inv = 1 / b.scale;  d = log(a.scale) - log(b.scale);
+ *   0.5 * squared_difference(a.loc * b_inv, b.loc * b_inv) + 0.5 * expm1(2 d) - d
+ * with log_std = transform_std(raw) (:704-707).  q, prior rows 5 wide, columns 0-3 used. */
+void qbo_kl_diag(const real *q, const real *prior, real *kl, int64_t N) {
+    for (int64_t i = 0; i < N; ++i) {
+        const real *qq = q + 5 * i, *pp = prior + 5 * i;
+        real acc = 0;
+        for (int dim = 0; dim < 2; ++dim) {
+            real a_loc = qq[2 * dim], b_loc = pp[2 * dim];
+            real a_scale = r_exp(transform_std(qq[2 * dim + 1]));
+            real b_scale = r_exp(transform_std(pp[2 * dim + 1]));
+            real b_inv = R(1.0) / b_scale;
+            real d = r_log(a_scale) - r_log(b_scale);
+            real sd = a_loc * b_inv - b_loc * b_inv;
+#ifdef QBO_DOUBLE
+            real em = expm1(R(2.0) * d);
+#else
+            real em = expm1f(R(2.0) * d);
+#endif
+            acc += R(0.5) * (sd * sd) + R(0.5) * em - d;
+        }
+        kl[i] = acc;
+    }
+}
+
+/* logit_gaussian_log_prob (diagonal family, model.py:406-421): NEGATIVE log-density up to the
+ * reference's own constant -- gaussian_nll (:403-404) carries no log sqrt(2 pi).  p rows 5 wide. */
+void qbo_logit_gaussian_nlogp(const real *y, const real *p, real *out, int64_t N) {
+    for (int64_t i = 0; i < N; ++i) {
+        const real *pp = p + 5 * i;
+        real x0 = (y[2 * i] - R(0.04)) / R(0.8), x1 = (y[2 * i + 1] - R(0.001)) / R(0.2); /* backwards_transform */
+        real l0 = r_log(x0) - r_log(R(1.0) - x0), l1 = r_log(x1) - r_log(R(1.0) - x1);     /* logit */
+        real so = transform_std(pp[1]), sd = transform_std(pp[3]);
+        real r0 = (l0 - pp[0]) / r_exp(so), r1 = (l1 - pp[2]) / r_exp(sd);
+        real lo = so + R(0.5) * (r0 * r0), ld = sd + R(0.5) * (r1 * r1);
+        out[i] = lo + ld + (r_log(x0 * (R(1.0) - x0)) + r_log(x1 * (R(1.0) - x1)));
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * Posterior moments -- calculate_means(include_r2p=True, return_stds=True), model.py:326-343.
  * ---------------------------------------------------------------------------------------- */

@@ -94,6 +94,7 @@ SIGNATURES = {
     "qbold_encoder_wide_pack": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, _P]),
     "qbold_encoder_wide_fwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, C.c_int, _P, _P, _P, C.c_int64, _P]),
     "qbold_signal_fwd_ex": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "qbold_kl_diag": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "qbold_wls_fit": (C.c_int, [_P, _P, C.c_double, _P, C.c_int64, _P]),
     "qbold_smoothness": (C.c_int, [_P, _P, _P, C.POINTER(Geometry), C.c_float, _P, _P, _P]),
     "qbold_synth_loss_bwd": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_float, C.c_double, C.c_double, _I64, _P]),

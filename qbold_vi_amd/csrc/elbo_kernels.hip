@@ -350,6 +350,64 @@ extern "C" int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float*
     return QBOLD_OK;
 }
 
+// kl_loss for the diagonal family (use_mvg = False, per-voxel prior): model.py:686-716 with
+// tfp LogitNormal.kl_divergence = kl_normal_normal of the underlying Gaussians,
+//   0.5 ((mu_q - mu_p) / sigma_p)^2 + 0.5 expm1(2 (s_q - s_p)) - (s_q - s_p)   per dimension,
+// s = transform_std(raw).  q / prior rows are 5 wide (the fifth, Cholesky, column is unused).
+// Analytic, so unlike the sampled KL every q parameter carries gradient.
+__global__ __launch_bounds__(256) void kl_diag_kernel(const float* __restrict__ q, const float* __restrict__ prior,
+                                                      const float* __restrict__ mask, float* __restrict__ kl_v,
+                                                      float* __restrict__ g_q, double* __restrict__ partials,
+                                                      int64_t N) {
+    __shared__ double red[3 * 4];
+    float s_kl = 0.0f, s_m = 0.0f;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < N;
+         v += (int64_t)gridDim.x * blockDim.x) {
+        float qv[5], pv[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            qv[k] = q[v * 5 + k];
+            pv[k] = prior[v * 5 + k];
+        }
+        const float m = mask ? mask[v] : 1.0f;
+        const float sqo = qb::transform_std(qv[1]), sqd = qb::transform_std(qv[3]);
+        const float spo = qb::transform_std(pv[1]), spd = qb::transform_std(pv[3]);
+        const float ipo = __expf(-spo), ipd = __expf(-spd);
+        const float do_ = sqo - spo, dd = sqd - spd;
+        const float ro = (qv[0] - pv[0]) * ipo, rd = (qv[2] - pv[2]) * ipd;
+        const float eo = expm1f(2.0f * do_), ed = expm1f(2.0f * dd);
+        const float kl = (0.5f * ro * ro + 0.5f * eo - do_) + (0.5f * rd * rd + 0.5f * ed - dd);
+        if (kl_v) kl_v[v] = kl;
+        if (m > 0.0f) s_kl += kl;   // model.py:718
+        s_m += m;
+        if (g_q && m > 0.0f) {
+            const float to = (sqo + 1.0f) * (1.0f / 3.0f), td = (sqd + 1.0f) * (1.0f / 3.0f);  // tanh(raw)
+            g_q[v * 5 + 0] += ro * ipo;
+            g_q[v * 5 + 1] += eo * 3.0f * (1.0f - to * to);   // d/ds_q = exp(2 (s_q - s_p)) - 1
+            g_q[v * 5 + 2] += rd * ipd;
+            g_q[v * 5 + 3] += ed * 3.0f * (1.0f - td * td);
+        }
+    }
+    qb::block_partials(red, 0.0f, s_kl, s_m, partials);
+}
+
+extern "C" int qbold_kl_diag(const qbold_ctx* ctx, const float* q, const float* prior, const float* mask,
+                             float* kl_v, float* g_q, double* sums, void* workspace, int64_t N,
+                             void* stream) {
+    QB_NEED_DEVICE(ctx);
+    QB_REQUIRE(N >= 0 && sums && workspace, "qbold_kl_diag: null sums/workspace");
+    QB_REQUIRE(N == 0 || (q && prior), "qbold_kl_diag: null buffer");
+    hipStream_t s = (hipStream_t)stream;
+    double* partials = reinterpret_cast<double*>(workspace);
+    const int64_t nb = (N + 255) / 256;
+    const int grid = (int)(nb < qb::elbo_grid(ctx) ? (nb > 0 ? nb : 1) : qb::elbo_grid(ctx));
+    hipLaunchKernelGGL(kl_diag_kernel, dim3(grid), dim3(256), 0, s, q, prior, mask, kl_v, g_q, partials, N);
+    QB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(qb::reduce_partials_kernel, dim3(1), dim3(192), 0, s, partials, grid, sums);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
 extern "C" int qbold_reparam(const qbold_ctx* ctx, const float* q, const float* z, float* oef_dbv,
                              int64_t N, void* stream) {
     QB_NEED_DEVICE(ctx);

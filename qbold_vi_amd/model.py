@@ -32,6 +32,16 @@ def _synth_loss(ctx, y, q, alpha, beta):
     return lv
 
 
+def _pad5(t):
+    """Distribution parameters as the kernels take them: 5 per voxel.  The diagonal family
+    (use_mvg=False, model.py:33-37) is the 5-parameter one with a zero Cholesky term."""
+    if t.shape[-1] == 5:
+        return t
+    if t.shape[-1] != 4:
+        raise ValueError("distribution parameters must have 4 (use_mvg=False) or 5 channels")
+    return torch.cat([t, torch.zeros_like(t[..., :1])], -1)
+
+
 def _flat(t, c):
     return t.reshape(-1, c)
 
@@ -51,22 +61,33 @@ class EncoderModel:
         """Voxel batches go through the fused kernels; image crops [B, X, Y, Z, T] (X or Y > 1) get
         stream 2 with its 3x3x1 'same' convolutions (stream 1 is voxel-wise by construction)."""
         ctx = self._trainer._ctx
+        nq = self._trainer._nq
+        cut = (lambda t: t if t is None or nq == 5 else t[..., :nq].contiguous())
         if not self._trainer._is_spatial(x):
-            return list(ctx.encoder_fwd(self.weights, x, want=want))
-        o1 = ctx.encoder_fwd(self.weights, x, want=("out1",))[0] if "out1" in want else None
+            o1, o2, sg = ctx.encoder_fwd(self.weights, x, want=want)
+            return [cut(o1), cut(o2), sg]
+        o1 = cut(ctx.encoder_fwd(self.weights, x, want=("out1",))[0]) if "out1" in want else None
         o2 = sg = None
         if "out2" in want or "sigma" in want:
             st = self._trainer._spatial_state(self.weights)
             q, ls = st.forward_spatial(x)
-            o2 = q.reshape(x.shape[:-1] + (5,)) if "out2" in want else None
+            o2 = cut(q.reshape(x.shape[:-1] + (5,))) if "out2" in want else None
             sg = ctx.transform("exp", ls).reshape(x.shape) if "sigma" in want else None
         return [o1, o2, sg]
 
     # Weights travel as .npz with the canonical tensor names (Keras HDF5 is SURVEY N3).
     def get_weights(self):
-        return self.weights.to_arrays()
+        w = self.weights.to_arrays()
+        if self._trainer._nq == 4:  # the reference's final layer has 4 outputs (model.py:191-196)
+            w["Wf"], w["bf"] = w["Wf"][:, :4].copy(), w["bf"][:4].copy()
+        return w
 
     def set_weights(self, arrays):
+        arrays = dict(arrays)
+        if np.asarray(arrays["Wf"]).shape[-1] == 4:
+            Wf, bf = np.asarray(arrays["Wf"], np.float32), np.asarray(arrays["bf"], np.float32)
+            arrays["Wf"] = np.concatenate([Wf, np.zeros_like(Wf[:, :1])], 1)
+            arrays["bf"] = np.concatenate([bf, np.zeros(1, np.float32)])
         self.weights.set_from_arrays(arrays)
 
     def save_weights(self, path):
@@ -100,9 +121,8 @@ class ReparamTrickLayer:
     def call(self, inputs, z=None, *args, **kwargs):
         input, mask = inputs
         tr = self._encoder_trainer
-        if not tr._use_mvg:
-            raise NotImplementedError("use_mvg=False (model.py:33-37) is disabled in optimal.yaml")
-        q = _flat(input, input.shape[-1])[:, :5]
+        # use_mvg=False (model.py:33-37): independent draws = the Cholesky form with a zero off-diagonal
+        q = _pad5(_flat(input, input.shape[-1])[:, :tr._nq]).contiguous()
         if z is None:
             z = tr._ctx.normals(q.shape[0], 1, stream_id=0, seed=tr._seed + 104729 * self._draws)
             self._draws += 1
@@ -142,14 +162,19 @@ class FineTuner:
         S = tr._no_samples if no_samples is None else no_samples
         x = _flat(data, data.shape[-1])
         m = None if mask is None else mask.reshape(-1)
+        p5 = _pad5(_flat(prior, prior.shape[-1])).contiguous()
+        K = kl_samples if tr._use_mvg else 0   # diagonal family: closed-form KL below (model.py:686-716)
         if tr._is_spatial(data):
             _, q5, sg5 = self.encoder_model.predict(data, want=("out2", "sigma"))
-            q = _flat(q5, 5)
-            sums, nll_kl = tr._ctx.elbo_fwd(x, m, q, _flat(prior, 5), _flat(sg5, x.shape[-1]), S,
-                                            kl_samples, seed=seed, voxel0=voxel0)
+            q = _pad5(_flat(q5, q5.shape[-1])).contiguous()
+            sums, nll_kl = tr._ctx.elbo_fwd(x, m, q, p5, _flat(sg5, x.shape[-1]), S, K, seed=seed, voxel0=voxel0)
         else:
-            sums, q, nll_kl = tr._ctx.vi_fwd(self.encoder_model.weights, x, m, _flat(prior, 5), S,
-                                             kl_samples, seed=seed, voxel0=voxel0)
+            sums, q, nll_kl = tr._ctx.vi_fwd(self.encoder_model.weights, x, m, p5, S, K, seed=seed, voxel0=voxel0)
+        if not tr._use_mvg:
+            ksums, kl_v = tr._ctx.kl_diag(q, p5, m)
+            sums[1] = ksums[1]
+            nll_kl[:, 1] = kl_v
+            q = q[:, :4].contiguous()
         return dict(sums=sums, q=q, nll_kl=nll_kl, nll=sums[0] / sums[2], kl=sums[1] / sums[2],
                     elbo=(sums[0] + sums[1]) / sums[2])
 
@@ -189,6 +214,7 @@ class EncoderTrainer:
         self._channelwise_gating = channelwise_gating
         self._infer_inv_gamma = infer_inv_gamma
         self._use_mvg = use_mvg
+        self._nq = 5 if use_mvg else 4   # parameters of the predicted distribution (model.py:191-193)
         self._use_population_prior = use_population_prior
         self._mog_components = mog_components
         self._no_samples = no_samples
@@ -208,8 +234,6 @@ class EncoderTrainer:
             unsupported.append(f"activation_type={activation_type!r} (kernels implement 'relu')")
         if infer_inv_gamma:
             unsupported.append("infer_inv_gamma (model.py:201-205)")
-        if not use_mvg:
-            unsupported.append("use_mvg=False (4-parameter posterior)")
         if use_population_prior:
             unsupported.append("use_population_prior (model.py:252-271)")
         if not heteroscedastic_noise:
@@ -255,6 +279,9 @@ class EncoderTrainer:
                                  channelwise_gating=self._channelwise_gating,
                                  resid_init_std=resid_init_std, im_loss_sigma=self._initial_im_sigma,
                                  seed=self._seed, spatial_taps=9)
+        if not self._use_mvg:  # 4 outputs: the Cholesky column of the 5-wide head stays exactly zero
+            w["Wf"][:, 4] = 0.0
+            w["bf"][4] = 0.0
         ew = EncoderWeights(self._ctx, no_ip_images, self._no_units, self._no_intermediate_layers,
                             self._channelwise_gating, gate_offset, spatial_taps=9).set_from_arrays(w)
         return EncoderModel(self, ew), _InnerModel()
@@ -281,7 +308,7 @@ class EncoderTrainer:
 
     # -- sampling / moments (model.py:318-374) -----------------------------------------------
     def create_samples(self, predicted_params, mask, no_samples, seed=None):
-        q = _flat(predicted_params, predicted_params.shape[-1])[:, :5]
+        q = _pad5(_flat(predicted_params, predicted_params.shape[-1])[:, :self._nq]).contiguous()
         z = self._ctx.normals(q.shape[0], no_samples, stream_id=2,
                               seed=self._seed if seed is None else seed)
         qs = q[:, None, :].expand(-1, no_samples, -1).reshape(-1, 5)
@@ -290,7 +317,7 @@ class EncoderTrainer:
 
     def calculate_means(self, predicted_params, mask, include_r2p=False, return_stds=False,
                         no_samples=20, seed=None):
-        q = _flat(predicted_params, predicted_params.shape[-1])[:, :5]
+        q = _pad5(_flat(predicted_params, predicted_params.shape[-1])[:, :self._nq]).contiguous()
         means, var = self._ctx.posterior_moments(q, no_samples, seed=self._seed if seed is None else seed,
                                                  want_vars=return_stds)
         c = 3 if include_r2p else 2
@@ -325,6 +352,14 @@ class EncoderTrainer:
     def calculate_log_chol_det(oef_log_std, dbv_log_std):
         return 2.0 * (oef_log_std + dbv_log_std)
 
+    def logit_gaussian_log_prob(self, observations, predicted_params):
+        """Diagonal family (model.py:406-421): the 5-parameter density with a zero Cholesky term, less
+        the log 2 pi that the reference's gaussian_nll (:403-404) does not carry."""
+        shape = predicted_params.shape[:-1]
+        p = _pad5(_flat(predicted_params, predicted_params.shape[-1])[:, :4]).contiguous()
+        out = self._ctx.logit_mvn_nlogp(observations.reshape(-1, observations.shape[-1])[:, 0:2], p)
+        return (out - 1.8378770664093453).reshape(shape)
+
     def synthetic_data_loss(self, y_true_orig, y_pred_orig, use_r2p_loss=False, inv_gamma_alpha=0.0,
                             inv_gamma_beta=0.0):
         """Pre-training loss (model.py:449-514): mean negative log density of the true (OEF, DBV),
@@ -334,11 +369,12 @@ class EncoderTrainer:
         if self._infer_inv_gamma:
             raise NotImplementedError("infer_inv_gamma (model.py:493-496) is disabled in optimal.yaml")
         y = y_true_orig.reshape(-1, 3).contiguous()
-        q = _flat(y_pred_orig, 5)
+        q = _pad5(_flat(y_pred_orig, y_pred_orig.shape[-1])[:, :self._nq]).contiguous()
+        offset = 0.0 if self._use_mvg else 1.8378770664093453   # logit_gaussian_log_prob, model.py:470
         if inv_gamma_alpha * inv_gamma_beta > 0.0:
             lv = _synth_loss(self._ctx, y, q, inv_gamma_alpha, inv_gamma_beta)
-            return lv.mean()
-        return self._ctx.logit_mvn_nlogp(y[:, :2], q).mean()
+            return lv.mean() - offset
+        return self._ctx.logit_mvn_nlogp(y[:, :2], q).mean() - offset
 
     def calculate_dw(self, oef):  # model.py:516-522
         from .signals import SignalGenerationLayer
@@ -376,8 +412,16 @@ class EncoderTrainer:
         pr = _flat(true, 6)
         return self._ctx.kl_closed(_flat(predicted, 5), pr[:, :5]).reshape(predicted.shape[:-1] + (1,))
 
-    def kl_loss(self, true, predicted, return_mean=True, no_samples=70, seed=None):  # model.py:654-665
+    def kl_loss(self, true, predicted, return_mean=True, no_samples=70, seed=None):  # model.py:654-724
         true = torch.cat([true] * self._no_samples, 0)
+        if not self._use_mvg:  # closed form per dimension, model.py:686-721 (no population prior)
+            pr = _flat(true, 5)   # [p_oef_mean, p_oef_log_std, p_dbv_mean, p_dbv_log_std, mask]
+            _, kl = self._ctx.kl_diag(_pad5(_flat(predicted, predicted.shape[-1])[:, :4]).contiguous(),
+                                      _pad5(pr[:, :4]).contiguous())
+            kl_op = kl.reshape(predicted.shape[:-1] + (1,))
+            mask = true[..., 4:5]
+            kl_op = torch.where(mask > 0, kl_op, torch.zeros_like(kl_op))
+            return kl_op.sum() / mask.sum() if return_mean else kl_op
         kl_op = self.mvg_kl_samples(true, predicted, no_samples=no_samples, seed=seed)
         mask = true[..., 5:6]
         kl_op = torch.where(mask > 0, kl_op, torch.zeros_like(kl_op))
@@ -392,8 +436,8 @@ class EncoderTrainer:
         true_params = torch.cat([true_params] * self._no_samples, 0)
         if not self._is_spatial(pred_params):
             return torch.zeros((), dtype=torch.float32, device=pred_params.device)
-        mask = true_params[..., 5]
-        tv = self._ctx.smoothness(pred_params[..., :5], mask)
+        mask = true_params[..., self._nq]   # model.py:729-734
+        tv = self._ctx.smoothness(_pad5(pred_params[..., :self._nq]).contiguous(), mask)
         return (tv[0] / mask.sum()).float()
 
     def estimate_population_param_distribution(self, model, data):
@@ -447,7 +491,7 @@ class EncoderTrainer:
             if priors is None:
                 raise ValueError("save_predictions with a fine tuner needs the prior maps (train.py:272-279)")
             no_passes = 100
-            out = fine_tuner_model.elbo(data[..., :-1], mask, torch.as_tensor(priors, device=data.device)[..., :5],
+            out = fine_tuner_model.elbo(data[..., :-1], mask, torch.as_tensor(priors, device=data.device)[..., :self._nq],
                                         no_samples=no_passes * self._no_samples, kl_samples=100,
                                         seed=self._seed + 17)
             m = mask.reshape(-1)

@@ -410,6 +410,21 @@ def transform(self, op, x):
 
 
 @_ctx_method
+def kl_diag(self, q, prior, mask=None, g_q=None, per_voxel=True):
+    """Closed-form KL of the diagonal family (use_mvg=False): q, prior [N,5] (columns 0-3 used).
+    Returns (sums double[3] = (0, sum [m>0] kl, sum m), kl_v [N] or None); d kl / d q is added to g_q."""
+    q = _f32(q, "q", 5)
+    prior = _f32(prior, "prior", 5)
+    N = q.numel() // 5
+    mask = _f32(mask, "mask") if mask is not None else None
+    sums = torch.empty(3, dtype=torch.float64, device=q.device)
+    kl = torch.empty(N, dtype=torch.float32, device=q.device) if per_voxel else None
+    _lib.check(self.lib.qbold_kl_diag(self.handle, _ptr(q), _ptr(prior), _ptr(mask), _ptr(kl), _ptr(g_q), _ptr(sums),
+                                      _ptr(self._workspace()), N, _stream()), "qbold_kl_diag")
+    return sums, kl
+
+
+@_ctx_method
 def wls_fit(self, signals, tau_min=0.016):
     """loglinear.fit_wls per voxel: signals [N,T] -> [N,3] = (OEF, DBV, R2'), clipped."""
     x = _f32(signals, "signals", self.T)

@@ -159,6 +159,9 @@ def create_and_train_on_synthetic_data(config_dict, params, log=None, sample_siz
             xb, yb = tx[idx[a:b]], ty[idx[a:b]]
             q1, _ = state.forward(xb, 1)
             lv, gq = state.synth_loss_bwd(yb, q1, ig_a, ig_b)
+            if not trainer._use_mvg:   # logit_gaussian_log_prob (model.py:406-421): no log 2 pi, no Cholesky term
+                gq[:, 4] = 0.0
+                lv = lv - 1.8378770664093453
             state.backward(1, gq)
             qd.allreduce_mean_(state.grad)
             state.adamw(lr, wd, 0.9, 0.999, 1e-7)
@@ -184,11 +187,31 @@ def create_and_train_on_synthetic_data(config_dict, params, log=None, sample_siz
 # ----------------------------------------------------------------------------------------------
 # phase 2: ELBO fine-tuning (train.py:285-376)
 # ----------------------------------------------------------------------------------------------
+def _pad5(t):
+    from .model import _pad5 as pad
+    return pad(t).contiguous()
+
+
+def _elbo_bwd(trainer, x, mask, q, prior5, ls, S, K, seed, voxel0):
+    """Head gradients of m nll + [m > 0] kl.  Diagonal family (use_mvg=False): the sampled KL is
+    replaced by the closed form (model.py:686-716), whose gradient reaches every q parameter, and the
+    unused Cholesky column carries no gradient."""
+    ctx = trainer.context
+    if trainer._use_mvg:
+        sums, gq, gls, _ = ctx.elbo_bwd(x, mask, q, prior5, ls, S, K, seed=seed, voxel0=voxel0)
+        return sums, gq, gls
+    sums, gq, gls, _ = ctx.elbo_bwd(x, mask, q, prior5, ls, S, 0, seed=seed, voxel0=voxel0)
+    gq[:, 4] = 0.0
+    ksums, _ = ctx.kl_diag(q, prior5, mask, g_q=gq, per_voxel=False)
+    sums[1] = ksums[1]
+    return sums, gq, gls
+
+
 def prepare_voxel_dataset(data, mask, model):
     """Voxel-batch counterpart of train.prepare_dataset (train.py:17-72): data are masked, the
     stream-1 output of the (pre-trained) model is the per-voxel prior."""
     x = (data * mask[:, None]).contiguous()
-    prior = model.predict(x, want=("out1",))[0]
+    prior = _pad5(model.predict(x, want=("out1",))[0])
     return x, mask.contiguous(), prior
 
 
@@ -203,7 +226,7 @@ class CropDataset:
         self.mask = real_data[..., -1].contiguous()
         self.data = (real_data[..., :-1] * real_data[..., -1:]).contiguous()
         self.crop = [min(crop_size, self.data.shape[1]), min(crop_size, self.data.shape[2])]
-        self.prior = model.predict(self.data, want=("out1",))[0]
+        self.prior = _pad5(model.predict(self.data, want=("out1",))[0])
         self.batch = 38 if training else 3  # train.py:66-70
         self.training = training
         self._cursor = 0
@@ -248,8 +271,8 @@ def _train_full_model_crops(config_dict, trainer, full_model, study_dataset, tra
             x5, m5, p5 = train_dataset.next_batch(g)
             n = m5.numel()
             q, ls = state.forward_spatial(x5)
-            sums, gq, gls, _ = ctx.elbo_bwd(x5.reshape(n, -1), m5.reshape(n), q, p5.reshape(n, 5), ls, S,
-                                            kl_samples, seed=1000 + step, voxel0=rank * n)
+            sums, gq, gls = _elbo_bwd(trainer, x5.reshape(n, -1), m5.reshape(n), q, p5.reshape(n, 5), ls, S,
+                                      kl_samples, 1000 + step, rank * n)
             tv = ctx.smoothness(q.reshape(m5.shape + (5,)), m5, weight=sw, g_q=gq)
             red = torch.cat([sums, tv])
             if world > 1:
@@ -278,7 +301,7 @@ def _train_full_model_crops(config_dict, trainer, full_model, study_dataset, tra
                 nll_b += float(out["nll"])
             vn += nll_b / 10.0
             vk += float(out["kl"])
-            vs += float(ctx.smoothness(out["q"].reshape(m5.shape + (5,)), m5)[0] / m5.sum())
+            vs += float(ctx.smoothness(_pad5(out["q"]).reshape(m5.shape + (5,)), m5)[0] / m5.sum())
         vn, vk, vs = vn / 4, vk / 4, vs / 4
         metrics.update({"val_nll": vn, "val_elbo": vn + vk, "val_elbo_smooth": vn + vk * 1.0 + vs * sw,
                         "val_smoothness": vs, "val_smoothness_scaled": vs * sw, "val_kl": vk})
@@ -318,7 +341,7 @@ def train_full_model(config_dict, trainer, full_model, study_dataset, train_data
             sel = idx[a:b]
             xb, mb, pb = x[sel], mask[sel], prior[sel]
             q2, ls = state.forward(xb, 2)
-            sums, gq, gls, _ = ctx.elbo_bwd(xb, mb, q2, pb, ls, S, kl_samples, seed=1000 + step, voxel0=a)
+            sums, gq, gls = _elbo_bwd(trainer, xb, mb, q2, pb, ls, S, kl_samples, 1000 + step, a)
             qd.allreduce_sums(sums)          # global sum(mask) before the gradient is normalised
             state.backward(2, gq, gls, sums)
             if world > 1:

@@ -246,3 +246,80 @@ def test_fit_wls_matches_loglinear_restatement(oracle32, params, tmp_path, monke
     bad = Context(dict(params, tau_start="-0.015"), True, True)
     with pytest.raises(RuntimeError, match="no tau equals 0"):
         bad.wls_fit(torch.ones(4, bad.T, device="cuda"))
+
+
+def test_diagonal_family_use_mvg_false(params, oracle32):
+    """use_mvg=False is the reference's argparse default (train.py:181): 4-parameter predictions,
+    independent draws, closed-form KL (model.py:33-37, 191-193, 406-421, 686-721)."""
+    from oracle.oracle import Oracle, synth_inputs
+    from qbold_vi_amd import EncoderTrainer, SignalGenerationLayer
+    tr = EncoderTrainer(system_params=params, no_units=30, use_layer_norm=False, dropout_rate=0.0,
+                        no_intermediate_layers=1, student_t_df=2, initial_im_sigma=0.08, activation_type='relu',
+                        multi_image_normalisation=True, channelwise_gating=True, infer_inv_gamma=False,
+                        use_population_prior=False, use_mvg=False, predict_log_data=True, no_samples=2)
+    orc = Oracle("f32", params, multi_image_normalisation=True, predict_log_data=True, student_t_df=2)
+    model, _ = tr.create_encoder(gate_offset=0.0, resid_init_std=0.1, no_ip_images=11)
+    w = model.get_weights()
+    assert w["Wf"].shape == (30, 4) and w["bf"].shape == (4,)
+    model.set_weights(w)                                   # round trip through the 4-column form
+    n = 600
+    x, y = synth_inputs(n, seed=3, oracle=oracle32)
+    xd = dev(x).reshape(n, 1, 1, 1, 11)
+    o1, o2, sg = model.predict(xd)
+    assert o1.shape == o2.shape == (n, 1, 1, 1, 4)
+    w5 = dict(w, Wf=np.concatenate([w["Wf"], np.zeros((30, 1), np.float32)], 1), bf=np.concatenate([w["bf"], [0.0]]).astype(np.float32),
+              gate_offset=0.0, meta=dict(T=11, U=30, L=1, channelwise_gating=True, taps=9))
+    w1, w2, wsg = orc.encoder_fwd(w5, x)
+    assert np.abs(o2.reshape(n, 4).cpu().numpy() - w2[:, :4]).max() < 2e-5 and np.abs(w2[:, 4]).max() == 0.0
+    # pre-training loss: logit_gaussian_log_prob
+    y3 = np.concatenate([y, y[:, :1]], -1).astype(np.float32)
+    got = float(tr.synthetic_data_loss(dev(y3).reshape(n, 1, 1, 1, 3), o1))
+    want = float(orc.logit_gaussian_nlogp(y, w1).mean())
+    assert abs(got - want) < 1e-4 * abs(want) + 1e-5
+    lp = tr.logit_gaussian_log_prob(dev(y), o1)
+    np.testing.assert_allclose(lp.reshape(-1).cpu().numpy(), orc.logit_gaussian_nlogp(y, w1), rtol=1e-4, atol=1e-4)
+    # closed-form KL through kl_loss: true = [prior (4), mask]
+    mask = (np.random.default_rng(1).uniform(size=n) > 0.2).astype(np.float32)
+    true = torch.cat([o1, dev(mask).reshape(n, 1, 1, 1, 1)], -1)
+    q_t = torch.cat([o2, o2], 0)                             # no_samples = 2: the S-fold tiled distribution
+    kl = float(tr.kl_loss(true, q_t))
+    klv = orc.kl_diag(w2, w1)
+    assert abs(kl - float(np.where(mask > 0, klv, 0).sum() / mask.sum())) < 1e-4 * abs(kl) + 1e-6
+    # ELBO: sampled NLL (Student-t, log data, 3-image normalisation) + closed-form KL
+    full = tr.build_fine_tuner(model, SignalGenerationLayer(dict(params, simulate_noise='False'), True, True))
+    out = full.elbo(xd, dev(mask).reshape(n, 1, 1, 1, 1), o1, no_samples=4, seed=5)
+    zs = orc.philox_normals(5, 0, 0, n, 4)
+    e = orc.elbo(x, mask, w2, w1, wsg, zs, np.zeros((n, 1, 2), np.float32))
+    assert abs(float(out["nll"]) - e["sums"][0] / e["sums"][2]) < 1e-4 * abs(float(out["nll"]))
+    assert abs(float(out["kl"]) - kl) < 1e-5 * abs(kl) + 1e-7
+    assert out["q"].shape == (n, 4)
+    # sampling: independent normals per dimension
+    s = tr.create_samples(o2, None, 5)
+    assert s.shape == (n, 1, 1, 1, 2, 5)
+    means = tr.calculate_means(o2, None, include_r2p=True)
+    assert means.shape == (n, 1, 1, 1, 3) and bool(torch.isfinite(means).all())
+
+
+def test_kl_diag_gradient(params, oracle32):
+    from oracle.oracle import Oracle
+    from qbold_vi_amd.ops import Context
+    ctx = Context(params, True, True)
+    o64 = Oracle("f64", params)
+    rng = np.random.default_rng(2)
+    n = 300
+    q = (rng.normal(size=(n, 5)) * 0.5).astype(np.float32)
+    p = (rng.normal(size=(n, 5)) * 0.5).astype(np.float32)
+    mask = (rng.uniform(size=n) > 0.3).astype(np.float32)
+    g = torch.full((n, 5), 0.25, device="cuda")
+    sums, kl = ctx.kl_diag(dev(q), dev(p), dev(mask), g_q=g)
+    want = oracle32.kl_diag(q, p)
+    np.testing.assert_allclose(kl.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+    assert abs(float(sums[1]) - float(want[mask > 0].astype(np.float64).sum())) < 1e-5 * float(sums[1])
+    assert float(sums[2]) == float(mask.sum()) and float(sums[0]) == 0.0
+    g = g.cpu().numpy() - 0.25                                # the gradient is ADDED
+    assert np.abs(g[mask == 0]).max() == 0.0 and np.abs(g[:, 4]).max() == 0.0
+    q64 = q.astype(np.float64)
+    for k in range(4):
+        d = np.zeros_like(q64); d[:, k] = 1e-6
+        fd = (o64.kl_diag(q64 + d, p) - o64.kl_diag(q64 - d, p)) / 2e-6
+        np.testing.assert_allclose(g[mask > 0, k], fd[mask > 0], rtol=2e-4, atol=2e-5)

@@ -84,6 +84,26 @@ def test_sweep_style_configuration_trains(tmp_path, monkeypatch):
     assert trainer.context.lib is not None and trainer._student_t_df == 2
 
 
+def test_reference_argparse_defaults_train(tmp_path, monkeypatch):
+    """`python train.py` without a YAML uses get_defaults() (train.py:150-187): the diagonal family
+    (use_mvg=False), Student-t df = 2, log data, 3-image normalisation, 30 units, one block."""
+    from qbold_vi_amd import training
+    from qbold_vi_amd.utils import load_arguments
+    monkeypatch.chdir(ROOT)
+    args = load_arguments(["train.py"], entry="train")
+    assert args["use_mvg"] is False and args["predict_log_data"] is True and args["student_t_df"] == 2
+    args.update(save_directory=str(tmp_path), synthetic_voxels=20000, no_pt_epochs=40, no_ft_epochs=3, pt_lr=2e-3)
+    model, trainer, hist = training.train_model(args, pt_sample_size=200)
+    pt = [h for h in hist if "val_oef_metric" in h]
+    ft = [h for h in hist if "val_elbo" in h]
+    assert len(pt) == 40 and len(ft) == 3 and all(np.isfinite(h["loss"]) for h in hist)
+    assert pt[-1]["loss"] < pt[0]["loss"] - 3.0
+    assert ft[-1]["loss"] < ft[0]["loss"]
+    w = model.get_weights()
+    assert w["Wf"].shape == (30, 4)
+    assert np.abs(model.weights.to_arrays()["Wf"][:, 4]).max() == 0.0    # the unused head column never moves
+
+
 def test_missing_real_data_directory_raises(tmp_path, monkeypatch):
     from qbold_vi_amd import training
     monkeypatch.chdir(ROOT)

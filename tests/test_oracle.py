@@ -336,6 +336,38 @@ def test_inverse_gamma_prior_term(oracle64):
     np.testing.assert_allclose(oracle64.synthetic_data_loss(y, q, a, b), base - prior.mean(), rtol=1e-12)
 
 
+def test_diagonal_family_restatements(oracle64):
+    """use_mvg=False (the reference's argparse default): closed-form KL = sum of two univariate Gaussian
+    KLs (what tfp LogitNormal.kl_divergence returns), and logit_gaussian_log_prob = the product of two
+    scipy logit-normal densities without the (2 pi)^-1 the reference leaves out (model.py:403-421)."""
+    rng = np.random.default_rng(13)
+    n = 200
+    q, p = rng.normal(size=(n, 5)) * 0.6, rng.normal(size=(n, 5)) * 0.6
+    want = 0.0
+    for d in (0, 2):
+        sq, sp = np.exp(np.tanh(q[:, d + 1]) * 3 - 1), np.exp(np.tanh(p[:, d + 1]) * 3 - 1)
+        want = want + np.log(sp / sq) + (sq ** 2 + (q[:, d] - p[:, d]) ** 2) / (2 * sp ** 2) - 0.5
+    np.testing.assert_allclose(oracle64.kl_diag(q, p), want, rtol=1e-10, atol=1e-12)
+    # the Cholesky column is ignored
+    q2 = q.copy(); q2[:, 4] += 1.0
+    np.testing.assert_array_equal(oracle64.kl_diag(q2, p), oracle64.kl_diag(q, p))
+    # with a zero Cholesky term the 5-parameter closed form (model.py:612-652) is exact and agrees
+    q0, p0 = q.copy(), p.copy(); q0[:, 4] = 0; p0[:, 4] = 0
+    np.testing.assert_allclose(oracle64.kl_closed(q0, p0), want, rtol=1e-9, atol=1e-11)
+    y = np.stack([rng.uniform(0.06, 0.8, n), rng.uniform(0.003, 0.19, n)], -1)
+    x0, x1 = (y[:, 0] - 0.04) / 0.8, (y[:, 1] - 0.001) / 0.2
+    lg = lambda x: np.log(x) - np.log1p(-x)
+    so, sd = np.tanh(q[:, 1]) * 3 - 1, np.tanh(q[:, 3]) * 3 - 1
+    # density of logit-normal x: N(logit x; mu, s) / (x (1 - x)); the reference ADDS log(x(1-x)) to
+    # the negative log-density (:418) -- restated as written
+    nl = -(st.norm.logpdf(lg(x0), q[:, 0], np.exp(so)) + st.norm.logpdf(lg(x1), q[:, 2], np.exp(sd))) \
+        - np.log(2 * np.pi) + np.log(x0 * (1 - x0)) + np.log(x1 * (1 - x1))
+    np.testing.assert_allclose(oracle64.logit_gaussian_nlogp(y, q), nl, rtol=1e-10)
+    # = the 5-parameter density with a zero Cholesky term, less log 2 pi
+    np.testing.assert_allclose(oracle64.logit_gaussian_nlogp(y, q), oracle64.logit_mvn_nlogp(y, q0) - np.log(2 * np.pi),
+                               rtol=1e-10)
+
+
 def test_moments_and_elbo_composition(oracle64):
     rng = np.random.default_rng(4)
     n, S, K = 30, 3, 5
