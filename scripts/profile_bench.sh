@@ -17,4 +17,4 @@ find $OUT -name "*.csv" | head -50
 mkdir -p gpurun_out/profiles_$TAG
 cp $OUT/trace/*/*_kernel_stats.csv gpurun_out/profiles_$TAG/${TAG}_kernel_stats.csv
 python3 scripts/summarise_prof.py $OUT vi_fwd > gpurun_out/profiles_$TAG/${TAG}_vi_fwd_summary.json
-tail -1 $OUT/bench_trace.log > gpurun_out/profiles_$TAG/${TAG}_bench_under_rocprof.json
+grep -h "\"metric\"" $OUT/bench_trace.log | tail -1 > gpurun_out/profiles_$TAG/${TAG}_bench_under_rocprof.json
