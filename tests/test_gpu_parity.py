@@ -335,6 +335,35 @@ def test_vi_fwd_sharding_invariance(ctx, weights, oracle32):
     assert torch.allclose(a + b, full, rtol=1e-12)
 
 
+def test_vi_fwd_ragged_and_empty_batches(ctx, weights, oracle32):
+    """Batch sizes around the 16-voxel wave tile and the 256-voxel block pass, a single voxel, and
+    the empty batch: each voxel's outputs do not depend on what else is in the batch."""
+    from oracle.oracle import synth_inputs
+    w, ew = weights
+    x, _ = synth_inputs(300, seed=8, oracle=oracle32)
+    prior = dev(oracle32.encoder_fwd(w, x)[0])
+    xd = dev(x)
+    mask = dev((np.random.default_rng(3).uniform(size=300) > 0.3).astype(np.float32))
+    full, qf, nkf = ctx.vi_fwd(ew, xd, mask, prior, 3, 5, seed=9)
+    for n in (1, 2, 15, 16, 17, 255, 257):
+        s, q, nk = ctx.vi_fwd(ew, xd[:n], mask[:n], prior[:n], 3, 5, seed=9)
+        assert torch.equal(q, qf[:n]) and torch.equal(nk, nkf[:n]), n
+        want = torch.stack([(nkf[:n, 0].double() * mask[:n].double()).sum(),
+                            nkf[:n, 1].double()[mask[:n] > 0].sum(), mask[:n].double().sum()])
+        assert torch.allclose(s, want, rtol=1e-6, atol=1e-9), n
+    s0, q0, nk0 = ctx.vi_fwd(ew, xd[:0], mask[:0], prior[:0], 3, 5, seed=9)
+    assert s0.tolist() == [0.0, 0.0, 0.0] and q0.shape == (0, 5) and nk0.shape == (0, 2)
+    e0, _ = ctx.elbo_fwd(xd[:0], mask[:0], qf[:0], prior[:0], torch.empty((0, 11), device="cuda"), 3, 5, seed=9)
+    assert e0.tolist() == [0.0, 0.0, 0.0]
+    # odd S / K (half-used Philox calls) agree with the oracle too
+    for S, K in ((1, 1), (5, 3)):
+        sums, q, nk = ctx.vi_fwd(ew, xd[:64], None, prior[:64], S, K, seed=2)
+        qn, sg = q.cpu().numpy(), oracle32.encoder_fwd(w, x[:64])[2]
+        want = oracle32.elbo(x[:64], np.ones(64, np.float32), qn, prior[:64].cpu().numpy(), sg,
+                             oracle32.philox_normals(2, 0, 0, 64, S), oracle32.philox_normals(2, 1, 0, 64, K))
+        assert abs(float((sums[0] + sums[1]) / sums[2]) - want["elbo"]) < 1e-4 * abs(want["elbo"]), (S, K)
+
+
 def test_full_size_properties_one_million_voxels(ctx, weights, oracle32, params):
     """BASELINE config 2 at its full size (1,048,576 voxels x 11 tau, S=32, K=70), through the
     properties that do not need the oracle on every voxel: determinism, shard additivity, masking,
