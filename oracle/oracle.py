@@ -116,6 +116,7 @@ class Oracle:
         p = dict(DEFAULT_PARAMS)
         if params is not None:
             p.update({k: params[k] for k in DEFAULT_PARAMS if k in params})
+        self.params = p
         self.phys = _Phys(**{k: float(p[k]) for k in DEFAULT_PARAMS},
                           full_model=int(bool(full_model)), include_blood=int(bool(include_blood)))
         se_idx = int(abs(float(p["tau_start"]) / float(p["tau_step"])))  # model.py:95

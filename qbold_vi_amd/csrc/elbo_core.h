@@ -49,7 +49,8 @@ __device__ __forceinline__ float se_norm(const QbDev& c, const float (&v)[T]) {
 }
 
 // LOGSIG: `sigma` holds log sigma (the encoder's pre-activation, model.py:211-214) instead of sigma.
-template <int T, int SE, bool LOGSIG>
+// PRESCALE (fast path with a compile-time spin-echo index only): yt holds yt / sigma, see sample_sq_fast.
+template <int T, int SE, bool LOGSIG, bool PRESCALE = false>
 __device__ __forceinline__ void prepare_lik(const QbDev& c, const float (&x)[T],
                                             const float (&sigma)[T], float mask, VoxelLik<T>& k) {
     const float inv_nt = rcpf_(se_norm<T, SE>(c, x));
@@ -66,6 +67,10 @@ __device__ __forceinline__ void prepare_lik(const QbDev& c, const float (&x)[T],
             k.inv_s[t] = rcpf_(sigma[t]);
             ls += QB_LN2 * log2f_(sigma[t]);
         }
+    }
+    if (PRESCALE) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) k.yt[t] *= k.inv_s[t];
     }
     k.log_s_sum = c.use_student_t ? ls : ls + (float)T * 0.9189385332046727f;  // log sqrt(2 pi)
     k.mask = mask;
@@ -102,14 +107,27 @@ __device__ __forceinline__ float sample_sq_fast(const FwdLds* L, const QbDev& c,
     const FwdFast fv = fwd_fast(c, oef, dbv);
     float acc = 0.0f;
     if (SE >= 0) {
-        // spin-echo signal first, then each tau's residual as soon as its signal exists: no
-        // T-element signal array is kept live
+        // Spin-echo signal first, then each tau's residual as soon as its signal exists: no T-element
+        // signal array is kept live.  The per-draw factors of the normalised prediction
+        //   yhat_t = (tissue_w 2^(nd F_t) + blood_w 2^(ng B_t)) / (s_se + 1e-3)          model.py:545
+        // go into the exponents (two log2 per draw instead of three multiplies per tau), and the data
+        // arrive pre-divided by sigma (prepare_lik<.., PRESCALE>): r_t = yt_t / s_t - yhat_t / s_t.
         const float s_se = fwd_signal_fast(L, c, fv, SE >= 0 ? SE : 0);
-        const float inv_np = rcpf_(s_se + 1e-3f);  // model.py:545
+        const float inv_np = rcpf_(s_se + 1e-3f);
+        const float lt = log2f_(fv.tissue_w * inv_np), lb = log2f_(fv.blood_w * inv_np);  // log2(0) = -inf: term vanishes
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const float st = (t == SE) ? s_se : fwd_signal_fast(L, c, fv, t);
-            const float r = fmaf(-st, inv_np, k.yt[t]) * k.inv_s[t];
+            float yh;
+            if (t == SE) {
+                yh = s_se * inv_np;
+            } else {
+                const float u = fabsf(fmaf((float)t, fv.ub, fv.ua));
+                const float4 kk = L->tab[(int)u];
+                const float f = __builtin_amdgcn_fractf(u);
+                const float F = fmaf(fmaf(fmaf(kk.w, f, kk.z), f, kk.y), f, kk.x);
+                yh = exp2f_(fmaf(fv.nd, F, lt)) + exp2f_(fmaf(fv.ng, c.blood_B[t], lb));
+            }
+            const float r = fmaf(-yh, k.inv_s[t], k.yt[t]);
             acc = fmaf(r, r, acc);
             // keep at most four table rows (16 VGPRs) in flight: without a compiler barrier all T
             // LDS reads are hoisted to the top of the draw and the kernel spills

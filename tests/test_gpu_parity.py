@@ -255,11 +255,23 @@ def test_elbo_explicit_eps(ctx, weights, oracle32, S, K):
     sums, nk = ctx.elbo_fwd(dev(x), dev(mask), dev(q), dev(prior), dev(sigma), S, K, dev(zs), dev(zk))
     sums = sums.cpu().numpy()
     nk = nk.cpu().numpy()
-    assert rel(nk[:, 0], want["nll_v"], 1.0) < 1e-4
+    # Per-voxel NLL: at one draw per voxel the float32 oracle itself is ~1.2e-4 away from exact
+    # arithmetic (rounding noise of its 129-term float32 Simpson sum, amplified by 1/sigma = 20),
+    # so the bound against it is 2e-4 there; against the float64 evaluation of the same float32
+    # semantics (node 0 removed) the kernel is held to 1e-4 at every S (measured 3e-5 / 1e-5).
+    assert rel(nk[:, 0], want["nll_v"], 1.0) < (2e-4 if S == 1 else 1e-4)
+    from oracle.oracle import Oracle
+    o64 = Oracle("f64", oracle32.params, node0_zero=True)
+    try:
+        truth = o64.elbo(x, mask, q, prior, sigma, zs, zk)
+    finally:
+        o64.lib.qbo_set_node0_zero(0)
+    assert rel(nk[:, 0], truth["nll_v"], 1.0) < 1e-4
     assert np.max(np.abs(nk[:, 1] - want["kl_v"]) / (np.abs(want["kl_v"]) + 1.0)) < 1e-4
     assert sums[2] == want["sums"][2]
     elbo = sums[0] / sums[2] + sums[1] / sums[2]
     assert abs(elbo - want["elbo"]) / abs(want["elbo"]) < 1e-4
+    assert abs(elbo - truth["elbo"]) / abs(truth["elbo"]) < 1e-5
 
 
 def test_elbo_philox_matches_oracle_stream(ctx, weights, oracle32):
