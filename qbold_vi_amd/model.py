@@ -91,9 +91,15 @@ class EncoderModel:
         self.weights.set_from_arrays(arrays)
 
     def save_weights(self, path):
+        if str(path).endswith((".h5", ".hdf5")):   # Keras layout; needs h5py (keras_h5.py)
+            from .keras_h5 import save_keras_h5
+            return save_keras_h5(path, self.get_weights())
         np.savez(path, **self.get_weights())
 
     def load_weights(self, path):
+        if str(path).endswith((".h5", ".hdf5")):
+            from .keras_h5 import load_keras_h5
+            return self.set_weights(load_keras_h5(path))
         with np.load(path) as f:
             self.set_weights({k: f[k] for k in f.files})
 

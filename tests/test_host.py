@@ -197,3 +197,66 @@ def test_nifti_writer_follows_the_nifti1_layout(tmp_path):
     assert struct.unpack_from("<hh", hb, 252) == (1, 1) and struct.unpack_from("<8f", hb, 76)[1:4] == (2.0, 2.0, 3.0)
     with pytest.raises(ValueError):
         nifti.save(arr.astype(np.complex64), str(tmp_path / "c.nii"))
+
+
+class _FakeH5Node(dict):
+    """Stand-in for h5py groups / files: a mapping with .attrs; 'a/b' paths resolve like h5py's."""
+
+    def __init__(self):
+        super().__init__()
+        self.attrs = {}
+
+    def __getitem__(self, key):
+        node = self
+        for part in key.split("/"):
+            node = dict.__getitem__(node, part)
+        return node
+
+
+def test_keras_h5_mapping_by_order_and_shape():
+    """keras_h5.py against an in-memory stand-in for the h5py objects (h5py itself is absent here):
+    Keras layout -> canonical names -> Keras layout, including layer names that do not start at
+    conv3d_1 (Keras numbers layers per process) and the 4-output head of use_mvg=False."""
+    from qbold_vi_amd import keras_h5
+    from qbold_vi_amd.init import init_encoder_weights
+    w = init_encoder_weights(T=11, U=12, L=2, channelwise_gating=True, seed=4, spatial_taps=9)
+    rng = np.random.default_rng(0)
+    for k in ("b0", "bc", "br1", "br2", "bg", "bf"):
+        w[k] = rng.normal(size=w[k].shape).astype(np.float32)
+    var = keras_h5.canonical_to_variables(w)
+    assert len(var) == 6 + 8 * 2 and var[0][1].shape == (1, 1, 1, 11, 12) and var[4][1].shape == (3, 3, 1, 12, 12)
+    # build the file as Keras would after an earlier model shifted the numbering by 7
+    f = _FakeH5Node()
+    shift = lambda n: n if n.startswith("conv3d/") else "conv3d_%d/%s" % (int(n.split("/")[0].split("_")[1]) + 7, n.split("/")[1])
+    groups = [("input_1", []), ("lambda", []), ("conv3d", var[:2]), ("model", var[2:-2]), ("conv3d_sigma", var[-2:])]
+    f.attrs["layer_names"] = [g.encode() for g, _ in groups]
+    for gname, items in groups:
+        g = _FakeH5Node()
+        g.attrs["weight_names"] = [shift(n).encode() for n, _ in items]
+        for n, a in items:
+            node = g
+            parts = shift(n).split("/")
+            for part in parts[:-1]:
+                node = node.setdefault(part, _FakeH5Node()) if part not in node else dict.__getitem__(node, part)
+            dict.__setitem__(node, parts[-1], a)
+        dict.__setitem__(f, gname, g)
+    back = keras_h5.variables_to_canonical(keras_h5.flatten_variables(f))
+    for k in w:
+        if k != "meta":
+            np.testing.assert_array_equal(back[k], w[k])
+    # diagonal family: 4-column final layer
+    w4 = dict(w, Wf=w["Wf"][:, :4], bf=w["bf"][:4])
+    assert keras_h5.variables_to_canonical([a for _, a in keras_h5.canonical_to_variables(w4)])["Wf"].shape == (12, 4)
+    # wrong variable count / shapes are rejected
+    with pytest.raises(ValueError):
+        keras_h5.variables_to_canonical([a for _, a in var[:-1]])
+    bad = [a for _, a in var]
+    bad[4] = bad[4][:, :, :, :, :5]
+    with pytest.raises(ValueError):
+        keras_h5.variables_to_canonical(bad)
+    # without h5py the file entry points say what is missing
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="h5py"):
+            keras_h5.load_keras_h5("nope.h5")
