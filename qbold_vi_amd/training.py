@@ -59,6 +59,13 @@ def get_params(path="config"):
     return dict(cfg["DEFAULT"])
 
 
+def _existing_weights(save_dir, stem):
+    """<save_dir>/<stem>.npz (native), or the reference's Keras <stem>.h5 when only that exists
+    (qbold_build_model.py:29-33; read through keras_h5.py, which needs h5py).  New files are .npz."""
+    npz, h5 = os.path.join(save_dir, stem + ".npz"), os.path.join(save_dir, stem + ".h5")
+    return h5 if (os.path.isfile(h5) and not os.path.isfile(npz)) else npz
+
+
 def create_encoder_model(config_dict, params, device=None):
     """train.create_encoder_model (train.py:430-451) = ModelBuilder.create_encoder_model
     (qbold_build_model.py:59-82).  Returns (model, inner_model, trainer)."""
@@ -449,8 +456,8 @@ def train_model(config_dict, device=None, log=None, pt_sample_size=None, max_pt_
     log = log or MetricsLog(os.path.join(save_dir, "metrics.jsonl") if rank == 0 else None, rank=rank)
     if rank == 0:
         os.makedirs(save_dir, exist_ok=True)
-    pt_path = os.path.join(save_dir, "pt_model.npz")
-    final_path = os.path.join(save_dir, "final_model.npz")
+    pt_path = _existing_weights(save_dir, "pt_model")
+    final_path = _existing_weights(save_dir, "final_model")
     if os.path.isfile(pt_path):  # train.py:197-199
         model, inner_model, trainer = create_encoder_model(config_dict, params, device=device)
         model.load_weights(pt_path)
@@ -521,8 +528,8 @@ class ModelBuilder:
         model, inner_model, trainer = create_encoder_model(config_dict, self.system_params, device=device)
         self.model, self.inner_model, self.trainer = model, inner_model, trainer
         self.save_dir = os.path.join(os.getcwd(), self.config_dict['save_directory'])
-        self.final_model_weights = os.path.join(self.save_dir, 'final_model.npz')
-        self.pt_model_weights = os.path.join(self.save_dir, 'pt_model.npz')
+        self.final_model_weights = _existing_weights(self.save_dir, 'final_model')
+        self.pt_model_weights = _existing_weights(self.save_dir, 'pt_model')
         self.weight_status = self.load_model_weights()
 
     @staticmethod
