@@ -101,11 +101,99 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
     }
 }
 
+// The whole 3x3x1 'same' convolution of one layer in ONE launch (U <= 64):
+//   Y[v] = act(sum_tap X[nbr(v, tap)] K[tap] + b)            (flip = 0, model.py:152-157)
+//   Y[v] = (sum_tap X[nbr(v, -tap)] K[tap]^T) * (mask[v] > 0)  (flip = 1: adjoint wrt the input)
+// A block owns 256 consecutive voxels (4 waves x 4 tiles of 16), keeps their accumulators in registers
+// across the nine taps and re-stages one tap's kernel (<= 64 x 64 floats) in LDS per tap -- instead of
+// nine launches that each read and rewrite the output tensor.  Activation rows are read 16 bytes
+// per lane: in MFMA k-step (q, c) lane group g supplies k = 16 q + 4 g + c (any bijection of k over
+// (step, group) sums the same products), so one float4 load feeds four k-steps.
+__global__ __launch_bounds__(256) void conv9_kernel(const float* __restrict__ X, int ldx, int U,
+                                                    const float* __restrict__ K9, int flip,
+                                                    const float* __restrict__ b, float* __restrict__ Y,
+                                                    int ldy, int act, const float* __restrict__ mask,
+                                                    int ldm, int64_t N, Gather g0) {
+    __shared__ float Wl[64 * kWs];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int64_t nchunk = (N + 255) / 256;
+    for (int64_t chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[tl][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int tap = 0; tap < 9; ++tap) {
+            __syncthreads();  // the previous tap's (or chunk's) readers are done
+            const float* W = K9 + (int64_t)tap * U * U;
+            for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+                const int k = e >> 6, j = e & 63;
+                float v = 0.0f;
+                if (k < U && j < U) v = flip ? W[j * U + k] : W[k * U + j];
+                Wl[k * kWs + j] = v;
+            }
+            __syncthreads();
+            const int dx = tap / 3 - 1, dy = tap % 3 - 1;
+            const Gather gt{g0.X, g0.Y, g0.Z, flip ? -dx : dx, flip ? -dy : dy};
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
+                const int64_t v0 = chunk * 256 + (wave * 4 + tl) * 16;
+                if (v0 >= N) continue;
+                const int64_t va = gather_row(gt, v0 + i < N ? v0 + i : N - 1);
+                if (__builtin_amdgcn_ballot_w64(va >= 0) == 0) continue;  // the whole tile reads padding
+                const float* xr = X + (va < 0 ? 0 : va) * ldx + 4 * g;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (16 * q >= U) break;
+                    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (va >= 0) a = *reinterpret_cast<const float4*>(xr + 16 * q);
+                    const int k0 = 16 * q + 4 * g;
+                    const float ac[4] = {k0 + 0 < U ? a.x : 0.0f, k0 + 1 < U ? a.y : 0.0f,
+                                         k0 + 2 < U ? a.z : 0.0f, k0 + 3 < U ? a.w : 0.0f};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float* wr = Wl + (k0 + c) * kWs + i;
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) acc[tl][m] = QB_MFMA16F(ac[c], wr[16 * m], acc[tl][m]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            const int64_t v0 = chunk * 256 + (wave * 4 + tl) * 16;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int j = 16 * m + i;
+                if (j >= U) continue;
+                const float bj = b ? b[j] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t v = v0 + 4 * g + r;
+                    if (v >= N) continue;
+                    float y = acc[tl][m][r] + bj;
+                    if (act == ACT_RELU) y = fmaxf(y, 0.0f);
+                    if (mask) y = mask[v * ldm + j] > 0.0f ? y : 0.0f;
+                    Y[v * ldy + j] = y;
+                }
+            }
+        }
+    }
+}
+
 // partial[blk][64*64 + 64]: dW[i][j] = sum_v X[v][i] D[v][j] over this block's voxels, then db[j]
+// gridDim.y == 9: blockIdx.y is the tap of a 3x3x1 kernel (gt carries the crop geometry only) and the
+// partials of tap t start at partial + t * gridDim.x * (64*64 + 64).
 __global__ __launch_bounds__(256) void xtd_kernel(const float* __restrict__ X, int ldx, int kdim,
                                                   const float* __restrict__ D, int ldd, int ndim,
                                                   float* __restrict__ partial, int64_t N, Gather gt) {
     __shared__ float red[64 * 64 + 64];
+    if (gridDim.y == 9) {
+        gt.dx = (int)blockIdx.y / 3 - 1;
+        gt.dy = (int)blockIdx.y % 3 - 1;
+        partial += (int64_t)blockIdx.y * gridDim.x * (64 * 64 + 64);
+    }
     for (int e = threadIdx.x; e < 64 * 64 + 64; e += 256) red[e] = 0.0f;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -160,10 +248,17 @@ __global__ __launch_bounds__(256) void xtd_kernel(const float* __restrict__ X, i
 }
 
 // dW[i * ldw + j] (+)= sum_blk partial[blk][i][j]; db[j] (+)= sum_blk partial[blk][4096 + j]
+// gridDim.y == 9: one 3x3x1 kernel -- tap t reads its own partials and writes dW + t * kdim * ndim; the
+// bias gradient comes from tap 0 only.
 __global__ void slab_reduce_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dW,
                                    int ldw, int kdim, int ndim, float* __restrict__ db, int accum) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 64 * 64 + 64) return;
+    if (gridDim.y == 9) {
+        partial += (int64_t)blockIdx.y * nblk * (64 * 64 + 64);
+        dW += (int64_t)blockIdx.y * kdim * ndim;
+        if (blockIdx.y != 0) db = nullptr;
+    }
     double a = 0.0;
     for (int bk = 0; bk < nblk; ++bk) a += (double)partial[(int64_t)bk * (64 * 64 + 64) + e];
     if (e < 64 * 64) {
@@ -358,6 +453,14 @@ struct Launcher {
     // flip = 1 is the adjoint wrt the input (taps mirrored, kernels transposed).
     void conv3x3(const float* X, const float* K9, int U, const float* b, float* Y, int act, int flip,
                  const float* mask, const qbold_geometry& gm) {
+        if (U <= 64 && ld == kLd && !(ctx->dev.debug_skip & 256)) {  // one launch, accumulators in registers
+            const int64_t nb = (N + 255) / 256;
+            const int64_t cap = (int64_t)ctx->num_cus * 4;
+            hipLaunchKernelGGL(conv9_kernel, dim3((unsigned)(nb < cap ? (nb > 0 ? nb : 1) : cap)), dim3(256), 0, s,
+                               X, ld, U, K9, flip, b, Y, ld, act, mask, ld, N, Gather{gm.X, gm.Y, gm.Z, 0, 0});
+            gather = Gather{0, 0, 0, 0, 0};
+            return;
+        }
         for (int tap = 0; tap < 9; ++tap) {
             const int dx = tap / 3 - 1, dy = tap % 3 - 1;
             gather = Gather{gm.X, gm.Y, gm.Z, flip ? -dx : dx, flip ? -dy : dy};
@@ -377,6 +480,14 @@ struct Launcher {
                            gather);
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64 + 255) / 256), dim3(256), 0, s, partial,
                            nblk, dW, ldw, kdim, ndim, db, accum);
+    }
+    // all nine taps of a 3x3x1 kernel gradient in two launches: dK[tap] = X[nbr(., tap)]^T D, db = sum D
+    void xtd9(const float* X, int U, const float* D, float* partial, int nblk, float* dK9, float* db,
+              const qbold_geometry& gm) const {
+        hipLaunchKernelGGL(xtd_kernel, dim3(nblk, 9), dim3(256), 0, s, X, kLd, U, D, kLd, U, partial, N,
+                           Gather{gm.X, gm.Y, gm.Z, 0, 0});
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64 + 255) / 256, 9), dim3(256), 0, s, partial,
+                           nblk, dK9, U, U, U, db, 0);
     }
     int ew() const {
         int64_t nb = (N * ld + 255) / 256;
@@ -410,7 +521,7 @@ constexpr int kSlabBlocks = 128;
 extern "C" int64_t qbold_train_workspace_floats(const qbold_encoder_shape* shape, int64_t N) {
     if (!shape || N < 0) return QBOLD_ERR_INVALID;
     const int64_t slots = 2 + 5 * (int64_t)shape->L + 5;  // activations + 5 delta scratch tensors
-    return slots * N * train_ld(shape->U) + (int64_t)kSlabBlocks * (64 * 64 + 64);
+    return slots * N * train_ld(shape->U) + (int64_t)9 * kSlabBlocks * (64 * 64 + 64);  // 9: taps of a 3x3x1 kernel
 }
 
 static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* w,
@@ -554,19 +665,11 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             k.xw(dE, kLd, G, wb + c.Wg, G, 1, nullptr, dD, U, ACT_NONE, 1, nullptr);
             if (gm) {
                 // second residual conv (3x3x1): dK2[tap] = t[nbr]^T dD; d t_pre = conv^T(dD) * (t > 0) -> dE
-                for (int tap = 0; tap < 9; ++tap) {
-                    k.gather = Gather{gm->X, gm->Y, gm->Z, tap / 3 - 1, tap % 3 - 1};
-                    k.xtd(t, U, dD, U, partial, kSlabBlocks, gb + c.Wr2 + tap * U * U, U,
-                          tap == 0 ? gb + c.br2 : nullptr, 0);
-                }
+                k.xtd9(t, U, dD, partial, kSlabBlocks, gb + c.Wr2, gb + c.br2, *gm);
                 k.conv3x3(dD, wb + c.Wr2, U, nullptr, dE, ACT_NONE, 1, t, *gm);
                 // first residual conv: input relu(b_in)
                 hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, b_in, dD, N * kLd);
-                for (int tap = 0; tap < 9; ++tap) {
-                    k.gather = Gather{gm->X, gm->Y, gm->Z, tap / 3 - 1, tap % 3 - 1};
-                    k.xtd(dD, U, dE, U, partial, kSlabBlocks, gb + c.Wr1 + tap * U * U, U,
-                          tap == 0 ? gb + c.br1 : nullptr, 0);
-                }
+                k.xtd9(dD, U, dE, partial, kSlabBlocks, gb + c.Wr1, gb + c.br1, *gm);
                 k.conv3x3(dE, wb + c.Wr1, U, nullptr, dB, ACT_NONE, 1, b_in, *gm);
             } else {
                 const int ctr = c.taps == 9 ? 4 * U * U : 0;
