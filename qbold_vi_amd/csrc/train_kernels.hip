@@ -56,7 +56,10 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
                                                  Gather gt) {
     extern __shared__ float Wl[];
     const int n0 = blockIdx.y * 64;
-    const int kpad = (kdim + 3) & ~3;
+    // rows of X that are 16-byte aligned are read as float4: in MFMA k-step (q, c) lane group g then
+    // supplies k = 16 q + 4 g + c (any bijection of k over (step, group) sums the same products)
+    const bool vec = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    const int kpad = vec ? (kdim + 15) & ~15 : (kdim + 3) & ~3;
     for (int e = threadIdx.x; e < kpad * 64; e += 256) {
         const int k = e >> 6, j = n0 + (e & 63);
         float v = 0.0f;
@@ -75,12 +78,28 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const float* xr = X + (va < 0 ? 0 : va) * ldx;
-        for (int s = 0; s < ksteps; ++s) {
-            const int k = 4 * s + g;
-            const float a = (k < kdim && va >= 0) ? xr[k] : 0.0f;
-            const float* wr = Wl + k * kWs + i;
+        if (vec) {
+            for (int q = 0; 16 * q < kdim; ++q) {
+                const int k0 = 16 * q + 4 * g;
+                float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (va >= 0 && k0 < kdim) a = *reinterpret_cast<const float4*>(xr + k0);
+                const float ac[4] = {k0 + 0 < kdim ? a.x : 0.0f, k0 + 1 < kdim ? a.y : 0.0f,
+                                     k0 + 2 < kdim ? a.z : 0.0f, k0 + 3 < kdim ? a.w : 0.0f};
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(a, wr[16 * m], acc[m]);
+                for (int c = 0; c < 4; ++c) {
+                    const float* wr = Wl + (k0 + c) * kWs + i;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(ac[c], wr[16 * m], acc[m]);
+                }
+            }
+        } else {
+            for (int s = 0; s < ksteps; ++s) {
+                const int k = 4 * s + g;
+                const float a = (k < kdim && va >= 0) ? xr[k] : 0.0f;
+                const float* wr = Wl + k * kWs + i;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(a, wr[16 * m], acc[m]);
+            }
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -439,7 +458,7 @@ struct Launcher {
     // Y (row stride ldy) = act(X W + b); ndim output columns in slabs of 64
     int xw_ld(const float* X, int ldx, int kdim, const float* W, int ldw, int trans, const float* b,
               float* Y, int ldy, int ndim, int act, int accum, const float* mask) const {
-        const size_t smem = sizeof(float) * (size_t)((kdim + 3) & ~3) * kWs;
+        const size_t smem = sizeof(float) * (size_t)((kdim + 15) & ~15) * kWs;  // room for the float4 k order
         if (smem > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xw_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
