@@ -223,18 +223,34 @@ __global__ __launch_bounds__(256) void xtd_kernel(const float* __restrict__ X, i
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     float dbsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // 16-byte aligned rows are read as float4: tile m of lane i then stands for column 4 i + m instead
+    // of 16 m + i (a permutation of the output rows / columns, undone where the tiles are reduced)
+    const bool vec = ((ldx | ldd) & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D)) & 15) == 0;
     const int64_t nstep = (N + 3) / 4;  // 4 voxels per MFMA k-step
     for (int64_t st = (int64_t)blockIdx.x * 4 + wave; st < nstep; st += (int64_t)gridDim.x * 4) {
         const int64_t v = st * 4 + g;
         const bool ok = v < N;
         const int64_t vx = ok ? gather_row(gt, v) : -1;
         float xa[4], dd[4];
+        if (vec) {
+            float4 x4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = x4;
+            if (vx >= 0 && 4 * i < kdim) x4 = *reinterpret_cast<const float4*>(X + vx * ldx + 4 * i);
+            if (ok && 4 * i < ndim) d4 = *reinterpret_cast<const float4*>(D + v * ldd + 4 * i);
+            const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ds[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int c = 16 * m + i;
-            xa[m] = (vx >= 0 && c < kdim) ? X[vx * ldx + c] : 0.0f;
-            dd[m] = (ok && c < ndim) ? D[v * ldd + c] : 0.0f;
-            dbsum[m] += dd[m];
+            for (int m = 0; m < 4; ++m) {
+                xa[m] = 4 * i + m < kdim ? xs[m] : 0.0f;
+                dd[m] = 4 * i + m < ndim ? ds[m] : 0.0f;
+                dbsum[m] += dd[m];
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int c = 16 * m + i;
+                xa[m] = (vx >= 0 && c < kdim) ? X[vx * ldx + c] : 0.0f;
+                dd[m] = (ok && c < ndim) ? D[v * ldd + c] : 0.0f;
+                dbsum[m] += dd[m];
+            }
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -250,14 +266,17 @@ __global__ __launch_bounds__(256) void xtd_kernel(const float* __restrict__ X, i
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        red[(16 * a + 4 * g + r) * 64 + 16 * c + i] += acc[a][c][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = vec ? 4 * (4 * g + r) + a : 16 * a + 4 * g + r;
+                        const int col = vec ? 4 * i + c : 16 * c + i;
+                        red[row * 64 + col] += acc[a][c][r];
+                    }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 float sm = dbsum[m];
                 sm += __shfl_xor(sm, 16, 64);
                 sm += __shfl_xor(sm, 32, 64);
-                if (g == 0) red[64 * 64 + 16 * m + i] += sm;
+                if (g == 0) red[64 * 64 + (vec ? 4 * i + m : 16 * m + i)] += sm;
             }
         }
         __syncthreads();
