@@ -123,79 +123,69 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
 // The whole 3x3x1 'same' convolution of one layer in ONE launch (U <= 64):
 //   Y[v] = act(sum_tap X[nbr(v, tap)] K[tap] + b)            (flip = 0, model.py:152-157)
 //   Y[v] = (sum_tap X[nbr(v, -tap)] K[tap]^T) * (mask[v] > 0)  (flip = 1: adjoint wrt the input)
-// A block owns 256 consecutive voxels (4 waves x 4 tiles of 16), keeps their accumulators in registers
-// across the nine taps and re-stages one tap's kernel (<= 64 x 64 floats) in LDS per tap -- instead of
-// nine launches that each read and rewrite the output tensor.  Activation rows are read 16 bytes
+// All nine tap kernels (<= 64 x 64 floats each) are staged in LDS once per workgroup (one 1024-thread
+// workgroup per CU); a wave keeps its 16-voxel tile's accumulators in registers across the taps --
+// instead of nine launches that each read and rewrite the output tensor.  Activation rows are read 16 bytes
 // per lane: in MFMA k-step (q, c) lane group g supplies k = 16 q + 4 g + c (any bijection of k over
 // (step, group) sums the same products), so one float4 load feeds four k-steps.
-__global__ __launch_bounds__(256) void conv9_kernel(const float* __restrict__ X, int ldx, int U,
-                                                    const float* __restrict__ K9, int flip,
-                                                    const float* __restrict__ b, float* __restrict__ Y,
-                                                    int ldy, int act, const float* __restrict__ mask,
-                                                    int ldm, int64_t N, Gather g0) {
-    __shared__ float Wl[64 * kWs];
+__global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X, int ldx, int U,
+                                                     const float* __restrict__ K9, int flip,
+                                                     const float* __restrict__ b, float* __restrict__ Y,
+                                                     int ldy, int act, const float* __restrict__ mask,
+                                                     int ldm, int64_t N, Gather g0) {
+    extern __shared__ float Wl[];  // [9][64][kWs]: all nine taps stay resident (146 KiB), one block per CU
+    for (int e = threadIdx.x; e < 9 * 64 * 64; e += 1024) {
+        const int tap = e >> 12, k = (e >> 6) & 63, j = e & 63;
+        const float* W = K9 + (int64_t)tap * U * U;
+        float v = 0.0f;
+        if (k < U && j < U) v = flip ? W[j * U + k] : W[k * U + j];
+        Wl[(tap * 64 + k) * kWs + j] = v;
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
-    const int64_t nchunk = (N + 255) / 256;
-    for (int64_t chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
-        f32x4 acc[4][4];
+    const int64_t ntile = (N + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 16 + wave; tile < ntile; tile += (int64_t)gridDim.x * 16) {
+        const int64_t v0 = tile * 16;
+        f32x4 acc[4];
 #pragma unroll
-        for (int tl = 0; tl < 4; ++tl)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[tl][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         for (int tap = 0; tap < 9; ++tap) {
-            __syncthreads();  // the previous tap's (or chunk's) readers are done
-            const float* W = K9 + (int64_t)tap * U * U;
-            for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-                const int k = e >> 6, j = e & 63;
-                float v = 0.0f;
-                if (k < U && j < U) v = flip ? W[j * U + k] : W[k * U + j];
-                Wl[k * kWs + j] = v;
-            }
-            __syncthreads();
             const int dx = tap / 3 - 1, dy = tap % 3 - 1;
             const Gather gt{g0.X, g0.Y, g0.Z, flip ? -dx : dx, flip ? -dy : dy};
+            const int64_t va = gather_row(gt, v0 + i < N ? v0 + i : N - 1);
+            if (__builtin_amdgcn_ballot_w64(va >= 0) == 0) continue;  // the whole tile reads padding
+            const float* xr = X + (va < 0 ? 0 : va) * ldx + 4 * g;
+            const float* Wt = Wl + tap * 64 * kWs;
 #pragma unroll
-            for (int tl = 0; tl < 4; ++tl) {
-                const int64_t v0 = chunk * 256 + (wave * 4 + tl) * 16;
-                if (v0 >= N) continue;
-                const int64_t va = gather_row(gt, v0 + i < N ? v0 + i : N - 1);
-                if (__builtin_amdgcn_ballot_w64(va >= 0) == 0) continue;  // the whole tile reads padding
-                const float* xr = X + (va < 0 ? 0 : va) * ldx + 4 * g;
+            for (int q = 0; q < 4; ++q) {
+                if (16 * q >= U) break;
+                float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (va >= 0) a = *reinterpret_cast<const float4*>(xr + 16 * q);
+                const int k0 = 16 * q + 4 * g;
+                const float ac[4] = {k0 + 0 < U ? a.x : 0.0f, k0 + 1 < U ? a.y : 0.0f,
+                                     k0 + 2 < U ? a.z : 0.0f, k0 + 3 < U ? a.w : 0.0f};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (16 * q >= U) break;
-                    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (va >= 0) a = *reinterpret_cast<const float4*>(xr + 16 * q);
-                    const int k0 = 16 * q + 4 * g;
-                    const float ac[4] = {k0 + 0 < U ? a.x : 0.0f, k0 + 1 < U ? a.y : 0.0f,
-                                         k0 + 2 < U ? a.z : 0.0f, k0 + 3 < U ? a.w : 0.0f};
+                for (int c = 0; c < 4; ++c) {
+                    const float* wr = Wt + (k0 + c) * kWs + i;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float* wr = Wl + (k0 + c) * kWs + i;
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) acc[tl][m] = QB_MFMA16F(ac[c], wr[16 * m], acc[tl][m]);
-                    }
+                    for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(ac[c], wr[16 * m], acc[m]);
                 }
             }
         }
 #pragma unroll
-        for (int tl = 0; tl < 4; ++tl) {
-            const int64_t v0 = chunk * 256 + (wave * 4 + tl) * 16;
+        for (int m = 0; m < 4; ++m) {
+            const int j = 16 * m + i;
+            if (j >= U) continue;
+            const float bj = b ? b[j] : 0.0f;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int j = 16 * m + i;
-                if (j >= U) continue;
-                const float bj = b ? b[j] : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t v = v0 + 4 * g + r;
-                    if (v >= N) continue;
-                    float y = acc[tl][m][r] + bj;
-                    if (act == ACT_RELU) y = fmaxf(y, 0.0f);
-                    if (mask) y = mask[v * ldm + j] > 0.0f ? y : 0.0f;
-                    Y[v * ldy + j] = y;
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int64_t v = v0 + 4 * g + r;
+                if (v >= N) continue;
+                float y = acc[m][r] + bj;
+                if (act == ACT_RELU) y = fmaxf(y, 0.0f);
+                if (mask) y = mask[v * ldm + j] > 0.0f ? y : 0.0f;
+                Y[v * ldy + j] = y;
             }
         }
     }
@@ -493,8 +483,11 @@ struct Launcher {
                  const float* mask, const qbold_geometry& gm) {
         if (U <= 64 && ld == kLd && !(ctx->dev.debug_skip & 256)) {  // one launch, accumulators in registers
             const int64_t nb = (N + 255) / 256;
-            const int64_t cap = (int64_t)ctx->num_cus * 4;
-            hipLaunchKernelGGL(conv9_kernel, dim3((unsigned)(nb < cap ? (nb > 0 ? nb : 1) : cap)), dim3(256), 0, s,
+            const int64_t cap = (int64_t)ctx->num_cus;
+            const size_t smem = sizeof(float) * 9 * 64 * kWs;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipLaunchKernelGGL(conv9_kernel, dim3((unsigned)(nb < cap ? (nb > 0 ? nb : 1) : cap)), dim3(1024), smem, s,
                                X, ld, U, K9, flip, b, Y, ld, act, mask, ld, N, Gather{gm.X, gm.Y, gm.Z, 0, 0});
             gather = Gather{0, 0, 0, 0, 0};
             return;
