@@ -461,7 +461,7 @@ struct Launcher {
     Gather gather{0, 0, 0, 0, 0};
     int grid() const {
         int64_t nb = (N + 63) / 64;
-        int64_t cap = (int64_t)ctx->num_cus * 8;
+        int64_t cap = (int64_t)ctx->num_cus * 16;  // measured: 8 -> 12.8 ms, 16 -> 12.2 ms, 32 -> 12.3 ms per step
         return (int)(nb < cap ? (nb > 0 ? nb : 1) : cap);
     }
     // Y (row stride ldy) = act(X W + b); ndim output columns in slabs of 64
