@@ -376,6 +376,43 @@ def test_vi_fwd_ragged_and_empty_batches(ctx, weights, oracle32):
         assert abs(float((sums[0] + sums[1]) / sums[2]) - want["elbo"]) < 1e-4 * abs(want["elbo"]), (S, K)
 
 
+def test_vi_fwd_random_configurations(params, oracle32):
+    """A sweep over seeded random cases of the fused kernel: encoder width / depth / gating, draw
+    counts, masks, voxel offsets, gate offsets and weight scales -- ELBO within the north-star
+    tolerance of the oracle on each."""
+    from oracle.oracle import init_weights, synth_inputs
+    from qbold_vi_amd.ops import Context, EncoderWeights
+    ctx = Context(params, True, True)
+    rng = np.random.default_rng(2024)
+    for case in range(12):
+        U = int(rng.choice([8, 17, 32, 47, 60, 64]))
+        L = int(rng.choice([1, 2]))
+        cw = bool(rng.integers(0, 2))
+        S, K = int(rng.integers(1, 40)), int(rng.integers(0, 80))
+        n = int(rng.integers(1, 900))
+        v0 = int(rng.integers(0, 2 ** 40))
+        seed = int(rng.integers(0, 2 ** 62))
+        goff = float(rng.uniform(-3, 1))
+        w = init_weights(T=11, U=U, L=L, channelwise_gating=cw, seed=case, resid_init_std=float(rng.uniform(0.02, 0.2)))
+        for nm in ("b0", "bc", "br1", "br2", "bg", "bf"):
+            w[nm] = (rng.standard_normal(w[nm].shape) * 0.1).astype(np.float32)
+        w["gate_offset"] = goff
+        ew = EncoderWeights(ctx, 11, U, L, cw, goff).set_from_arrays(w)
+        x, _ = synth_inputs(n, seed=case, oracle=oracle32)
+        prior, q_want, sigma = oracle32.encoder_fwd(w, x)
+        mask = (rng.uniform(size=n) > rng.uniform(0, 0.6)).astype(np.float32)
+        if mask.sum() == 0:
+            mask[0] = 1.0
+        sums, q, nk = ctx.vi_fwd(ew, dev(x), dev(mask), dev(prior), S, K, seed=seed, voxel0=v0)
+        assert np.abs(q.cpu().numpy() - q_want).max() < 3e-5, (case, U, L, cw)
+        want = oracle32.elbo(x, mask, q_want, prior, sigma, oracle32.philox_normals(seed, 0, v0, n, S),
+                             oracle32.philox_normals(seed, 1, v0, n, max(K, 1)) if K else np.zeros((n, 1, 2), np.float32))
+        sums = sums.cpu().numpy()
+        got = (sums[0] + sums[1]) / sums[2]
+        ref = want["elbo"] if K else want["sums"][0] / want["sums"][2]
+        assert abs(got - ref) < 1e-4 * abs(ref), (case, U, L, cw, S, K, n, got, ref)
+
+
 def test_full_size_properties_one_million_voxels(ctx, weights, oracle32, params):
     """BASELINE config 2 at its full size (1,048,576 voxels x 11 tau, S=32, K=70), through the
     properties that do not need the oracle on every voxel: determinism, shard additivity, masking,
