@@ -20,11 +20,14 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # RCCL on a real node; QBOLD_DIST_BACKEND=gloo for rehearsals where several ranks share one card
+            backend = os.environ.get("QBOLD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, device_id=torch.device(f"cuda:{local_rank}"))
         else:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local_rank % torch.cuda.device_count())
             dist.init_process_group(backend)
     return rank, world, local_rank
 

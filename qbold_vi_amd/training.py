@@ -451,7 +451,7 @@ def train_model(config_dict, device=None, log=None, pt_sample_size=None, max_pt_
     params = get_params('config')
     rank, world, local_rank = qd.init_from_env()
     if device is None and torch.cuda.is_available():
-        device = f"cuda:{local_rank}"
+        device = f"cuda:{local_rank % torch.cuda.device_count()}"   # one rank per GPU on a real node
     save_dir = _get(config_dict, "save_directory") or "."
     log = log or MetricsLog(os.path.join(save_dir, "metrics.jsonl") if rank == 0 else None, rank=rank)
     if rank == 0:

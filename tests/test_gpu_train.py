@@ -181,3 +181,29 @@ def test_train_py_cli(tmp_path):
     assert os.path.isfile(tmp_path / "run" / "final_model.npz")
     last = json.loads(r.stdout.strip().splitlines()[-1])
     assert np.isfinite(last["val_elbo"])
+
+
+def test_two_rank_training_matches_single_process(tmp_path):
+    """train.py under torchrun with two ranks (sharing this box's one card over gloo -- the launch line
+    the driver uses, with RCCL, on a real node): voxel shards per rank, all-reduced sums and gradients.
+    Every rank applies the same update, so the result equals the single-process run up to the
+    summation order of the gradient all-reduce."""
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configurations", "optimal.yaml")))
+    cfg.update(no_pt_epochs=2, no_ft_epochs=2, no_units=16, no_intermediate_layers=1)
+    env = dict(os.environ, PYTHONPATH=ROOT, QBOLD_DIST_BACKEND="gloo")
+    runs = {}
+    for name, launcher in (("one", [sys.executable]),
+                           ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                    "--master-addr", "127.0.0.1", "--master-port", "29517"])):
+        c = dict(cfg, save_directory=str(tmp_path / name))
+        ypath = tmp_path / f"{name}.yaml"
+        yaml.safe_dump(c, open(ypath, "w"))
+        r = subprocess.run(launcher + [os.path.join(ROOT, "train.py"), str(ypath), "--synthetic_voxels", "4096"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        runs[name] = np.load(tmp_path / name / "final_model.npz")
+    for k in runs["one"].files:
+        a, b = runs["one"][k], runs["two"][k]
+        assert np.isfinite(b).all()
+        np.testing.assert_allclose(b, a, rtol=5e-3, atol=5e-4, err_msg=k)
