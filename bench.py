@@ -123,6 +123,11 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_budget_s", type=float, default=15.0)
     args = ap.parse_args()
+    if os.environ.get("QBOLD_DEBUG_SKIP", "0") not in ("", "0"):
+        # the ablation hooks of the kernels (phases switched off for timing experiments)
+        # must never reach a reported number
+        print("bench.py: QBOLD_DEBUG_SKIP is set -- kernels would skip work; this run is an ablation, not a "
+              "benchmark", file=sys.stderr)
 
     import torch
     import torch.distributed as dist
@@ -252,6 +257,8 @@ def main():
                        "global_voxels": total_vox, "parallelism": f"voxel-shard x{world}",
                        "collective": "all_reduce(3 x f64)/step, overlapped with the next step" if world > 1 else "none"},
             "neg_elbo": neg_elbo,
+            **({"ablation": "QBOLD_DEBUG_SKIP=" + os.environ["QBOLD_DEBUG_SKIP"] + " (NOT a benchmark result)"}
+               if os.environ.get("QBOLD_DEBUG_SKIP", "0") not in ("", "0") else {}),
             "roofline": {"kernel": "vi_fwd_kernel" if args.config == 2 else "wide_dense_kernel (one launch per layer) + elbo_fwd_generic_kernel", "bound": "mfma", "achieved": ach_tf,
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
