@@ -260,3 +260,48 @@ def test_keras_h5_mapping_by_order_and_shape():
     except ImportError:
         with pytest.raises(ImportError, match="h5py"):
             keras_h5.load_keras_h5("nope.h5")
+
+
+def test_crop_dataset_windows_match_the_volumes():
+    """train.prepare_dataset (train.py:17-72) as CropDataset: blank crop [17:-17, 10:-10], masking,
+    random crop_size x crop_size windows over (X, Y) that keep every slice and channel, batches of
+    38 (training) / 3 (validation, subjects in order).  Host index arithmetic only: runs on CPU
+    tensors with a stand-in model."""
+    torch = pytest.importorskip("torch")
+    from qbold_vi_amd.training import CropDataset
+
+    class Model:
+        def predict(self, x, want=("out1",)):
+            # a "prior" that encodes where each voxel came from: (x index, y index, subject, 0, 0)
+            return [self.tag.to(x.dtype)]
+
+    rng = np.random.default_rng(0)
+    S, X, Y, Z, T = 3, 60, 44, 8, 11
+    vol = rng.uniform(0.5, 1.5, (S, X, Y, Z, T + 1)).astype(np.float32)
+    vol[..., -1] = (rng.uniform(size=(S, X, Y, Z)) > 0.3)
+    m = Model()
+    xs, ys, ss = np.meshgrid(np.arange(X - 34), np.arange(Y - 20), np.arange(S), indexing="ij")
+    tag = np.zeros((S, X - 34, Y - 20, Z, 5), np.float32)
+    tag[..., 0] = xs.transpose(2, 0, 1)[..., None]
+    tag[..., 1] = ys.transpose(2, 0, 1)[..., None]
+    tag[..., 2] = ss.transpose(2, 0, 1)[..., None]
+    m.tag = torch.as_tensor(tag)
+    ds = CropDataset(torch.as_tensor(vol), m, crop_size=10, training=True)
+    assert ds.data.shape == (S, X - 34, Y - 20, Z, T) and ds.batch == 38
+    g = torch.Generator().manual_seed(1)
+    x5, m5, p5 = ds.next_batch(g)
+    assert x5.shape == (38, 10, 10, Z, T) and m5.shape == (38, 10, 10, Z) and p5.shape == (38, 10, 10, Z, 5)
+    inner = vol[:, 17:-17, 10:-10]
+    for b in range(38):
+        x0, y0, s = int(p5[b, 0, 0, 0, 0]), int(p5[b, 0, 0, 0, 1]), int(p5[b, 0, 0, 0, 2])
+        win = inner[s, x0:x0 + 10, y0:y0 + 10]
+        np.testing.assert_array_equal(m5[b].numpy(), win[..., -1])
+        np.testing.assert_array_equal(x5[b].numpy(), win[..., :-1] * win[..., -1:])
+        # the prior travels with its voxels
+        np.testing.assert_array_equal(p5[b, :, :, 0, 0].numpy(), (x0 + np.arange(10))[:, None] * np.ones((1, 10)))
+    # crops larger than the volume are clamped (train.py:24); validation walks the subjects in order
+    m.tag = torch.zeros((S, X, Y, Z, 5))
+    dv = CropDataset(torch.as_tensor(vol), m, crop_size=76, training=False, blank_crop=False)
+    assert dv.crop == [60, 44] and dv.batch == 3
+    xa, ma, _ = dv.next_batch(g)
+    np.testing.assert_array_equal(ma.numpy(), vol[..., -1])
