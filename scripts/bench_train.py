@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--S", type=int, default=1)
     ap.add_argument("--K", type=int, default=70)
+    ap.add_argument("--graph", action="store_true")
     a = ap.parse_args()
     os.chdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     params = get_params("config")
@@ -74,6 +75,24 @@ def main():
 
     ms = timed(crop_step)
     out["crop_batch"] = dict(crops=[B, X, Y, Z], voxels=V, ms_per_step=ms, voxels_per_s=V / ms * 1e3)
+    if a.graph:  # how much of the step is launch gaps: replay the same launches from a captured hipGraph
+        sidestream = torch.cuda.Stream()
+        with torch.cuda.stream(sidestream):
+            crop_step()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=sidestream):
+                crop_step()
+            for _ in range(2):
+                g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.steps):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            out["crop_batch_graph_replay_ms"] = e0.elapsed_time(e1) / a.steps
     print(json.dumps(out))
 
 
