@@ -336,26 +336,28 @@ __global__ void gate_fwd_kernel(float* __restrict__ gl, const float* __restrict_
 __global__ void gate_bwd_kernel(const float* __restrict__ d_b, const float* __restrict__ gl,
                                 const float* __restrict__ skip, const float* __restrict__ r,
                                 float* __restrict__ d_skip_pre, float* __restrict__ d_r,
-                                float* __restrict__ d_gl, float offset, int U, int G, int64_t N) {
+                                float* __restrict__ d_gl, float offset, int U, int G, int ld, int64_t N) {
     for (int64_t v = blockIdx.x * (int64_t)(blockDim.x / 64) + (threadIdx.x >> 6); v < N;
          v += (int64_t)gridDim.x * (blockDim.x / 64)) {
-        const int j = threadIdx.x & 63;
-        const int64_t e = v * kLd + j;
-        float dgl = 0.0f, ds = 0.0f, dr = 0.0f;
-        if (j < U) {
-            const float gate = 1.0f / (1.0f + expf(-(gl[v * kLd + (G == 1 ? 0 : j)] + offset)));
-            const float db = d_b[e];
-            ds = skip[e] > 0.0f ? db * (1.0f - gate) : 0.0f;
-            dr = db * gate;
-            dgl = db * (r[e] - skip[e]) * gate * (1.0f - gate);
+        float shared_sum = 0.0f;
+        for (int j = threadIdx.x & 63; j < ld; j += 64) {
+            const int64_t e = v * ld + j;
+            float dgl = 0.0f, ds = 0.0f, dr = 0.0f;
+            if (j < U) {
+                const float gate = 1.0f / (1.0f + expf(-(gl[v * ld + (G == 1 ? 0 : j)] + offset)));
+                const float db = d_b[e];
+                ds = skip[e] > 0.0f ? db * (1.0f - gate) : 0.0f;
+                dr = db * gate;
+                dgl = db * (r[e] - skip[e]) * gate * (1.0f - gate);
+            }
+            d_skip_pre[e] = ds;
+            d_r[e] = dr;
+            if (G == 1) shared_sum += dgl;  // shared gate: sum the contributions of all units
+            else d_gl[e] = dgl;
         }
-        d_skip_pre[e] = ds;
-        d_r[e] = dr;
-        if (G == 1) {  // shared gate: sum the contributions of all units
-            dgl = qb::wave_sum(dgl);
-            d_gl[e] = j == 0 ? dgl : 0.0f;
-        } else {
-            d_gl[e] = dgl;
+        if (G == 1) {
+            shared_sum = qb::wave_sum(shared_sum);
+            for (int j = threadIdx.x & 63; j < ld; j += 64) d_gl[v * ld + j] = j == 0 ? shared_sum : 0.0f;
         }
     }
 }
@@ -420,13 +422,13 @@ __global__ void nlogp_bwd_kernel(const float* __restrict__ y_true, int ldy, cons
 
 // copy g_q [N][5] and g_ls [N][T] into one [N][64] delta tensor (cols 0-4, 5..5+T-1), scaled
 __global__ void head_delta_kernel(const float* __restrict__ g_q, const float* __restrict__ g_ls, int T,
-                                  const double* __restrict__ sums, float* __restrict__ d, int64_t N) {
+                                  const double* __restrict__ sums, float* __restrict__ d, int ld, int64_t N) {
     const float scale = sums ? (float)(1.0 / sums[2]) : 1.0f;  // 1 / sum(mask)
-    const int64_t total = N * kLd;
+    const int64_t total = N * ld;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
-        const int j = (int)(e & 63);
-        const int64_t v = e >> 6;
+        const int j = (int)(e % ld);
+        const int64_t v = e / ld;
         float o = 0.0f;
         if (j < 5) o = g_q[v * 5 + j] * scale;
         else if (g_ls && j < 5 + T) o = g_ls[v * T + j - 5] * scale;
@@ -504,13 +506,17 @@ struct Launcher {
             float* Y, int ndim, int act, int accum, const float* mask) const {
         (void)xw_ld(X, ldx, kdim, W, ldw, trans, b, Y, ld, ndim, act, accum, mask);
     }
-    // dW (+)= X^T D, db (+)= sum D   (U <= 64 only)
+    // dW (+)= X^T D, db (+)= sum D: 64 x 64 slabs of the (kdim x ndim) product, one launch pair per slab
     void xtd(const float* X, int kdim, const float* D, int ndim, float* partial, int nblk, float* dW,
              int ldw, float* db, int accum) const {
-        hipLaunchKernelGGL(xtd_kernel, dim3(nblk), dim3(256), 0, s, X, kLd, kdim, D, kLd, ndim, partial, N,
-                           gather);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64 + 255) / 256), dim3(256), 0, s, partial,
-                           nblk, dW, ldw, kdim, ndim, db, accum);
+        for (int a = 0; a < kdim; a += 64)
+            for (int c = 0; c < ndim; c += 64) {
+                const int ka = kdim - a < 64 ? kdim - a : 64, nc = ndim - c < 64 ? ndim - c : 64;
+                hipLaunchKernelGGL(xtd_kernel, dim3(nblk), dim3(256), 0, s, X + a, ld, ka, D + c, ld, nc, partial, N,
+                                   gather);
+                hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64 + 255) / 256), dim3(256), 0, s, partial,
+                                   nblk, dW + (int64_t)a * ldw + c, ldw, ka, nc, a == 0 && db ? db + c : nullptr, accum);
+            }
     }
     // all nine taps of a 3x3x1 kernel gradient in two launches: dK[tap] = X[nbr(., tap)]^T D, db = sum D
     void xtd9(const float* X, int U, const float* D, float* partial, int nblk, float* dK9, float* db,
@@ -643,31 +649,33 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     QB_NEED_DEVICE(ctx);
     int rc = check_layerwise_shape(ctx, shape);
     if (rc) return rc;
-    if (shape->U > 64) {
-        qb::set_error("qbold_encoder_train_bwd: gradients are built for U <= 64");
+    if (gm && shape->U > 64) {
+        qb::set_error("qbold_encoder_spatial_bwd: the 3x3x1 path is built for U <= 64");
         return QBOLD_ERR_UNSUPPORTED;
     }
     QB_REQUIRE(N > 0 && w && ws && g_q && grad, "qbold_encoder_train_bwd: bad argument");
     QB_REQUIRE(stream_sel == 1 || stream_sel == 2, "qbold_encoder_train_bwd: stream must be 1 or 2");
     const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating, shape->spatial_taps);
     const int T = c.T, U = c.U, L = c.L, G = c.G;
-    Launcher k{ctx, (hipStream_t)stream, N, kLd};
-    auto slot = [&](int i) { return ws + (int64_t)i * N * kLd; };
+    const int ld = train_ld(shape->U);
+    QB_REQUIRE(5 + shape->T <= ld, "qbold_encoder_train_bwd: the head delta (5 + T columns) exceeds the row stride");
+    Launcher k{ctx, (hipStream_t)stream, N, ld};
+    auto slot = [&](int i) { return ws + (int64_t)i * N * ld; };
     const int base = 2 + 5 * L;
     float* dA = slot(base), *dB = slot(base + 1), *dC = slot(base + 2), *dD = slot(base + 3),
           *dE = slot(base + 4);
-    float* partial = ws + (int64_t)(base + 5) * N * kLd;
+    float* partial = ws + (int64_t)(base + 5) * N * ld;
     QB_HIP(hipMemsetAsync(grad, 0, sizeof(float) * c.total, k.s));
     // head delta [N][64]: cols 0-4 = g_q, 5.. = g_ls, scaled by 1 / sum(mask)
     hipLaunchKernelGGL(head_delta_kernel, dim3(k.ew()), dim3(256), 0, k.s, g_q,
-                       stream_sel == 2 ? g_ls : nullptr, T, sums, dA, N);
+                       stream_sel == 2 ? g_ls : nullptr, T, sums, dA, ld, N);
     const float* last = stream_sel == 1 ? slot(2 + L - 1) : slot(6 + 5 * (L - 1));
     // dWf, dbf (and dWs, dbs), d_last = g_q Wf^T (+ g_ls Ws^T)
     k.xtd(last, U, dA, 5, partial, kSlabBlocks, grad + c.Wf, 5, grad + c.bf, 0);
-    k.xw(dA, kLd, 5, w + c.Wf, 5, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
+    k.xw(dA, ld, 5, w + c.Wf, 5, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
     if (stream_sel == 2 && g_ls) {
         k.xtd(last, U, dA + 5, T, partial, kSlabBlocks, grad + c.Ws, T, grad + c.bs, 0);
-        k.xw(dA + 5, kLd, T, w + c.Ws, T, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
+        k.xw(dA + 5, ld, T, w + c.Ws, T, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
     }
     // dB = gradient wrt the last activation tensor
     if (stream_sel == 1) {
@@ -677,9 +685,9 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             const float* a_out = slot(2 + l);
             const float* a_in = l == 0 ? slot(1) : slot(2 + l - 1);
             // through the relu: dC = dB * (a_out > 0)
-            hipLaunchKernelGGL(mask_mul_kernel, dim3(k.ew()), dim3(256), 0, k.s, dB, a_out, dC, N * kLd);
+            hipLaunchKernelGGL(mask_mul_kernel, dim3(k.ew()), dim3(256), 0, k.s, dB, a_out, dC, N * ld);
             k.xtd(a_in, U, dC, U, partial, kSlabBlocks, gb + c.Wc, U, gb + c.bc, 0);
-            k.xw(dC, kLd, U, wb + c.Wc, U, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
+            k.xw(dC, ld, U, wb + c.Wc, U, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
         }
     } else {
         for (int l = L - 1; l >= 0; --l) {
@@ -690,35 +698,35 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             const float* b_in = l == 0 ? slot(1) : slot(6 + 5 * (l - 1));
             // dB = d b_out.  dC = d skip_pre, dD = d r, dE = d gate logits
             hipLaunchKernelGGL(gate_bwd_kernel, dim3(k.grid()), dim3(256), 0, k.s, dB, gl, skip, r, dC, dD,
-                               dE, shape->gate_offset, U, G, N);
+                               dE, shape->gate_offset, U, G, ld, N);
             // gating conv: dWg = r^T dE; d r += dE Wg^T
             k.xtd(r, U, dE, G, partial, kSlabBlocks, gb + c.Wg, G, gb + c.bg, 0);
-            k.xw(dE, kLd, G, wb + c.Wg, G, 1, nullptr, dD, U, ACT_NONE, 1, nullptr);
+            k.xw(dE, ld, G, wb + c.Wg, G, 1, nullptr, dD, U, ACT_NONE, 1, nullptr);
             if (gm) {
                 // second residual conv (3x3x1): dK2[tap] = t[nbr]^T dD; d t_pre = conv^T(dD) * (t > 0) -> dE
                 k.xtd9(t, U, dD, partial, kSlabBlocks, gb + c.Wr2, gb + c.br2, *gm);
                 k.conv3x3(dD, wb + c.Wr2, U, nullptr, dE, ACT_NONE, 1, t, *gm);
                 // first residual conv: input relu(b_in)
-                hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, b_in, dD, N * kLd);
+                hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, b_in, dD, N * ld);
                 k.xtd9(dD, U, dE, partial, kSlabBlocks, gb + c.Wr1, gb + c.br1, *gm);
                 k.conv3x3(dE, wb + c.Wr1, U, nullptr, dB, ACT_NONE, 1, b_in, *gm);
             } else {
                 const int ctr = c.taps == 9 ? 4 * U * U : 0;
                 // second residual conv: dWr2 = t^T dD; d t_pre = (dD Wr2^T) * (t > 0)  -> dE
                 k.xtd(t, U, dD, U, partial, kSlabBlocks, gb + c.Wr2 + ctr, U, gb + c.br2, 0);
-                k.xw(dD, kLd, U, wb + c.Wr2 + ctr, U, 1, nullptr, dE, U, ACT_NONE, 0, t);
+                k.xw(dD, ld, U, wb + c.Wr2 + ctr, U, 1, nullptr, dE, U, ACT_NONE, 0, t);
                 // first residual conv: input relu(b_in): dWr1 = relu(b_in)^T dE; d b_in = (dE Wr1^T) * (b_in > 0)
-                hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, b_in, dD, N * kLd);
+                hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, b_in, dD, N * ld);
                 k.xtd(dD, U, dE, U, partial, kSlabBlocks, gb + c.Wr1 + ctr, U, gb + c.br1, 0);
-                k.xw(dE, kLd, U, wb + c.Wr1 + ctr, U, 1, nullptr, dB, U, ACT_NONE, 0, b_in);
+                k.xw(dE, ld, U, wb + c.Wr1 + ctr, U, 1, nullptr, dB, U, ACT_NONE, 0, b_in);
             }
             // skip conv: dWc = b_in^T dC; d b_in += dC Wc^T
             k.xtd(b_in, U, dC, U, partial, kSlabBlocks, gb + c.Wc, U, gb + c.bc, 0);
-            k.xw(dC, kLd, U, wb + c.Wc, U, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
+            k.xw(dC, ld, U, wb + c.Wc, U, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
         }
     }
     // first layer: delta_pre = dB * (h > 0); dW0 = n^T delta_pre
-    hipLaunchKernelGGL(mask_mul_kernel, dim3(k.ew()), dim3(256), 0, k.s, dB, slot(1), dC, N * kLd);
+    hipLaunchKernelGGL(mask_mul_kernel, dim3(k.ew()), dim3(256), 0, k.s, dB, slot(1), dC, N * ld);
     k.xtd(slot(0), T, dC, U, partial, kSlabBlocks, grad + c.W0, U, grad + c.b0, 0);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;

@@ -238,7 +238,7 @@ def test_inverse_gamma_prior_loss_and_head_gradient(ctx, oracle32, oracle64):
         tr.synthetic_data_loss(dev(y3), dev(q), True, 0.0, 0.0)
 
 
-@pytest.mark.parametrize("U,L,cw", [(60, 2, True), (24, 1, False)])
+@pytest.mark.parametrize("U,L,cw", [(60, 2, True), (24, 1, False), (128, 1, True), (80, 2, False), (96, 1, True)])
 def test_pretraining_weight_gradient_directional(ctx, oracle32, oracle64, U, L, cw):
     """d/dw mean_v -log p(y_v; q1(x_v; w)) against central differences of the float64 oracle along
     random directions in weight space."""
@@ -267,10 +267,14 @@ def test_pretraining_weight_gradient_directional(ctx, oracle32, oracle64, U, L, 
                 direction[k] *= 0
         dflat = EncoderWeights(ctx, 11, U, L, cw, -1.0).set_from_arrays(
             {k: direction[k].astype(np.float32) for k in WEIGHT_NAMES}).flat.cpu().numpy().astype(np.float64)
-        eps = 1e-4
+        # float64 oracle: a small step keeps the number of relu kinks crossed (an O(eps) error in the
+        # difference quotient each) negligible; the tolerance is relative to the size of the per-tensor
+        # contributions, which can cancel in the total
+        eps = 2e-6
         fd = (loss(_perturbed(w, direction, eps)) - loss(_perturbed(w, direction, -eps))) / (2 * eps)
         got = float(grad @ dflat)
-        assert abs(got - fd) < 5e-3 * (abs(fd) + 1e-2), (trial, got, fd)
+        scale = abs(fd) + 1e-3 * float(np.abs(grad * dflat).sum())
+        assert abs(got - fd) < 5e-3 * (scale + 1e-2), (trial, got, fd, scale)
     # tensors that stream 1 does not touch get exactly zero gradient
     g = EncoderWeights(ctx, 11, U, L, cw, -1.0)
     g.flat.copy_(torch.as_tensor(grad, dtype=torch.float32))
@@ -279,7 +283,7 @@ def test_pretraining_weight_gradient_directional(ctx, oracle32, oracle64, U, L, 
         assert np.all(ga[k] == 0)
 
 
-@pytest.mark.parametrize("U,L,cw", [(60, 2, True), (24, 1, False)])
+@pytest.mark.parametrize("U,L,cw", [(60, 2, True), (24, 1, False), (128, 1, True), (80, 2, False)])
 def test_finetune_weight_gradient_directional(ctx, oracle32, oracle64, U, L, cw):
     """d/dw of the masked-mean negative ELBO through encoder stream 2 + sampling, along random
     directions, against the float64 oracle (stop-gradient KL emulated as in kl_stopgrad)."""
@@ -317,7 +321,7 @@ def test_finetune_weight_gradient_directional(ctx, oracle32, oracle64, U, L, cw)
                     direction[k] *= 0
         dflat = EncoderWeights(ctx, 11, U, L, cw, -1.0).set_from_arrays(
             {k: direction[k].astype(np.float32) for k in WEIGHT_NAMES}).flat.cpu().numpy().astype(np.float64)
-        eps = 3e-5
+        eps = 2e-6
         fd = (loss(_perturbed(w, direction, eps)) - loss(_perturbed(w, direction, -eps))) / (2 * eps)
         got = float(grad @ dflat)
         assert abs(got - fd) < 1e-2 * (abs(fd) + 0.05), (trial, got, fd)

@@ -104,6 +104,21 @@ def test_reference_argparse_defaults_train(tmp_path, monkeypatch):
     assert np.abs(model.weights.to_arrays()["Wf"][:, 4]).max() == 0.0    # the unused head column never moves
 
 
+def test_wide_encoder_trains(tmp_path, monkeypatch):
+    """no_units beyond the LDS-resident kernels (128: weight-streaming inference, layer-wise training
+    GEMMs in 64 x 64 slabs) through both training phases."""
+    from qbold_vi_amd import training
+    monkeypatch.chdir(ROOT)
+    cfg = small_config(tmp_path, no_units=128, no_intermediate_layers=1, no_pt_epochs=25, no_ft_epochs=2,
+                       synthetic_voxels=8192)
+    model, trainer, hist = training.train_model(cfg, pt_sample_size=120)
+    pt = [h for h in hist if "val_oef_metric" in h]
+    ft = [h for h in hist if "val_elbo" in h]
+    assert len(pt) == 25 and len(ft) == 2 and all(np.isfinite(h["loss"]) for h in hist)
+    assert pt[-1]["loss"] < pt[0]["loss"] - 3.0
+    assert model.weights.wide
+
+
 def test_missing_real_data_directory_raises(tmp_path, monkeypatch):
     from qbold_vi_amd import training
     monkeypatch.chdir(ROOT)
