@@ -19,19 +19,6 @@ from .init import init_encoder_weights
 from .ops import Context, EncoderWeights
 
 
-def _synth_loss(ctx, y, q, alpha, beta):
-    """Per-voxel pre-training loss through qbold_synth_loss_bwd (the gradient output is discarded)."""
-    from . import _lib
-    from .ops import _ptr, _stream
-    import ctypes as C  # noqa: F401
-    N = q.shape[0]
-    gq = torch.empty((N, 5), dtype=torch.float32, device=q.device)
-    lv = torch.empty(N, dtype=torch.float32, device=q.device)
-    _lib.check(ctx.lib.qbold_synth_loss_bwd(ctx.handle, _ptr(y), int(y.shape[-1]), _ptr(q), _ptr(gq), _ptr(lv),
-                                            1.0, float(alpha), float(beta), N, _stream()), "qbold_synth_loss_bwd")
-    return lv
-
-
 def _pad5(t):
     """Distribution parameters as the kernels take them: 5 per voxel.  The diagonal family
     (use_mvg=False, model.py:33-37) is the 5-parameter one with a zero Cholesky term."""
@@ -378,7 +365,7 @@ class EncoderTrainer:
         q = _pad5(_flat(y_pred_orig, y_pred_orig.shape[-1])[:, :self._nq]).contiguous()
         offset = 0.0 if self._use_mvg else 1.8378770664093453   # logit_gaussian_log_prob, model.py:470
         if inv_gamma_alpha * inv_gamma_beta > 0.0:
-            lv = _synth_loss(self._ctx, y, q, inv_gamma_alpha, inv_gamma_beta)
+            lv = self._ctx.synth_loss(y, q, inv_gamma_alpha, inv_gamma_beta)
             return lv.mean() - offset
         return self._ctx.logit_mvn_nlogp(y[:, :2], q).mean() - offset
 

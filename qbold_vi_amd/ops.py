@@ -410,6 +410,21 @@ def transform(self, op, x):
 
 
 @_ctx_method
+def synth_loss(self, y_true, q, inv_gamma_alpha=0.0, inv_gamma_beta=0.0):
+    """Per-voxel pre-training loss (model.py:449-514) through qbold_synth_loss_bwd; the gradient
+    output is discarded."""
+    y = _f32(y_true, "y_true")
+    q = _f32(q, "q", 5)
+    N = q.shape[0]
+    gq = torch.empty((N, 5), dtype=torch.float32, device=q.device)
+    lv = torch.empty(N, dtype=torch.float32, device=q.device)
+    _lib.check(self.lib.qbold_synth_loss_bwd(self.handle, _ptr(y), int(y.shape[-1]), _ptr(q), _ptr(gq), _ptr(lv),
+                                             1.0, float(inv_gamma_alpha), float(inv_gamma_beta), N, _stream()),
+               "qbold_synth_loss_bwd")
+    return lv
+
+
+@_ctx_method
 def kl_diag(self, q, prior, mask=None, g_q=None, per_voxel=True):
     """Closed-form KL of the diagonal family (use_mvg=False): q, prior [N,5] (columns 0-3 used).
     Returns (sums double[3] = (0, sum [m>0] kl, sum m), kl_v [N] or None); d kl / d q is added to g_q."""
