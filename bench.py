@@ -240,6 +240,18 @@ def main():
         ach_tf = flops / (kernel_ms * 1e-3) / 1e12
         ach_gbs = byts / (kernel_ms * 1e-3) / 1e9
         traffic = None
+        counters = {}
+        mix = os.path.join(ROOT, "profiles", "r01_vi_fwd_instruction_mix.json")
+        if os.path.exists(mix) and args.config == 2 and args.tissue == "table" and n == 1 << 20:
+            # utilisation counters of the committed rocprofv3 --pmc passes of this same command
+            pm = json.load(open(mix)).get("pmc", {})
+            try:
+                cyc = pm["GRBM_GUI_ACTIVE"]["mean"] / 8.0          # cycles per XCD
+                counters = {"mfma_util": pm["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024.0 / cyc,
+                            "valu_issue_util": pm["SQ_ACTIVE_INST_VALU"]["mean"] * 4.0 / 1024.0 / cyc,
+                            "source": "profiles/r01_vi_fwd_instruction_mix.json"}
+            except (KeyError, ZeroDivisionError):
+                counters = {}
         pmc = os.path.join(ROOT, "profiles", "r01_vi_fwd_pmc.json")
         if os.path.exists(pmc) and args.tissue == "table" and n == 1 << 20:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
@@ -263,6 +275,7 @@ def main():
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "kernel_ms": kernel_ms,
+                         **({"counters": counters} if counters else {}),
                          "algorithmic_flops_per_voxel": algorithmic_flops_per_voxel(T, U, L, S, K),
                          "note": "compute-bound path: peak = f32 matrix (= vector) rate; the "
                                  "metric's HBM view is in 'hbm'",
