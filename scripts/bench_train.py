@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--S", type=int, default=1)
     ap.add_argument("--K", type=int, default=70)
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--only", choices=["voxel", "crop"], default=None)
     a = ap.parse_args()
     os.chdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     params = get_params("config")
@@ -57,8 +58,9 @@ def main():
         st.backward(2, gq, gls, sums)
         st.adamw(5e-3, 2e-4, 0.9, 0.9, 1e-7)
 
-    ms = timed(voxel_step)
-    out["voxel_batch"] = dict(voxels=N, ms_per_step=ms, voxels_per_s=N / ms * 1e3)
+    if a.only != "crop":
+        ms = timed(voxel_step)
+        out["voxel_batch"] = dict(voxels=N, ms_per_step=ms, voxels_per_s=N / ms * 1e3)
 
     B, X, Y, Z = a.crops
     V = B * X * Y * Z
@@ -73,6 +75,9 @@ def main():
         st.backward_spatial(gq, gls, sums)
         st.adamw(5e-3, 2e-4, 0.9, 0.9, 1e-7)
 
+    if a.only == "voxel":
+        print(json.dumps(out))
+        return
     ms = timed(crop_step)
     out["crop_batch"] = dict(crops=[B, X, Y, Z], voxels=V, ms_per_step=ms, voxels_per_s=V / ms * 1e3)
     if a.graph:  # how much of the step is launch gaps: replay the same launches from a captured hipGraph
