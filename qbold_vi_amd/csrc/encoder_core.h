@@ -175,6 +175,7 @@ __device__ __forceinline__ void dense_f16x3(const float* __restrict__ A,
         return;
     }
     f16x8 whi = lds_frag(A, 0, lane), wlo = lds_frag(A, 1, lane);
+    __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -193,6 +194,7 @@ __device__ __forceinline__ void dense_f16x3(const float* __restrict__ A,
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
