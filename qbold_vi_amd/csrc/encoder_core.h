@@ -94,6 +94,9 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define QB_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 #define QB_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#ifndef QB_ENC_BASE_PRIO
+#define QB_ENC_BASE_PRIO 0
+#endif
 #define QB_LO_SCALE 2048.0f
 #define QB_LO_UNSCALE (1.0f / 2048.0f)
 
@@ -194,7 +197,7 @@ __device__ __forceinline__ void dense_f16x3(const float* __restrict__ A,
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(QB_ENC_BASE_PRIO);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
