@@ -6,6 +6,20 @@
 // j & 3).  Everything a lane needs per voxel lives in registers: T normalised data points, T
 // inverse sigmas, the transformed posterior / prior parameters.
 #pragma once
+// Wave priorities of the sampling phases (s_setprio; the fused kernel runs its encoder phase at 2-3, see
+// vi_kernels.hip).  Measured on the fused kernel at sustained clocks, 1 M voxels: all phases equal 0.597 ms;
+// likelihood loop 1 / KL loop 3 / everything after the draws 0: 0.572 ms.  Preferring the waves that are
+// about to finish a tile (KL) and those that feed the matrix pipe over the long likelihood loops keeps the
+// four waves of a SIMD in different phases.
+#ifndef QB_PRIO_LIK
+#define QB_PRIO_LIK 1
+#endif
+#ifndef QB_PRIO_KL
+#define QB_PRIO_KL 3
+#endif
+#ifndef QB_PRIO_AFTER
+#define QB_PRIO_AFTER 0
+#endif
 
 #include "qbold_dev.h"
 
@@ -187,6 +201,7 @@ __device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
     nll_sum = 0.0f;
     kl_sum = 0.0f;
     int n_lik = 0, n_kl = 0;  // draws taken by this lane
+    __builtin_amdgcn_s_setprio(QB_PRIO_LIK);
     for (int j = part; 2 * j < S; j += QB_LANES_PER_VOXEL) {
         float z[4];
         const bool two = 2 * j + 1 < S;
@@ -218,6 +233,7 @@ __device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
 #pragma unroll
     for (int k = 0; k < 5; ++k) pv[k] = prior_row[k];
     const LogitMvn prior = make_mvn(pv);
+    __builtin_amdgcn_s_setprio(QB_PRIO_KL);
     for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
         float z[4];
         const bool two = 2 * j + 1 < K;
@@ -245,6 +261,7 @@ __device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
             }
         }
     }
+    __builtin_amdgcn_s_setprio(QB_PRIO_AFTER);
     if (FAST) {  // log q - log p = 0.5 (swr_p - swr_q) + (s_o + s_d)_p - (s_o + s_d)_q per draw
         kl_sum = fmaf(0.5f, kl_sum, (float)n_kl * ((prior.s_o + prior.s_d) - (q.s_o + q.s_d)));
     }

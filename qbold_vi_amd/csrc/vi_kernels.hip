@@ -18,9 +18,14 @@
 // LDS-table / transcendental latencies of the sampling phase are covered by thread-level
 // parallelism.
 #include "elbo_core.h"
-// Wave priorities (s_setprio): a wave in its encoder phase runs at 2 (3 inside the MFMA chains), a wave in
-// its sampling phase at 0.  The four waves of a SIMD are in different phases most of the time; preferring
-// the one that feeds the matrix pipe keeps that pipe busy while the others fill the VALU: 0.610 -> 0.595 ms.
+// Wave priorities (s_setprio): a wave starts a tile (signal loads, normalisation) at 3, runs its encoder
+// phase at 2 (3 inside the MFMA chains), its likelihood draws at 1, its KL draws at 3 and the tile's tail
+// at 0 (elbo_core.h).  The four waves of a SIMD are in different phases most of the time; preferring the
+// one that feeds the matrix pipe, and the one about to finish, keeps the matrix pipe busy while the
+// others fill the VALU: 0.610 -> 0.572 ms per 1 M voxels.
+#ifndef QB_PRIO_TILE_START
+#define QB_PRIO_TILE_START 3
+#endif
 #define QB_ENC_BASE_PRIO 2
 #include "encoder_core.h"
 #include "qbold_ctx.h"
@@ -66,6 +71,7 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
         const int64_t vc = v < N ? v : N - 1;
         float o[5 + T];
         {
+            __builtin_amdgcn_s_setprio(QB_PRIO_TILE_START);
             float xv[T], nv[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) xv[t] = x[vc * T + t];
