@@ -146,8 +146,10 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
         // one 32x32->64 multiply (v_mad_u64_u32) per word instead of a mul_hi / mul_lo pair
         const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
-        c = make_uint4((uint32_t)(p1 >> 32) ^ c.y ^ k.x, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k.y,
-                       (uint32_t)p0);
+        // hi ^ ctr ^ key as one v_bitop3_b32 (truth table 0x96 = three-input XOR; the compiler emits two
+        // v_xor_b32 for a ^ b ^ c on gfx950)
+        c = make_uint4(__builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c.y, k.x, 0x96), (uint32_t)p1,
+                       __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c.w, k.y, 0x96), (uint32_t)p0);
         k.x += 0x9E3779B9u;
         k.y += 0xBB67AE85u;
     }
