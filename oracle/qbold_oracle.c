@@ -908,9 +908,10 @@ void qbo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 }
 
 static inline void box_muller(uint32_t a, uint32_t b, real *z0, real *z1) {
-    /* u in (0,1): top 24 bits + half an ulp.  Evaluated in double, rounded once. */
-    double u1 = ((double)(a >> 8) + 0.5) * (1.0 / 16777216.0);
-    double u2 = ((double)(b >> 8) + 0.5) * (1.0 / 16777216.0);
+    /* u in (0,1]: the float32 value fma(float(a), 2^-32, 2^-33) that the kernels form (uint32 -> float32
+     * round-to-nearest, one FMA), then everything in double, rounded once. */
+    double u1 = (double)fmaf((float)a, 0x1p-32f, 0x1p-33f);
+    double u2 = (double)fmaf((float)b, 0x1p-32f, 0x1p-33f);
     double rr = sqrt(-2.0 * log(u1));
     *z0 = R(rr * cos(2.0 * M_PI * u2));
     *z1 = R(rr * sin(2.0 * M_PI * u2));

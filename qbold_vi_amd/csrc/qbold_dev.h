@@ -157,8 +157,11 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 }
 
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
-    float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    // u in (0, 1]: all 32 bits, converted with round-to-nearest and centred -- v_cvt_f32_u32 + one FMA
+    // (two instructions per uniform; the 24-bit (x >> 8) + 0.5 form took four), and the float grid is finer
+    // near 0, where the radius sqrt(-2 ln u1) needs it.  u = 1 (from a >= 2^32 - 128) gives radius 0.
+    float u1 = fmaf((float)a, 0x1p-32f, 0x1p-33f);
+    float u2 = fmaf((float)b, 0x1p-32f, 0x1p-33f);
     // r = sqrt(-2 ln u1) via v_log_f32 (log2) and v_sqrt_f32; v_sin/v_cos take revolutions
     float r = __builtin_amdgcn_sqrtf((-2.0f * QB_LN2) * log2f_(u1));
     z0 = r * __builtin_amdgcn_cosf(u2);
