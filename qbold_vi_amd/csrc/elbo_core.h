@@ -126,7 +126,11 @@ __device__ __forceinline__ float sample_sq_fast(const FwdLds* L, const QbDev& c,
         //   yhat_t = (tissue_w 2^(nd F_t) + blood_w 2^(ng B_t)) / (s_se + 1e-3)          model.py:545
         // go into the exponents (two log2 per draw instead of three multiplies per tau), and the data
         // arrive pre-divided by sigma (prepare_lik<.., PRESCALE>): r_t = yt_t / s_t - yhat_t / s_t.
-        const float s_se = fwd_signal_fast(L, c, fv, SE >= 0 ? SE : 0);
+        // tau = 0 at the spin echo (the reference's protocols): x = 0, F(0) = 0 exactly (the table's first
+        // coefficient), so the tissue factor is tissue_w and no lookup is needed -- bit-identical
+        const float s_se = c.tauh0 + (float)(SE >= 0 ? SE : 0) * c.tauh_step == 0.0f
+                               ? fmaf(fv.tissue_w, 1.0f, fv.blood_w * exp2f_(fv.ng * c.blood_B[SE >= 0 ? SE : 0]))
+                               : fwd_signal_fast(L, c, fv, SE >= 0 ? SE : 0);
         const float inv_np = rcpf_(s_se + 1e-3f);
         const float lt = log2f_(fv.tissue_w * inv_np), lb = log2f_(fv.blood_w * inv_np);  // log2(0) = -inf: term vanishes
 #pragma unroll
