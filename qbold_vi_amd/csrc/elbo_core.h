@@ -127,30 +127,46 @@ __device__ __forceinline__ float sample_sq_fast(const FwdLds* L, const QbDev& c,
         // go into the exponents (two log2 per draw instead of three multiplies per tau), and the data
         // arrive pre-divided by sigma (prepare_lik<.., PRESCALE>): r_t = yt_t / s_t - yhat_t / s_t.
         // tau = 0 at the spin echo (the reference's protocols): x = 0, F(0) = 0 exactly (the table's first
-        // coefficient), so the tissue factor is tissue_w and no lookup is needed -- bit-identical
-        const float s_se = c.tauh0 + (float)(SE >= 0 ? SE : 0) * c.tauh_step == 0.0f
-                               ? fmaf(fv.tissue_w, 1.0f, fv.blood_w * exp2f_(fv.ng * c.blood_B[SE >= 0 ? SE : 0]))
-                               : fwd_signal_fast(L, c, fv, SE >= 0 ? SE : 0);
+        // coefficient), so the tissue factor is tissue_w and no lookup is needed -- bit-identical.
+        constexpr int kSE = SE >= 0 ? SE : 0;
+        const bool se0 = fmaf((float)kSE, c.tauh_step, c.tauh0) == 0.0f;  // uniform: tau = 0 at the spin echo
+        const float s_se = se0 ? fmaf(fv.tissue_w, 1.0f, fv.blood_w * exp2f_(fv.ng * c.blood_B[kSE]))
+                               : fwd_signal_fast(L, c, fv, kSE);
         const float inv_np = rcpf_(s_se + 1e-3f);
         const float lt = log2f_(fv.tissue_w * inv_np), lb = log2f_(fv.blood_w * inv_np);  // log2(0) = -inf: term vanishes
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            float yh;
-            if (t == SE) {
-                yh = s_se * inv_np;
-            } else {
-                const float u = fabsf(fmaf((float)t, fv.ub, fv.ua));
-                const float4 kk = L->tab[(int)u];
-                const float f = __builtin_amdgcn_fractf(u);
-                const float F = fmaf(fmaf(fmaf(kk.w, f, kk.z), f, kk.y), f, kk.x);
-                yh = exp2f_(fmaf(fv.nd, F, lt)) + exp2f_(fmaf(fv.ng, c.blood_B[t], lb));
-            }
+        auto signal = [&](int t) -> float {  // normalised prediction at tau index t
+            const float u = fabsf(fmaf((float)t, fv.ub, fv.ua));
+            const float4 kk = L->tab[(int)u];
+            const float f = __builtin_amdgcn_fractf(u);
+            const float F = fmaf(fmaf(fmaf(kk.w, f, kk.z), f, kk.y), f, kk.x);
+            return exp2f_(fmaf(fv.nd, F, lt)) + exp2f_(fmaf(fv.ng, c.blood_B[t], lb));
+        };
+        auto residual = [&](int t, float yh) {
             const float r = fmaf(-yh, k.inv_s[t], k.yt[t]);
             acc = fmaf(r, r, acc);
-            // keep at most two table rows in flight: without a compiler barrier all T LDS reads are
-            // hoisted to the top of the draw and the kernel spills (every 2 taus measured best: 0.611 ms;
-            // every 4: 0.612 ms)
-            if ((t & 1) == 1) asm volatile("" ::: "memory");
+        };
+        // keep at most two table rows in flight: without a compiler barrier all T LDS reads are hoisted to
+        // the top of the draw and the kernel spills (every 2 taus measured best: 0.611 ms; every 4: 0.612 ms)
+        residual(kSE, s_se * inv_np);
+        if (se0) {
+            // The signal is even in tau (|x| enters F, and the blood bracket swaps its two roots), and the
+            // protocol samples both sides of the spin echo on one grid: tau_{SE-j} = -tau_{SE+j}.  Each
+            // mirrored pair is evaluated once (9 evaluations instead of 11 for tau = -16 .. 64 ms).
+#pragma unroll
+            for (int t = kSE + 1; t < T; ++t) {
+                const float yh = signal(t);
+                residual(t, yh);
+                if (2 * kSE - t >= 0) residual(2 * kSE - t, yh);
+                if (((t - kSE) & 1) == 0) asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int t = 0; t < 2 * kSE - (T - 1); ++t) residual(t, signal(t));  // no partner on the grid
+        } else {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                if (t != kSE) residual(t, signal(t));
+                if ((t & 1) == 1) asm volatile("" ::: "memory");
+            }
         }
         return acc;
     }
