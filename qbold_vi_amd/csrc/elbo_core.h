@@ -139,7 +139,7 @@ __device__ __forceinline__ float sample_sq_fast(const FwdLds* L, const QbDev& c,
             const float4 kk = L->tab[(int)u];
             const float f = __builtin_amdgcn_fractf(u);
             const float F = fmaf(fmaf(fmaf(kk.w, f, kk.z), f, kk.y), f, kk.x);
-            return exp2f_(fmaf(fv.nd, F, lt)) + exp2f_(fmaf(fv.ng, c.blood_B[t], lb));
+            return exp2f_(fmaf(fv.nd, F, lt)) + exp2f_(fmaf(fv.ng, L->blood_B[t], lb));
         };
         auto residual = [&](int t, float yh) {
             const float r = fmaf(-yh, k.inv_s[t], k.yt[t]);

@@ -23,6 +23,7 @@ __global__ __launch_bounds__(kBlock) void elbo_fwd_kernel(
     __shared__ qb::FwdLds L;
     __shared__ double red[3 * (kBlock / 64)];
     qb::fwd_lds_fill(&L, g_tab, true);
+    if (threadIdx.x < QB_MAX_T) L.blood_B[threadIdx.x] = c.blood_B[threadIdx.x];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -222,21 +222,28 @@ __device__ __forceinline__ void dense_head(const float* __restrict__ A,
     dense_f16x3<HT, 2, BF>(A, bias, f.hi, f.lo, out, lane);
 }
 
-// normalise_data -- model.py:97-113; n[t] for this lane's voxel.
-template <int T>
+// normalise_data -- model.py:97-113; n[t] for this lane's voxel.  SE >= 0: the caller dispatched on
+// se_idx == SE && !multi_norm, and the spin-echo image is picked at compile time (same arithmetic; the
+// run-time form costs 3 T selects whose lane-uniform masks the register allocator spills).
+template <int T, int SE = -1>
 __device__ __forceinline__ void normalise(const QbDev& c, const float (&x)[T], float (&n)[T]) {
     float cl[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) cl[t] = clampf_(x[t], 1e-2f, 1e8f);  // model.py:101
-    const int se = c.se_idx;
-    float a = 0.0f, b = 0.0f, d = 0.0f;
+    float den;
+    if (SE >= 0) {
+        den = cl[SE >= 0 ? SE : 0];  // model.py:106
+    } else {
+        const int se = c.se_idx;
+        float a = 0.0f, b = 0.0f, d = 0.0f;
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        a = (t == se - 1) ? cl[t] : a;
-        b = (t == se) ? cl[t] : b;
-        d = (t == se + 1) ? cl[t] : d;
+        for (int t = 0; t < T; ++t) {
+            a = (t == se - 1) ? cl[t] : a;
+            b = (t == se) ? cl[t] : b;
+            d = (t == se + 1) ? cl[t] : d;
+        }
+        den = c.multi_norm ? (a + b + d) / 3.0f : b;  // model.py:104 / :106
     }
-    const float den = c.multi_norm ? (a + b + d) / 3.0f : b;  // model.py:104 / :106
     const float inv_den = 1.0f / den;
 #pragma unroll
     for (int t = 0; t < T; ++t) n[t] = QB_LN2 * log2f_(cl[t] * inv_den);  // model.py:108

@@ -260,6 +260,8 @@ struct FwdLds {
     float u[QB_NNODE + 3];
     float pre[QB_NNODE + 3];  // (2+u)*sqrt(1-u)
     float den[QB_NNODE + 3];  // 3*u^2
+    float blood_B[QB_MAX_T];  // QbDev::blood_B for the fused forward kernel's draw loop (a VGPR operand
+                              // instead of an SGPR one: v_fma_f32 issues in 2.9 instead of 5.5 cycles)
 };
 
 __device__ __forceinline__ void fwd_lds_fill(FwdLds* L, const float4* __restrict__ g_tab,

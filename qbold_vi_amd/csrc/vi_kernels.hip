@@ -58,6 +58,7 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
     for (int p = threadIdx.x; p < e.total / 4; p += kBlock)
         reinterpret_cast<float4*>(lds_w)[p] = reinterpret_cast<const float4*>(packed)[p];
     qb::fwd_lds_fill(L, g_tab, true);
+    if (threadIdx.x < QB_MAX_T) L->blood_B[threadIdx.x] = c.blood_B[threadIdx.x];
     __syncthreads();
 
     constexpr int HT = (5 + T + 15) / 16;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
             float xv[T], nv[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) xv[t] = x[vc * T + t];
-            qb::normalise<T>(c, xv, nv);
+            qb::normalise<T, SE>(c, xv, nv);
             __builtin_amdgcn_s_setprio(2);
             f32x4 b[4];
             qb::dense_first<T, BF>(lds_w + e.first_A, lds_w + e.first_b, nv, b, lane);
