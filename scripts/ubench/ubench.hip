@@ -1,4 +1,4 @@
-// Scratch: per-instruction issue cost on gfx950 (wave64), 4 waves per SIMD, independent chains.
+// per-instruction issue cost on gfx950 (wave64), 4 waves per SIMD, independent chains.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,4 +1,4 @@
-// Scratch: operand-kind effects on VALU issue cost, gfx950.
+// operand-kind effects on VALU issue cost, gfx950.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define ITERS 65536
