@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--tissue", choices=["table", "literal"], default="table")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3],
                     help="BASELINE.json config: 2 = 11 tau / width 60 (headline), 3 = 64 tau / width 256")
+    ap.add_argument("--protocol", type=int, default=11, choices=[11, 24],
+                    help="config 2 only: 11 = tau -16..64 ms in 8 ms steps (headline, the config file); 24 = the "
+                         "reference's second protocol, tau -28..64 ms in 4 ms steps (signals.py:120-121)")
     ap.add_argument("--encoder_precision", choices=["f32", "bf16"], default="f32",
                     help="f32 (headline): float32-grade split-f16 MFMA; bf16: BASELINE config 5's "
                          "'bf16 forward / fp32 ELBO accum' (encoder products on bf16 operands)")
@@ -164,6 +167,9 @@ def main():
     if args.config == 3:  # 64 taus from -0.015 s in 1.25 ms steps (se_idx 12), width 256
         params.update(tau_start="-0.015", tau_end="0.065", tau_step="0.00125")
         T, U = 64, 256
+    elif args.protocol == 24:
+        params.update(tau_start="-0.028", tau_end="0.065", tau_step="0.004")
+        T = 24
     S, K, n = args.mc_samples, args.kl_samples, args.voxels
 
     ctx, x = make_inputs(n, params, seed=1 + rank, device=device)
@@ -263,7 +269,7 @@ def main():
         traffic = None
         counters = {}
         mix = os.path.join(ROOT, "profiles", "r01_vi_fwd_instruction_mix.json")
-        if os.path.exists(mix) and args.config == 2 and args.tissue == "table" and n == 1 << 20:
+        if os.path.exists(mix) and args.config == 2 and args.protocol == 11 and args.tissue == "table" and n == 1 << 20:
             # utilisation counters of the committed rocprofv3 --pmc passes of this same command
             pm = json.load(open(mix)).get("pmc", {})
             try:
@@ -274,7 +280,7 @@ def main():
             except (KeyError, ZeroDivisionError):
                 counters = {}
         pmc = os.path.join(ROOT, "profiles", "r01_vi_fwd_pmc.json")
-        if os.path.exists(pmc) and args.tissue == "table" and n == 1 << 20:
+        if os.path.exists(pmc) and args.config == 2 and args.protocol == 11 and args.tissue == "table" and n == 1 << 20:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         line = {
             "metric": "voxel-ELBO evals/sec", "value": value, "unit": "voxel-ELBO evals/s",

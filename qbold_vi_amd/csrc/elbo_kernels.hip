@@ -326,7 +326,8 @@ extern "C" int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float*
             else QB_LAUNCH_ELBO(11, -1, false, false);
             break;
         case 24:  // the reference's second protocol (signals.py:120-121); se_idx = 7
-            if (fast) QB_LAUNCH_ELBO(24, -1, true, false);
+            if (fast && ctx->dev.se_idx == 7 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(24, 7, true, false);
+            else if (fast) QB_LAUNCH_ELBO(24, -1, true, false);
             else if (lit) QB_LAUNCH_ELBO(24, -1, false, true);
             else QB_LAUNCH_ELBO(24, -1, false, false);
             break;

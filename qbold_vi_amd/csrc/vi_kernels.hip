@@ -160,17 +160,18 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
                            x, mask, prior, S, K, seed, voxel0, q_out, out, partials, N);          \
     } while (0)
     const bool fast = qb::elbo_fast_path(ctx);
-#define QB_DISPATCH_VI(TT, NL)                                                    \
+    // SEC: the protocol's spin-echo index (tau = 0), folded at compile time when the context agrees
+#define QB_DISPATCH_VI(TT, NL, SEC)                                               \
     do {                                                                          \
-        if (fast && ctx->dev.se_idx == 2 && !ctx->dev.multi_norm && !(ctx->dev.debug_skip & 4)) QB_LAUNCH_VI(TT, NL, 2, true, false);   \
+        if (fast && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm && !(ctx->dev.debug_skip & 4)) QB_LAUNCH_VI(TT, NL, SEC, true, false);   \
         else if (fast) QB_LAUNCH_VI(TT, NL, -1, true, false);                     \
         else if (lit) QB_LAUNCH_VI(TT, NL, -1, false, true);                      \
         else QB_LAUNCH_VI(TT, NL, -1, false, false);                              \
     } while (0)
-    if (shape->T == 11 && shape->L == 1) QB_DISPATCH_VI(11, 1);
-    else if (shape->T == 11 && shape->L == 2) QB_DISPATCH_VI(11, 2);
-    else if (shape->T == 24 && shape->L == 1) QB_DISPATCH_VI(24, 1);
-    else if (shape->T == 24 && shape->L == 2) QB_DISPATCH_VI(24, 2);
+    if (shape->T == 11 && shape->L == 1) QB_DISPATCH_VI(11, 1, 2);
+    else if (shape->T == 11 && shape->L == 2) QB_DISPATCH_VI(11, 2, 2);
+    else if (shape->T == 24 && shape->L == 1) QB_DISPATCH_VI(24, 1, 7);
+    else if (shape->T == 24 && shape->L == 2) QB_DISPATCH_VI(24, 2, 7);
     else {
         qb::set_error("qbold_vi_fwd: kernels are built for T = 11 or 24 taus, L = 1 or 2");
         return QBOLD_ERR_UNSUPPORTED;
