@@ -96,8 +96,26 @@ __device__ __forceinline__ float sample_nll(const FwdLds* L, const QbDev& c, con
                                             float oef, float dbv) {
     const FwdVox fv = fwd_vox(c, oef, dbv);
     float s[T];
+    if (SE >= 0) {
+        // Compile-time spin-echo index: the full model's tissue factor is even in tau (F takes |x|; the
+        // literal Simpson sum sees tau only through j0f(|.|)), so a pair of taus that mirror EXACTLY in
+        // float32 about the spin echo shares one tissue factor -- the same float32 value either way.  (The
+        // reference's float32 grid start + i step mirrors only in part: -16 / +16 ms do, -8 / +8 ms differ
+        // by an ulp and are evaluated separately.)  The blood factor keeps its own bracket per tau.
+        constexpr int kSE = SE >= 0 ? SE : 0;
+        float tis[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) s[t] = fwd_signal<LITERAL>(L, c, fv, t);
+        for (int t = T - 1; t >= 0; --t) {
+            const int m = (t < kSE && 2 * kSE - t < T) ? 2 * kSE - t : 0;
+            const bool mirrored = t < kSE && 2 * kSE - t < T && c.full_model && c.taus[m] == -c.taus[t];
+            if (mirrored) tis[t] = tis[m];
+            else tis[t] = fwd_tissue<LITERAL>(L, c, fv, t);
+            s[t] = fwd_mix(c, fv, tis[t], t);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t) s[t] = fwd_signal<LITERAL>(L, c, fv, t);
+    }
     const float inv_np = 1.0f / se_norm<T, SE>(c, s);  // model.py:542 / :545
     float acc = 0.0f;
 #pragma unroll

@@ -322,12 +322,14 @@ extern "C" int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float*
         case 11:
             if (fast && ctx->dev.se_idx == 2 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(11, 2, true, false);
             else if (fast) QB_LAUNCH_ELBO(11, -1, true, false);
+            else if (lit && ctx->dev.se_idx == 2 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(11, 2, false, true);
             else if (lit) QB_LAUNCH_ELBO(11, -1, false, true);
             else QB_LAUNCH_ELBO(11, -1, false, false);
             break;
         case 24:  // the reference's second protocol (signals.py:120-121); se_idx = 7
             if (fast && ctx->dev.se_idx == 7 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(24, 7, true, false);
             else if (fast) QB_LAUNCH_ELBO(24, -1, true, false);
+            else if (lit && ctx->dev.se_idx == 7 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(24, 7, false, true);
             else if (lit) QB_LAUNCH_ELBO(24, -1, false, true);
             else QB_LAUNCH_ELBO(24, -1, false, false);
             break;

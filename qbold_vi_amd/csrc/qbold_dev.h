@@ -378,22 +378,29 @@ __device__ __forceinline__ FwdVox fwd_vox_hct(const QbDev& c, float oef, float d
 }
 // signal at one tau -- signals.py:98-114 with calc_tissue :152-209 and calc_blood :233-247.
 template <bool LITERAL>
-__device__ __forceinline__ float fwd_signal(const FwdLds* L, const QbDev& c, const FwdVox& v,
-                                            int t) {
+__device__ __forceinline__ float fwd_tissue(const FwdLds* L, const QbDev& c, const FwdVox& v, int t) {
     const float tau = c.taus[t];
-    float tissue;
     if (c.full_model) {
+        // tau = 0 (the spin echo): every node's 1 - j0f(0) is exactly 0 and the table's first coefficient is
+        // F(0) = 0, so F = 0 and exp(-dbv * 0) = 1 in either mode -- same float32 result without the sum
+        if (tau == 0.0f) return c.e_te_r2t;
         float F = tissue_F<LITERAL, false>(L, c, tau * v.dw, nullptr);
-        tissue = __expf(-v.dbv * F) * c.e_te_r2t;
-    } else {  // log-linear two-regime model, signals.py:194-207
-        float tc = 1.0f / v.dw;
-        float rt = (v.dw * v.dbv) * tau;
-        float e = __expf(c.r2t_te);
-        tissue = (fabsf(tau) < tc) ? e * __expf(-(0.3f * (rt * rt)) / v.dbv)
-                                   : e * __expf(v.dbv - rt);
+        return __expf(-v.dbv * F) * c.e_te_r2t;
     }
+    // log-linear two-regime model, signals.py:194-207
+    float tc = 1.0f / v.dw;
+    float rt = (v.dw * v.dbv) * tau;
+    float e = __expf(c.r2t_te);
+    return (fabsf(tau) < tc) ? e * __expf(-(0.3f * (rt * rt)) / v.dbv) : e * __expf(v.dbv - rt);
+}
+__device__ __forceinline__ float fwd_mix(const QbDev& c, const FwdVox& v, float tissue, int t) {
     float blood = c.include_blood ? c.e_r2b_te * __expf(-v.g * c.blood_B[t]) : 0.0f;
     return v.tw * tissue + v.bw * blood;
+}
+template <bool LITERAL>
+__device__ __forceinline__ float fwd_signal(const FwdLds* L, const QbDev& c, const FwdVox& v,
+                                            int t) {
+    return fwd_mix(c, v, fwd_tissue<LITERAL>(L, c, v, t), t);
 }
 
 // Fast path of the same model (full model, table mode, inputs from forward_transform so that

@@ -165,6 +165,7 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     do {                                                                          \
         if (fast && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm && !(ctx->dev.debug_skip & 4)) QB_LAUNCH_VI(TT, NL, SEC, true, false);   \
         else if (fast) QB_LAUNCH_VI(TT, NL, -1, true, false);                     \
+        else if (lit && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm) QB_LAUNCH_VI(TT, NL, SEC, false, true);   \
         else if (lit) QB_LAUNCH_VI(TT, NL, -1, false, true);                      \
         else QB_LAUNCH_VI(TT, NL, -1, false, false);                              \
     } while (0)
