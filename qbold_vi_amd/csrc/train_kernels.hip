@@ -59,12 +59,18 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
     // rows of X that are 16-byte aligned are read as float4: in MFMA k-step (q, c) lane group g then
     // supplies k = 16 q + 4 g + c (any bijection of k over (step, group) sums the same products)
     const bool vec = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    // 16-byte aligned output rows are written as float4: output tile m of lane i then stands for column
+    // 4 i + m instead of 16 m + i (the weight slab is staged with its columns permuted to match), so a lane
+    // holds four consecutive columns of each of its rows and a 16-lane group writes a whole 256-byte row
+    const bool vout = (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
+                      (!mask || ((ldm & 3) == 0 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0));
     const int kpad = vec ? (kdim + 15) & ~15 : (kdim + 3) & ~3;
     for (int e = threadIdx.x; e < kpad * 64; e += 256) {
         const int k = e >> 6, j = n0 + (e & 63);
         float v = 0.0f;
         if (k < kdim && j < ndim) v = trans ? W[j * ldw + k] : W[k * ldw + j];
-        Wl[k * kWs + (e & 63)] = v;
+        const int jj = e & 63;
+        Wl[k * kWs + (vout ? 16 * (jj & 3) + (jj >> 2) : jj)] = v;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -101,20 +107,62 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
                 for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(a, wr[16 * m], acc[m]);
             }
         }
+        if (vout) {
+            const int j = n0 + 4 * i;
+            if (j < ndim) {
+                float bj[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int j = n0 + 16 * m + i;
-            if (j >= ndim) continue;
-            const float bj = b ? b[j] : 0.0f;
+                for (int m = 0; m < 4; ++m) bj[m] = (b && j + m < ndim) ? b[j + m] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t v = v0 + 4 * g + r;
-                if (v >= N) continue;
-                float y = acc[m][r] + bj;
-                if (accum) y += Y[v * ldy + j];
-                if (act == ACT_RELU) y = fmaxf(y, 0.0f);
-                if (mask) y = mask[v * ldm + j] > 0.0f ? y : 0.0f;
-                Y[v * ldy + j] = y;
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t v = v0 + 4 * g + r;
+                    if (v >= N) continue;
+                    float y[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) y[m] = acc[m][r] + bj[m];
+                    float4* yp = reinterpret_cast<float4*>(Y + v * ldy + j);
+                    if (j + 3 < ndim) {
+                        if (accum) {
+                            const float4 o = *yp;
+                            y[0] += o.x; y[1] += o.y; y[2] += o.z; y[3] += o.w;
+                        }
+                        if (act == ACT_RELU) {
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) y[m] = fmaxf(y[m], 0.0f);
+                        }
+                        if (mask) {
+                            const float4 mk = *reinterpret_cast<const float4*>(mask + v * ldm + j);
+                            y[0] = mk.x > 0.0f ? y[0] : 0.0f; y[1] = mk.y > 0.0f ? y[1] : 0.0f;
+                            y[2] = mk.z > 0.0f ? y[2] : 0.0f; y[3] = mk.w > 0.0f ? y[3] : 0.0f;
+                        }
+                        *yp = make_float4(y[0], y[1], y[2], y[3]);
+                    } else {  // ragged last columns
+                        for (int m = 0; m < 4 && j + m < ndim; ++m) {
+                            float t = y[m];
+                            if (accum) t += Y[v * ldy + j + m];
+                            if (act == ACT_RELU) t = fmaxf(t, 0.0f);
+                            if (mask) t = mask[v * ldm + j + m] > 0.0f ? t : 0.0f;
+                            Y[v * ldy + j + m] = t;
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int j = n0 + 16 * m + i;
+                if (j >= ndim) continue;
+                const float bj = b ? b[j] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t v = v0 + 4 * g + r;
+                    if (v >= N) continue;
+                    float y = acc[m][r] + bj;
+                    if (accum) y += Y[v * ldy + j];
+                    if (act == ACT_RELU) y = fmaxf(y, 0.0f);
+                    if (mask) y = mask[v * ldm + j] > 0.0f ? y : 0.0f;
+                    Y[v * ldy + j] = y;
+                }
             }
         }
     }
@@ -194,101 +242,123 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
 // partial[blk][64*64 + 64]: dW[i][j] = sum_v X[v][i] D[v][j] over this block's voxels, then db[j]
 // gridDim.y == 9: blockIdx.y is the tap of a 3x3x1 kernel (gt carries the crop geometry only) and the
 // partials of tap t start at partial + t * gridDim.x * (64*64 + 64).
-__global__ __launch_bounds__(256) void xtd_kernel(const float* __restrict__ X, int ldx, int kdim,
-                                                  const float* __restrict__ D, int ldd, int ndim,
-                                                  float* __restrict__ partial, int64_t N, Gather gt) {
+// 1024 threads = 16 waves = 4 row groups x 4 output quadrants: wave (rg, qa, qc) accumulates the 32 x 32
+// quadrant (X columns 32 qa.., D columns 32 qc..) over the 4-voxel steps st = rg (mod 4) of its block --
+// 16 accumulator registers per lane instead of 64, so the in-block reduction over the row groups is 16
+// LDS adds per lane and phase (fixed order: bitwise reproducible, no float atomics), and one block per CU
+// keeps 4 waves per SIMD streaming rows.
+__global__ __launch_bounds__(1024) void xtd_kernel(const float* __restrict__ X, int ldx, int kdim,
+                                                   const float* __restrict__ D, int ldd, int ndim,
+                                                   float* __restrict__ partial, int64_t N, Gather gt) {
     __shared__ float red[64 * 64 + 64];
     if (gridDim.y == 9) {
         gt.dx = (int)blockIdx.y / 3 - 1;
         gt.dy = (int)blockIdx.y % 3 - 1;
         partial += (int64_t)blockIdx.y * gridDim.x * (64 * 64 + 64);
     }
-    for (int e = threadIdx.x; e < 64 * 64 + 64; e += 256) red[e] = 0.0f;
+    for (int e = threadIdx.x; e < 64 * 64 + 64; e += 1024) red[e] = 0.0f;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
-    f32x4 acc[4][4];
+    const int rg = wave >> 2, qa = (wave >> 1) & 1, qc = wave & 1;
+    f32x4 acc[2][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    float dbsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    // 16-byte aligned rows are read as float4: tile m of lane i then stands for column 4 i + m instead
-    // of 16 m + i (a permutation of the output rows / columns, undone where the tiles are reduced)
-    const bool vec = ((ldx | ldd) & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D)) & 15) == 0;
+        for (int c = 0; c < 2; ++c) acc[a][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float dbsum[2] = {0.0f, 0.0f};
+    // tile a of lane i stands for X column 32 qa + 2 i + a (8-byte loads), tile c for D column 32 qc + 2 i + c
+    const int cx = 32 * qa + 2 * i, cd = 32 * qc + 2 * i;
+    const bool vec = ((ldx | ldd) & 1) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D)) & 7) == 0;
     const int64_t nstep = (N + 3) / 4;  // 4 voxels per MFMA k-step
-    for (int64_t st = (int64_t)blockIdx.x * 4 + wave; st < nstep; st += (int64_t)gridDim.x * 4) {
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    auto load = [&](int64_t st, float (&xa)[2], float (&dd)[2]) {
         const int64_t v = st * 4 + g;
-        const bool ok = v < N;
+        const bool ok = st < nstep && v < N;
         const int64_t vx = ok ? gather_row(gt, v) : -1;
-        float xa[4], dd[4];
+        xa[0] = xa[1] = dd[0] = dd[1] = 0.0f;
         if (vec) {
-            float4 x4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = x4;
-            if (vx >= 0 && 4 * i < kdim) x4 = *reinterpret_cast<const float4*>(X + vx * ldx + 4 * i);
-            if (ok && 4 * i < ndim) d4 = *reinterpret_cast<const float4*>(D + v * ldd + 4 * i);
-            const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ds[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                xa[m] = 4 * i + m < kdim ? xs[m] : 0.0f;
-                dd[m] = 4 * i + m < ndim ? ds[m] : 0.0f;
-                dbsum[m] += dd[m];
+            if (vx >= 0 && cx < kdim) {
+                const float2 t = *reinterpret_cast<const float2*>(X + vx * ldx + cx);
+                xa[0] = t.x;
+                xa[1] = cx + 1 < kdim ? t.y : 0.0f;
+            }
+            if (ok && cd < ndim) {
+                const float2 t = *reinterpret_cast<const float2*>(D + v * ldd + cd);
+                dd[0] = t.x;
+                dd[1] = cd + 1 < ndim ? t.y : 0.0f;
             }
         } else {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int c = 16 * m + i;
-                xa[m] = (vx >= 0 && c < kdim) ? X[vx * ldx + c] : 0.0f;
-                dd[m] = (ok && c < ndim) ? D[v * ldd + c] : 0.0f;
-                dbsum[m] += dd[m];
+            for (int m = 0; m < 2; ++m) {
+                if (vx >= 0 && cx + m < kdim) xa[m] = X[vx * ldx + cx + m];
+                if (ok && cd + m < ndim) dd[m] = D[v * ldd + cd + m];
             }
         }
+    };
+    float xa[2], dd[2], xn[2], dn[2];
+    int64_t st = (int64_t)blockIdx.x * 4 + rg;
+    load(st, xa, dd);
+    for (; st < nstep; st += stride) {
+        load(st + stride, xn, dn);  // next step's rows are in flight while this step's MFMAs run
+        dbsum[0] += dd[0];
+        dbsum[1] += dd[1];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[a][c] = QB_MFMA16F(xa[a], dd[c], acc[a][c]);
+            for (int c = 0; c < 2; ++c) acc[a][c] = QB_MFMA16F(xa[a], dd[c], acc[a][c]);
+        xa[0] = xn[0]; xa[1] = xn[1]; dd[0] = dn[0]; dd[1] = dn[1];
     }
-    // D[i][j] layout: col j = lane & 15, rows 4g + r.  The four waves add their tiles one after
-    // the other (fixed order: bitwise reproducible gradients, no float atomics).
-    for (int wv = 0; wv < 4; ++wv) {
-        if (wave == wv) {
+    // MFMA output: acc[a][c][r] of lane (i, g) is row 4 g + r, column i of tile (a, c).  The four row
+    // groups add their quadrants one after the other; the four quadrant waves of a group write disjoint
+    // parts of red.
+    for (int ph = 0; ph < 4; ++ph) {
+        if (rg == ph) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = vec ? 4 * (4 * g + r) + a : 16 * a + 4 * g + r;
-                        const int col = vec ? 4 * i + c : 16 * c + i;
-                        red[row * 64 + col] += acc[a][c][r];
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        red[(32 * qa + 2 * (4 * g + r) + a) * 64 + 32 * qc + 2 * i + c] += acc[a][c][r];
+            if (qa == 0) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                float sm = dbsum[m];
-                sm += __shfl_xor(sm, 16, 64);
-                sm += __shfl_xor(sm, 32, 64);
-                if (g == 0) red[64 * 64 + (vec ? 4 * i + m : 16 * m + i)] += sm;
+                for (int m = 0; m < 2; ++m) {
+                    float sm = dbsum[m];
+                    sm += __shfl_xor(sm, 16, 64);
+                    sm += __shfl_xor(sm, 32, 64);
+                    if (g == 0) red[64 * 64 + cd + m] += sm;
+                }
             }
         }
         __syncthreads();
     }
     float* out = partial + (int64_t)blockIdx.x * (64 * 64 + 64);
-    for (int e = threadIdx.x; e < 64 * 64 + 64; e += 256) out[e] = red[e];
+    for (int e = threadIdx.x; e < 64 * 64 + 64; e += 1024) out[e] = red[e];
 }
 
 // dW[i * ldw + j] (+)= sum_blk partial[blk][i][j]; db[j] (+)= sum_blk partial[blk][4096 + j]
 // gridDim.y == 9: one 3x3x1 kernel -- tap t reads its own partials and writes dW + t * kdim * ndim; the
 // bias gradient comes from tap 0 only.
-__global__ void slab_reduce_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dW,
-                                   int ldw, int kdim, int ndim, float* __restrict__ db, int accum) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 64 * 64 + 64) return;
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, int nblk,
+                                                           float* __restrict__ dW, int ldw, int kdim, int ndim,
+                                                           float* __restrict__ db, int accum) {
+    // 64 elements per block x 4 interleaved parts of the block range, added in a fixed order
+    __shared__ double part[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6;
     if (gridDim.y == 9) {
         partial += (int64_t)blockIdx.y * nblk * (64 * 64 + 64);
         dW += (int64_t)blockIdx.y * kdim * ndim;
         if (blockIdx.y != 0) db = nullptr;
     }
     double a = 0.0;
-    for (int bk = 0; bk < nblk; ++bk) a += (double)partial[(int64_t)bk * (64 * 64 + 64) + e];
+    if (e < 64 * 64 + 64)
+        for (int bk = p; bk < nblk; bk += 4) a += (double)partial[(int64_t)bk * (64 * 64 + 64) + e];
+    part[p][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (p != 0 || e >= 64 * 64 + 64) return;
+    a = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
     if (e < 64 * 64) {
         const int i = e >> 6, j = e & 63;
         if (i < kdim && j < ndim) dW[i * ldw + j] = (accum ? dW[i * ldw + j] : 0.0f) + (float)a;
@@ -512,18 +582,18 @@ struct Launcher {
         for (int a = 0; a < kdim; a += 64)
             for (int c = 0; c < ndim; c += 64) {
                 const int ka = kdim - a < 64 ? kdim - a : 64, nc = ndim - c < 64 ? ndim - c : 64;
-                hipLaunchKernelGGL(xtd_kernel, dim3(nblk), dim3(256), 0, s, X + a, ld, ka, D + c, ld, nc, partial, N,
+                hipLaunchKernelGGL(xtd_kernel, dim3(nblk), dim3(1024), 0, s, X + a, ld, ka, D + c, ld, nc, partial, N,
                                    gather);
-                hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64 + 255) / 256), dim3(256), 0, s, partial,
+                hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64), dim3(256), 0, s, partial,
                                    nblk, dW + (int64_t)a * ldw + c, ldw, ka, nc, a == 0 && db ? db + c : nullptr, accum);
             }
     }
     // all nine taps of a 3x3x1 kernel gradient in two launches: dK[tap] = X[nbr(., tap)]^T D, db = sum D
     void xtd9(const float* X, int U, const float* D, float* partial, int nblk, float* dK9, float* db,
               const qbold_geometry& gm) const {
-        hipLaunchKernelGGL(xtd_kernel, dim3(nblk, 9), dim3(256), 0, s, X, kLd, U, D, kLd, U, partial, N,
+        hipLaunchKernelGGL(xtd_kernel, dim3(nblk, 9), dim3(1024), 0, s, X, kLd, U, D, kLd, U, partial, N,
                            Gather{gm.X, gm.Y, gm.Z, 0, 0});
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64 + 255) / 256, 9), dim3(256), 0, s, partial,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64, 9), dim3(256), 0, s, partial,
                            nblk, dK9, U, U, U, db, 0);
     }
     int ew() const {
@@ -546,7 +616,7 @@ int check_layerwise_shape(const qbold_ctx* ctx, const qbold_encoder_shape* s) {
     return QBOLD_OK;
 }
 
-constexpr int kSlabBlocks = 128;
+constexpr int kSlabBlocks = 512;  // xtd partial slabs per launch: two 1024-thread blocks per CU
 
 }  // namespace
 
@@ -671,10 +741,20 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                        stream_sel == 2 ? g_ls : nullptr, T, sums, dA, ld, N);
     const float* last = stream_sel == 1 ? slot(2 + L - 1) : slot(6 + 5 * (L - 1));
     // dWf, dbf (and dWs, dbs), d_last = g_q Wf^T (+ g_ls Ws^T)
-    k.xtd(last, U, dA, 5, partial, kSlabBlocks, grad + c.Wf, 5, grad + c.bf, 0);
+    // xtd slabs per launch: whole rounds of two 1024-thread blocks per CU, about 1024 voxels per block
+    // and tap (fewer, longer blocks leave a ragged last round; more pay the 16 KiB epilogue too often)
+    auto slab_count = [&](int taps) {
+        const int64_t per_round = 2 * (int64_t)ctx->num_cus;
+        int64_t rounds = (N * taps / 1024) / per_round;
+        if (rounds < 1) rounds = 1;
+        int64_t nb = rounds * per_round / taps;
+        return (int)(nb < 1 ? 1 : (nb > kSlabBlocks ? kSlabBlocks : nb));
+    };
+    const int slabs = slab_count(1), slabs9 = slab_count(9);
+    k.xtd(last, U, dA, 5, partial, slabs, grad + c.Wf, 5, grad + c.bf, 0);
     k.xw(dA, ld, 5, w + c.Wf, 5, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
     if (stream_sel == 2 && g_ls) {
-        k.xtd(last, U, dA + 5, T, partial, kSlabBlocks, grad + c.Ws, T, grad + c.bs, 0);
+        k.xtd(last, U, dA + 5, T, partial, slabs, grad + c.Ws, T, grad + c.bs, 0);
         k.xw(dA + 5, ld, T, w + c.Ws, T, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
     }
     // dB = gradient wrt the last activation tensor
@@ -686,7 +766,7 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             const float* a_in = l == 0 ? slot(1) : slot(2 + l - 1);
             // through the relu: dC = dB * (a_out > 0)
             hipLaunchKernelGGL(mask_mul_kernel, dim3(k.ew()), dim3(256), 0, k.s, dB, a_out, dC, N * ld);
-            k.xtd(a_in, U, dC, U, partial, kSlabBlocks, gb + c.Wc, U, gb + c.bc, 0);
+            k.xtd(a_in, U, dC, U, partial, slabs, gb + c.Wc, U, gb + c.bc, 0);
             k.xw(dC, ld, U, wb + c.Wc, U, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
         }
     } else {
@@ -700,34 +780,34 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             hipLaunchKernelGGL(gate_bwd_kernel, dim3(k.grid()), dim3(256), 0, k.s, dB, gl, skip, r, dC, dD,
                                dE, shape->gate_offset, U, G, ld, N);
             // gating conv: dWg = r^T dE; d r += dE Wg^T
-            k.xtd(r, U, dE, G, partial, kSlabBlocks, gb + c.Wg, G, gb + c.bg, 0);
+            k.xtd(r, U, dE, G, partial, slabs, gb + c.Wg, G, gb + c.bg, 0);
             k.xw(dE, ld, G, wb + c.Wg, G, 1, nullptr, dD, U, ACT_NONE, 1, nullptr);
             if (gm) {
                 // second residual conv (3x3x1): dK2[tap] = t[nbr]^T dD; d t_pre = conv^T(dD) * (t > 0) -> dE
-                k.xtd9(t, U, dD, partial, kSlabBlocks, gb + c.Wr2, gb + c.br2, *gm);
+                k.xtd9(t, U, dD, partial, slabs9, gb + c.Wr2, gb + c.br2, *gm);
                 k.conv3x3(dD, wb + c.Wr2, U, nullptr, dE, ACT_NONE, 1, t, *gm);
                 // first residual conv: input relu(b_in)
                 hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, b_in, dD, N * ld);
-                k.xtd9(dD, U, dE, partial, kSlabBlocks, gb + c.Wr1, gb + c.br1, *gm);
+                k.xtd9(dD, U, dE, partial, slabs9, gb + c.Wr1, gb + c.br1, *gm);
                 k.conv3x3(dE, wb + c.Wr1, U, nullptr, dB, ACT_NONE, 1, b_in, *gm);
             } else {
                 const int ctr = c.taps == 9 ? 4 * U * U : 0;
                 // second residual conv: dWr2 = t^T dD; d t_pre = (dD Wr2^T) * (t > 0)  -> dE
-                k.xtd(t, U, dD, U, partial, kSlabBlocks, gb + c.Wr2 + ctr, U, gb + c.br2, 0);
+                k.xtd(t, U, dD, U, partial, slabs, gb + c.Wr2 + ctr, U, gb + c.br2, 0);
                 k.xw(dD, ld, U, wb + c.Wr2 + ctr, U, 1, nullptr, dE, U, ACT_NONE, 0, t);
                 // first residual conv: input relu(b_in): dWr1 = relu(b_in)^T dE; d b_in = (dE Wr1^T) * (b_in > 0)
                 hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, b_in, dD, N * ld);
-                k.xtd(dD, U, dE, U, partial, kSlabBlocks, gb + c.Wr1 + ctr, U, gb + c.br1, 0);
+                k.xtd(dD, U, dE, U, partial, slabs, gb + c.Wr1 + ctr, U, gb + c.br1, 0);
                 k.xw(dE, ld, U, wb + c.Wr1 + ctr, U, 1, nullptr, dB, U, ACT_NONE, 0, b_in);
             }
             // skip conv: dWc = b_in^T dC; d b_in += dC Wc^T
-            k.xtd(b_in, U, dC, U, partial, kSlabBlocks, gb + c.Wc, U, gb + c.bc, 0);
+            k.xtd(b_in, U, dC, U, partial, slabs, gb + c.Wc, U, gb + c.bc, 0);
             k.xw(dC, ld, U, wb + c.Wc, U, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
         }
     }
     // first layer: delta_pre = dB * (h > 0); dW0 = n^T delta_pre
     hipLaunchKernelGGL(mask_mul_kernel, dim3(k.ew()), dim3(256), 0, k.s, dB, slot(1), dC, N * ld);
-    k.xtd(slot(0), T, dC, U, partial, kSlabBlocks, grad + c.W0, U, grad + c.b0, 0);
+    k.xtd(slot(0), T, dC, U, partial, slabs, grad + c.W0, U, grad + c.b0, 0);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }
