@@ -182,12 +182,14 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
                                                      int ldy, int act, const float* __restrict__ mask,
                                                      int ldm, int64_t N, Gather g0) {
     extern __shared__ float Wl[];  // [9][64][kWs]: all nine taps stay resident (146 KiB), one block per CU
+    const bool vout = (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
+                      (!mask || ((ldm & 3) == 0 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0));
     for (int e = threadIdx.x; e < 9 * 64 * 64; e += 1024) {
         const int tap = e >> 12, k = (e >> 6) & 63, j = e & 63;
         const float* W = K9 + (int64_t)tap * U * U;
         float v = 0.0f;
         if (k < U && j < U) v = flip ? W[j * U + k] : W[k * U + j];
-        Wl[(tap * 64 + k) * kWs + j] = v;
+        Wl[(tap * 64 + k) * kWs + (vout ? 16 * (j & 3) + (j >> 2) : j)] = v;  // columns permuted as in xw_kernel
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -221,19 +223,50 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
                 }
             }
         }
+        if (vout) {  // lane i holds columns 4 i .. 4 i + 3 of its four rows: one float4 store per row
+            const int j = 4 * i;
+            if (j < U) {
+                float bj[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int j = 16 * m + i;
-            if (j >= U) continue;
-            const float bj = b ? b[j] : 0.0f;
+                for (int m = 0; m < 4; ++m) bj[m] = (b && j + m < U) ? b[j + m] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t v = v0 + 4 * g + r;
-                if (v >= N) continue;
-                float y = acc[m][r] + bj;
-                if (act == ACT_RELU) y = fmaxf(y, 0.0f);
-                if (mask) y = mask[v * ldm + j] > 0.0f ? y : 0.0f;
-                Y[v * ldy + j] = y;
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t v = v0 + 4 * g + r;
+                    if (v >= N) continue;
+                    float y[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        y[m] = acc[m][r] + bj[m];
+                        if (act == ACT_RELU) y[m] = fmaxf(y[m], 0.0f);
+                    }
+                    if (j + 3 < U) {
+                        if (mask) {
+                            const float4 mk = *reinterpret_cast<const float4*>(mask + v * ldm + j);
+                            y[0] = mk.x > 0.0f ? y[0] : 0.0f; y[1] = mk.y > 0.0f ? y[1] : 0.0f;
+                            y[2] = mk.z > 0.0f ? y[2] : 0.0f; y[3] = mk.w > 0.0f ? y[3] : 0.0f;
+                        }
+                        *reinterpret_cast<float4*>(Y + v * ldy + j) = make_float4(y[0], y[1], y[2], y[3]);
+                    } else {
+                        for (int m = 0; m < 4 && j + m < U; ++m)
+                            Y[v * ldy + j + m] = (mask && !(mask[v * ldm + j + m] > 0.0f)) ? 0.0f : y[m];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int j = 16 * m + i;
+                if (j >= U) continue;
+                const float bj = b ? b[j] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t v = v0 + 4 * g + r;
+                    if (v >= N) continue;
+                    float y = acc[m][r] + bj;
+                    if (act == ACT_RELU) y = fmaxf(y, 0.0f);
+                    if (mask) y = mask[v * ldm + j] > 0.0f ? y : 0.0f;
+                    Y[v * ldy + j] = y;
+                }
             }
         }
     }
