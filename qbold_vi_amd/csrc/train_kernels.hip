@@ -32,14 +32,33 @@ enum { ACT_NONE = 0, ACT_RELU = 1 };
 // zeros outside the crop ('same' padding).  Z == 0 disables the gather.
 struct Gather {
     int X, Y, Z, dx, dy;
+    double iX, iY, iZ;  // reciprocals: the flat index is split by multiplies, not 64-bit divisions
 };
+inline Gather make_gather(int X, int Y, int Z, int dx, int dy) {
+    return Gather{X, Y, Z, dx, dy, X > 0 ? 1.0 / (double)X : 0.0, Y > 0 ? 1.0 / (double)Y : 0.0,
+                  Z > 0 ? 1.0 / (double)Z : 0.0};
+}
+// n = q d + r, 0 <= r < d, for 0 <= n < 2^51: the double product is within one of the quotient
+__device__ __forceinline__ void divmod(int64_t n, int d, double inv, int64_t& q, int& r) {
+    q = (int64_t)((double)n * inv);
+    int64_t rr = n - q * d;
+    if (rr < 0) { rr += d; --q; }
+    else if (rr >= d) { rr -= d; ++q; }
+    r = (int)rr;
+}
 __device__ __forceinline__ int64_t gather_row(const Gather& gt, int64_t v) {
     if (gt.Z == 0) return v;
-    const int64_t yz = (int64_t)gt.Y * gt.Z;
-    const int x = (int)((v / yz) % gt.X), y = (int)((v / gt.Z) % gt.Y);
+    // v = ((b X + x) Y + y) Z + z
+    int64_t q2, q3, q4;
+    int z, y, x;
+    divmod(v, gt.Z, gt.iZ, q2, z);
+    divmod(q2, gt.Y, gt.iY, q3, y);
+    divmod(q3, gt.X, gt.iX, q4, x);
+    (void)z;
+    (void)q4;
     const int xx = x + gt.dx, yy = y + gt.dy;
     if (xx < 0 || xx >= gt.X || yy < 0 || yy >= gt.Y) return -1;
-    return v + (int64_t)gt.dx * yz + (int64_t)gt.dy * gt.Z;
+    return v + ((int64_t)gt.dx * gt.Y + gt.dy) * gt.Z;
 }
 
 // Y[N][ldy] (cols < ndim) = act(X[N][ldx] (cols < kdim) . W + b), W given as Wl[k][j]:
@@ -202,7 +221,9 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
         for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         for (int tap = 0; tap < 9; ++tap) {
             const int dx = tap / 3 - 1, dy = tap % 3 - 1;
-            const Gather gt{g0.X, g0.Y, g0.Z, flip ? -dx : dx, flip ? -dy : dy};
+            Gather gt = g0;
+            gt.dx = flip ? -dx : dx;
+            gt.dy = flip ? -dy : dy;
             const int64_t va = gather_row(gt, v0 + i < N ? v0 + i : N - 1);
             if (__builtin_amdgcn_ballot_w64(va >= 0) == 0) continue;  // the whole tile reads padding
             const float* xr = X + (va < 0 ? 0 : va) * ldx + 4 * g;
@@ -306,42 +327,44 @@ __global__ __launch_bounds__(1024) void xtd_kernel(const float* __restrict__ X, 
                      ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D)) & 7) == 0;
     const int64_t nstep = (N + 3) / 4;  // 4 voxels per MFMA k-step
     const int64_t stride = (int64_t)gridDim.x * 4;
-    auto load = [&](int64_t st, float (&xa)[2], float (&dd)[2]) {
-        const int64_t v = st * 4 + g;
-        const bool ok = st < nstep && v < N;
+    // unconditional loads, zeroing deferred to the point of use (a select right behind a load makes the
+    // compiler wait for it and the prefetch would buy nothing); padded / invalid rows read row 0 or v itself
+    struct Raw {
+        float2 x, d;
+        unsigned in;  // bit 0: X row valid, bit 1: D row valid
+    };
+    auto load = [&](int64_t st, Raw& w) {
+        const int64_t v0 = st * 4 + g;
+        const bool ok = st < nstep && v0 < N;
+        const int64_t v = ok ? v0 : 0;
         const int64_t vx = ok ? gather_row(gt, v) : -1;
-        xa[0] = xa[1] = dd[0] = dd[1] = 0.0f;
+        w.in = (vx >= 0 ? 1u : 0u) | (ok ? 2u : 0u);
+        const float* xr = X + (vx >= 0 ? vx : v) * ldx + cx;
+        const float* dr = D + v * ldd + cd;
         if (vec) {
-            if (vx >= 0 && cx < kdim) {
-                const float2 t = *reinterpret_cast<const float2*>(X + vx * ldx + cx);
-                xa[0] = t.x;
-                xa[1] = cx + 1 < kdim ? t.y : 0.0f;
-            }
-            if (ok && cd < ndim) {
-                const float2 t = *reinterpret_cast<const float2*>(D + v * ldd + cd);
-                dd[0] = t.x;
-                dd[1] = cd + 1 < ndim ? t.y : 0.0f;
-            }
+            w.x = *reinterpret_cast<const float2*>(xr);
+            w.d = *reinterpret_cast<const float2*>(dr);
         } else {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                if (vx >= 0 && cx + m < kdim) xa[m] = X[vx * ldx + cx + m];
-                if (ok && cd + m < ndim) dd[m] = D[v * ldd + cd + m];
-            }
+            w.x = make_float2(xr[0], xr[1]);
+            w.d = make_float2(dr[0], dr[1]);
         }
     };
-    float xa[2], dd[2], xn[2], dn[2];
+    const bool kx0 = cx < kdim, kx1 = cx + 1 < kdim, nd0 = cd < ndim, nd1 = cd + 1 < ndim;
+    Raw cur, nxt;
     int64_t st = (int64_t)blockIdx.x * 4 + rg;
-    load(st, xa, dd);
+    load(st, cur);
     for (; st < nstep; st += stride) {
-        load(st + stride, xn, dn);  // next step's rows are in flight while this step's MFMAs run
+        load(st + stride, nxt);  // next step's rows are in flight while this step's MFMAs run
+        const bool okx = (cur.in & 1u) != 0, okd = (cur.in & 2u) != 0;
+        const float xa[2] = {okx && kx0 ? cur.x.x : 0.0f, okx && kx1 ? cur.x.y : 0.0f};
+        const float dd[2] = {okd && nd0 ? cur.d.x : 0.0f, okd && nd1 ? cur.d.y : 0.0f};
         dbsum[0] += dd[0];
         dbsum[1] += dd[1];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[a][c] = QB_MFMA16F(xa[a], dd[c], acc[a][c]);
-        xa[0] = xn[0]; xa[1] = xn[1]; dd[0] = dn[0]; dd[1] = dn[1];
+        cur = nxt;
     }
     // MFMA output: acc[a][c][r] of lane (i, g) is row 4 g + r, column i of tile (a, c).  The four row
     // groups add their quadrants one after the other; the four quadrant waves of a group write disjoint
@@ -371,14 +394,134 @@ __global__ __launch_bounds__(1024) void xtd_kernel(const float* __restrict__ X, 
     for (int e = threadIdx.x; e < 64 * 64 + 64; e += 1024) out[e] = red[e];
 }
 
+// All nine tap gradients of a 3x3x1 kernel in one pass over the rows: dK[tap] = X[nbr(., tap)]^T D.
+// A wave splits a 4-voxel step's flat index into crop coordinates once, reads its D half-row once and the
+// nine neighbour half-rows of X, and issues 36 MFMAs -- the per-step address arithmetic, which bounds the
+// one-tap-per-block form (about 100 VALU instructions against 4 MFMAs), is amortised over the taps.
+// 512 threads = 8 waves = 2 row groups x 4 output quadrants (144 accumulator registers per lane); partials
+// as xtd_kernel with gridDim.y == 9: tap t at partial + t * gridDim.x * (64*64 + 64), db in tap 0's slab.
+__global__ __launch_bounds__(512) void xtd9_kernel(const float* __restrict__ X, int ldx, int kdim,
+                                                   const float* __restrict__ D, int ldd, int ndim,
+                                                   float* __restrict__ partial, int64_t N, Gather gt) {
+    __shared__ float red[64 * 64 + 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int rg = wave >> 2, qa = (wave >> 1) & 1, qc = wave & 1;
+    f32x4 acc[9][2][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[t][a][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float dbsum[2] = {0.0f, 0.0f};
+    const int cx = 32 * qa + 2 * i, cd = 32 * qc + 2 * i;
+    const bool vec = ((ldx | ldd) & 1) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D)) & 7) == 0;
+    const int64_t nstep = (N + 3) / 4;
+    const int64_t stride = (int64_t)gridDim.x * 2;
+    // Loads are unconditional (a padded tap reads the voxel's own row, columns beyond kdim / ndim stay inside
+    // the row stride) and their zeroing is deferred to the point of use: a select right behind a load makes
+    // the compiler wait for it, which would serialise the ten loads of a step.
+    struct Raw {
+        float2 x[9], d;
+        unsigned in;  // bit t: tap t inside the crop; bit 9: row valid
+    };
+    auto load = [&](int64_t st, Raw& w) {
+        const int64_t v0 = st * 4 + g;
+        const bool ok = st < nstep && v0 < N;
+        const int64_t v = ok ? v0 : 0;
+        int64_t q2, q3, q4;
+        int z, y, x;
+        divmod(v, gt.Z, gt.iZ, q2, z);
+        divmod(q2, gt.Y, gt.iY, q3, y);
+        divmod(q3, gt.X, gt.iX, q4, x);
+        (void)z;
+        (void)q4;
+        w.in = ok ? 512u : 0u;
+        const float* dr = D + v * ldd + cd;
+        if (vec) w.d = *reinterpret_cast<const float2*>(dr);
+        else w.d = make_float2(dr[0], dr[1]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dx = t / 3 - 1, dy = t % 3 - 1;
+            const int xx = x + dx, yy = y + dy;
+            const bool in = ok && xx >= 0 && xx < gt.X && yy >= 0 && yy < gt.Y;
+            w.in |= in ? 1u << t : 0u;
+            const float* xr = X + (in ? v + ((int64_t)dx * gt.Y + dy) * gt.Z : v) * ldx + cx;
+            if (vec) w.x[t] = *reinterpret_cast<const float2*>(xr);
+            else w.x[t] = make_float2(xr[0], xr[1]);
+        }
+    };
+    const bool kx0 = cx < kdim, kx1 = cx + 1 < kdim, nd0 = cd < ndim, nd1 = cd + 1 < ndim;
+    Raw cur, nxt;
+    int64_t st = (int64_t)blockIdx.x * 2 + rg;
+    load(st, cur);
+    for (; st < nstep; st += stride) {
+        load(st + stride, nxt);  // the next step's ten half-rows are in flight during these 36 MFMAs
+        const bool ok = (cur.in & 512u) != 0;
+        const float dd[2] = {ok && nd0 ? cur.d.x : 0.0f, ok && nd1 ? cur.d.y : 0.0f};
+        dbsum[0] += dd[0];
+        dbsum[1] += dd[1];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const bool in = (cur.in >> t) & 1u;
+            const float xa[2] = {in && kx0 ? cur.x[t].x : 0.0f, in && kx1 ? cur.x[t].y : 0.0f};
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[t][a][c] = QB_MFMA16F(xa[a], dd[c], acc[t][a][c]);
+        }
+        cur = nxt;
+    }
+    float sm[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        sm[m] = dbsum[m];
+        sm[m] += __shfl_xor(sm[m], 16, 64);
+        sm[m] += __shfl_xor(sm[m], 32, 64);
+    }
+    // per tap: row group 0 writes its quadrants, row group 1 adds (fixed order), all threads store the slab
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            if (rg == ph) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* p = red + (32 * qa + 2 * (4 * g + r) + a) * 64 + 32 * qc + 2 * i + c;
+                            *p = ph == 0 ? acc[t][a][c][r] : *p + acc[t][a][c][r];
+                        }
+                if (qa == 0 && g == 0) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        float* p = red + 64 * 64 + cd + m;
+                        const float val = t == 0 ? sm[m] : 0.0f;
+                        *p = ph == 0 ? val : *p + val;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        float* out = partial + ((int64_t)t * gridDim.x + blockIdx.x) * (64 * 64 + 64);
+        for (int e = threadIdx.x; e < 64 * 64 + 64; e += 512) out[e] = red[e];
+        __syncthreads();
+    }
+}
+
 // dW[i * ldw + j] (+)= sum_blk partial[blk][i][j]; db[j] (+)= sum_blk partial[blk][4096 + j]
 // gridDim.y == 9: one 3x3x1 kernel -- tap t reads its own partials and writes dW + t * kdim * ndim; the
 // bias gradient comes from tap 0 only.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, int nblk,
-                                                           float* __restrict__ dW, int ldw, int kdim, int ndim,
-                                                           float* __restrict__ db, int accum) {
-    // 64 elements per block x 4 interleaved parts of the block range, added in a fixed order
-    __shared__ double part[4][64];
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ partial, int nblk,
+                                                            float* __restrict__ dW, int ldw, int kdim, int ndim,
+                                                            float* __restrict__ db, int accum) {
+    // 64 elements per block x 16 interleaved parts of the slab range, added in a fixed order
+    constexpr int kParts = 16;
+    __shared__ double part[kParts][64];
     const int e = blockIdx.x * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6;
     if (gridDim.y == 9) {
         partial += (int64_t)blockIdx.y * nblk * (64 * 64 + 64);
@@ -387,11 +530,13 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
     double a = 0.0;
     if (e < 64 * 64 + 64)
-        for (int bk = p; bk < nblk; bk += 4) a += (double)partial[(int64_t)bk * (64 * 64 + 64) + e];
+        for (int bk = p; bk < nblk; bk += kParts) a += (double)partial[(int64_t)bk * (64 * 64 + 64) + e];
     part[p][threadIdx.x & 63] = a;
     __syncthreads();
     if (p != 0 || e >= 64 * 64 + 64) return;
-    a = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    a = 0.0;
+#pragma unroll
+    for (int q = 0; q < kParts; ++q) a += part[q][threadIdx.x];
     if (e < 64 * 64) {
         const int i = e >> 6, j = e & 63;
         if (i < kdim && j < ndim) dW[i * ldw + j] = (accum ? dW[i * ldw + j] : 0.0f) + (float)a;
@@ -563,7 +708,7 @@ struct Launcher {
     hipStream_t s;
     int64_t N;
     int ld;  // row stride of the activation tensors (64, or U rounded up to 64 beyond that)
-    Gather gather{0, 0, 0, 0, 0};
+    Gather gather = make_gather(0, 0, 0, 0, 0);
     int grid() const {
         int64_t nb = (N + 63) / 64;
         int64_t cap = (int64_t)ctx->num_cus * 16;  // measured: 8 -> 12.8 ms, 16 -> 12.2 ms, 32 -> 12.3 ms per step
@@ -593,17 +738,17 @@ struct Launcher {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             hipLaunchKernelGGL(conv9_kernel, dim3((unsigned)(nb < cap ? (nb > 0 ? nb : 1) : cap)), dim3(1024), smem, s,
-                               X, ld, U, K9, flip, b, Y, ld, act, mask, ld, N, Gather{gm.X, gm.Y, gm.Z, 0, 0});
-            gather = Gather{0, 0, 0, 0, 0};
+                               X, ld, U, K9, flip, b, Y, ld, act, mask, ld, N, make_gather(gm.X, gm.Y, gm.Z, 0, 0));
+            gather = make_gather(0, 0, 0, 0, 0);
             return;
         }
         for (int tap = 0; tap < 9; ++tap) {
             const int dx = tap / 3 - 1, dy = tap % 3 - 1;
-            gather = Gather{gm.X, gm.Y, gm.Z, flip ? -dx : dx, flip ? -dy : dy};
+            gather = make_gather(gm.X, gm.Y, gm.Z, flip ? -dx : dx, flip ? -dy : dy);
             (void)xw_ld(X, ld, U, K9 + (int64_t)tap * U * U, U, flip, tap == 0 ? b : nullptr, Y, ld, U,
                         tap == 8 ? act : ACT_NONE, tap != 0, tap == 8 ? mask : nullptr);
         }
-        gather = Gather{0, 0, 0, 0, 0};
+        gather = make_gather(0, 0, 0, 0, 0);
     }
     void xw(const float* X, int ldx, int kdim, const float* W, int ldw, int trans, const float* b,
             float* Y, int ndim, int act, int accum, const float* mask) const {
@@ -617,16 +762,16 @@ struct Launcher {
                 const int ka = kdim - a < 64 ? kdim - a : 64, nc = ndim - c < 64 ? ndim - c : 64;
                 hipLaunchKernelGGL(xtd_kernel, dim3(nblk), dim3(1024), 0, s, X + a, ld, ka, D + c, ld, nc, partial, N,
                                    gather);
-                hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64), dim3(256), 0, s, partial,
+                hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64), dim3(1024), 0, s, partial,
                                    nblk, dW + (int64_t)a * ldw + c, ldw, ka, nc, a == 0 && db ? db + c : nullptr, accum);
             }
     }
     // all nine taps of a 3x3x1 kernel gradient in two launches: dK[tap] = X[nbr(., tap)]^T D, db = sum D
     void xtd9(const float* X, int U, const float* D, float* partial, int nblk, float* dK9, float* db,
               const qbold_geometry& gm) const {
-        hipLaunchKernelGGL(xtd_kernel, dim3(nblk, 9), dim3(1024), 0, s, X, kLd, U, D, kLd, U, partial, N,
-                           Gather{gm.X, gm.Y, gm.Z, 0, 0});
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64, 9), dim3(256), 0, s, partial,
+        hipLaunchKernelGGL(xtd9_kernel, dim3(nblk), dim3(512), 0, s, X, kLd, U, D, kLd, U, partial, N,
+                           make_gather(gm.X, gm.Y, gm.Z, 0, 0));
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64, 9), dim3(1024), 0, s, partial,
                            nblk, dK9, U, U, U, db, 0);
     }
     int ew() const {
@@ -783,7 +928,10 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
         int64_t nb = rounds * per_round / taps;
         return (int)(nb < 1 ? 1 : (nb > kSlabBlocks ? kSlabBlocks : nb));
     };
-    const int slabs = slab_count(1), slabs9 = slab_count(9);
+    const int slabs = slab_count(1);
+    // the nine-tap kernel runs one 512-thread block per CU (144 accumulator registers per lane)
+    const int slabs9 = (int)((N + 511) / 512 < ctx->num_cus ? ((N + 511) / 512 > 0 ? (N + 511) / 512 : 1)
+                                                           : (ctx->num_cus < kSlabBlocks ? ctx->num_cus : kSlabBlocks));
     k.xtd(last, U, dA, 5, partial, slabs, grad + c.Wf, 5, grad + c.bf, 0);
     k.xw(dA, ld, 5, w + c.Wf, 5, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
     if (stream_sel == 2 && g_ls) {
