@@ -96,14 +96,52 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
     const int g = lane >> 4, i = lane & 15;
     const int64_t ntile = (N + 15) / 16;
     const int ksteps = kpad >> 2;
+    // kdim <= 64 with aligned rows: the tile's four float4 per lane are loaded one tile ahead, unconditionally
+    // (a padded tap reads row 0; columns beyond kdim stay inside the row stride), and zeroed where they are
+    // used -- the next tile's rows are in flight during this tile's 64 MFMAs
+    const bool pre = vec && kdim <= 64 && ldx >= 64;
+    const int nq = (kdim + 15) >> 4;
+    float4 nxt[4];
+    int64_t nva = 0;
+    auto fetch = [&](int64_t tile) {
+        const int64_t t = tile < ntile ? tile : ntile - 1;
+        const int64_t v = t * 16 + i < N ? t * 16 + i : N - 1;
+        nva = gather_row(gt, v);
+        const float* xr = X + (nva < 0 ? 0 : nva) * ldx + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < nq) nxt[q] = *reinterpret_cast<const float4*>(xr + 16 * q);
+    };
+    if (pre && (int64_t)blockIdx.x * 4 + wave < ntile) fetch((int64_t)blockIdx.x * 4 + wave);
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
         const int64_t v0 = tile * 16;
-        const int64_t va = gather_row(gt, v0 + i < N ? v0 + i : N - 1);
         f32x4 acc[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (pre) {
+            float4 cur[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+            const bool rowok = nva >= 0;
+            fetch(tile + (int64_t)gridDim.x * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q >= nq) break;
+                const int k0 = 16 * q + 4 * g;
+                const float ac[4] = {rowok && k0 + 0 < kdim ? cur[q].x : 0.0f, rowok && k0 + 1 < kdim ? cur[q].y : 0.0f,
+                                     rowok && k0 + 2 < kdim ? cur[q].z : 0.0f, rowok && k0 + 3 < kdim ? cur[q].w : 0.0f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float* wr = Wl + (k0 + c) * kWs + i;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(ac[c], wr[16 * m], acc[m]);
+                }
+            }
+        }
+        const int64_t va = pre ? 0 : gather_row(gt, v0 + i < N ? v0 + i : N - 1);
         const float* xr = X + (va < 0 ? 0 : va) * ldx;
-        if (vec) {
+        if (pre) {
+        } else if (vec) {
             for (int q = 0; 16 * q < kdim; ++q) {
                 const int k0 = 16 * q + 4 * g;
                 float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
