@@ -749,7 +749,8 @@ struct Launcher {
     Gather gather = make_gather(0, 0, 0, 0, 0);
     int grid() const {
         int64_t nb = (N + 63) / 64;
-        int64_t cap = (int64_t)ctx->num_cus * 16;  // measured: 8 -> 12.8 ms, 16 -> 12.2 ms, 32 -> 12.3 ms per step
+        int64_t cap = (int64_t)ctx->num_cus * 4;  // 256-thread blocks per CU; measured per 1 M-voxel step with the
+                                                  // prefetching xw_kernel: 2 -> 8.4, 3 -> 7.6, 4 -> 7.3, 6 -> 7.7, 8 -> 7.4, 16 -> 7.5 ms
         return (int)(nb < cap ? (nb > 0 ? nb : 1) : cap);
     }
     // Y (row stride ldy) = act(X W + b); ndim output columns in slabs of 64
