@@ -26,7 +26,9 @@ constexpr int kLd = 64;        // row stride of the activation / delta tensors f
 constexpr int kMaxU = 256;     // forward-only layer-wise path (BASELINE config 3)
 constexpr int kWs = 65;        // LDS row stride of a staged weight matrix
 
-enum { ACT_NONE = 0, ACT_RELU = 1 };
+// bit 0: relu on the output; bit 1: relu on the INPUT rows as they are loaded (the reference's Activation
+// layer in front of a convolution, model.py:151 -- no materialised relu(b) tensor)
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU_IN = 2 };
 
 // Row gather of one 3x3x1 tap on a [B][X][Y][Z] crop batch: row v reads its (dx, dy) neighbour, or
 // zeros outside the crop ('same' padding).  Z == 0 disables the gather.
@@ -128,8 +130,12 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
             for (int q = 0; q < 4; ++q) {
                 if (q >= nq) break;
                 const int k0 = 16 * q + 4 * g;
-                const float ac[4] = {rowok && k0 + 0 < kdim ? cur[q].x : 0.0f, rowok && k0 + 1 < kdim ? cur[q].y : 0.0f,
-                                     rowok && k0 + 2 < kdim ? cur[q].z : 0.0f, rowok && k0 + 3 < kdim ? cur[q].w : 0.0f};
+                float ac[4] = {rowok && k0 + 0 < kdim ? cur[q].x : 0.0f, rowok && k0 + 1 < kdim ? cur[q].y : 0.0f,
+                               rowok && k0 + 2 < kdim ? cur[q].z : 0.0f, rowok && k0 + 3 < kdim ? cur[q].w : 0.0f};
+                if (act & ACT_RELU_IN) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ac[c] = fmaxf(ac[c], 0.0f);
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float* wr = Wl + (k0 + c) * kWs + i;
@@ -146,8 +152,12 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
                 const int k0 = 16 * q + 4 * g;
                 float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (va >= 0 && k0 < kdim) a = *reinterpret_cast<const float4*>(xr + k0);
-                const float ac[4] = {k0 + 0 < kdim ? a.x : 0.0f, k0 + 1 < kdim ? a.y : 0.0f,
-                                     k0 + 2 < kdim ? a.z : 0.0f, k0 + 3 < kdim ? a.w : 0.0f};
+                float ac[4] = {k0 + 0 < kdim ? a.x : 0.0f, k0 + 1 < kdim ? a.y : 0.0f,
+                               k0 + 2 < kdim ? a.z : 0.0f, k0 + 3 < kdim ? a.w : 0.0f};
+                if (act & ACT_RELU_IN) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ac[c] = fmaxf(ac[c], 0.0f);
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float* wr = Wl + (k0 + c) * kWs + i;
@@ -158,7 +168,8 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
         } else {
             for (int s = 0; s < ksteps; ++s) {
                 const int k = 4 * s + g;
-                const float a = (k < kdim && va >= 0) ? xr[k] : 0.0f;
+                float a = (k < kdim && va >= 0) ? xr[k] : 0.0f;
+                if (act & ACT_RELU_IN) a = fmaxf(a, 0.0f);
                 const float* wr = Wl + k * kWs + i;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(a, wr[16 * m], acc[m]);
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
                             const float4 o = *yp;
                             y[0] += o.x; y[1] += o.y; y[2] += o.z; y[3] += o.w;
                         }
-                        if (act == ACT_RELU) {
+                        if ((act & ACT_RELU)) {
 #pragma unroll
                             for (int m = 0; m < 4; ++m) y[m] = fmaxf(y[m], 0.0f);
                         }
@@ -197,7 +208,7 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
                         for (int m = 0; m < 4 && j + m < ndim; ++m) {
                             float t = y[m];
                             if (accum) t += Y[v * ldy + j + m];
-                            if (act == ACT_RELU) t = fmaxf(t, 0.0f);
+                            if ((act & ACT_RELU)) t = fmaxf(t, 0.0f);
                             if (mask) t = mask[v * ldm + j + m] > 0.0f ? t : 0.0f;
                             Y[v * ldy + j + m] = t;
                         }
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
                     if (v >= N) continue;
                     float y = acc[m][r] + bj;
                     if (accum) y += Y[v * ldy + j];
-                    if (act == ACT_RELU) y = fmaxf(y, 0.0f);
+                    if ((act & ACT_RELU)) y = fmaxf(y, 0.0f);
                     if (mask) y = mask[v * ldm + j] > 0.0f ? y : 0.0f;
                     Y[v * ldy + j] = y;
                 }
@@ -272,8 +283,12 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
                 float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (va >= 0) a = *reinterpret_cast<const float4*>(xr + 16 * q);
                 const int k0 = 16 * q + 4 * g;
-                const float ac[4] = {k0 + 0 < U ? a.x : 0.0f, k0 + 1 < U ? a.y : 0.0f,
-                                     k0 + 2 < U ? a.z : 0.0f, k0 + 3 < U ? a.w : 0.0f};
+                float ac[4] = {k0 + 0 < U ? a.x : 0.0f, k0 + 1 < U ? a.y : 0.0f,
+                               k0 + 2 < U ? a.z : 0.0f, k0 + 3 < U ? a.w : 0.0f};
+                if (act & ACT_RELU_IN) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ac[c] = fmaxf(ac[c], 0.0f);
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float* wr = Wt + (k0 + c) * kWs + i;
@@ -296,7 +311,7 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
                         y[m] = acc[m][r] + bj[m];
-                        if (act == ACT_RELU) y[m] = fmaxf(y[m], 0.0f);
+                        if ((act & ACT_RELU)) y[m] = fmaxf(y[m], 0.0f);
                     }
                     if (j + 3 < U) {
                         if (mask) {
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
                     const int64_t v = v0 + 4 * g + r;
                     if (v >= N) continue;
                     float y = acc[m][r] + bj;
-                    if (act == ACT_RELU) y = fmaxf(y, 0.0f);
+                    if ((act & ACT_RELU)) y = fmaxf(y, 0.0f);
                     if (mask) y = mask[v * ldm + j] > 0.0f ? y : 0.0f;
                     Y[v * ldy + j] = y;
                 }
@@ -341,7 +356,8 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
 // keeps 4 waves per SIMD streaming rows.
 __global__ __launch_bounds__(1024) void xtd_kernel(const float* __restrict__ X, int ldx, int kdim,
                                                    const float* __restrict__ D, int ldd, int ndim,
-                                                   float* __restrict__ partial, int64_t N, Gather gt) {
+                                                   float* __restrict__ partial, int64_t N, Gather gt,
+                                                   int relu_x) {
     __shared__ float red[64 * 64 + 64];
     if (gridDim.y == 9) {
         gt.dx = (int)blockIdx.y / 3 - 1;
@@ -394,7 +410,11 @@ __global__ __launch_bounds__(1024) void xtd_kernel(const float* __restrict__ X, 
     for (; st < nstep; st += stride) {
         load(st + stride, nxt);  // next step's rows are in flight while this step's MFMAs run
         const bool okx = (cur.in & 1u) != 0, okd = (cur.in & 2u) != 0;
-        const float xa[2] = {okx && kx0 ? cur.x.x : 0.0f, okx && kx1 ? cur.x.y : 0.0f};
+        float xa[2] = {okx && kx0 ? cur.x.x : 0.0f, okx && kx1 ? cur.x.y : 0.0f};
+        if (relu_x) {
+            xa[0] = fmaxf(xa[0], 0.0f);
+            xa[1] = fmaxf(xa[1], 0.0f);
+        }
         const float dd[2] = {okd && nd0 ? cur.d.x : 0.0f, okd && nd1 ? cur.d.y : 0.0f};
         dbsum[0] += dd[0];
         dbsum[1] += dd[1];
@@ -440,7 +460,8 @@ __global__ __launch_bounds__(1024) void xtd_kernel(const float* __restrict__ X, 
 // as xtd_kernel with gridDim.y == 9: tap t at partial + t * gridDim.x * (64*64 + 64), db in tap 0's slab.
 __global__ __launch_bounds__(512) void xtd9_kernel(const float* __restrict__ X, int ldx, int kdim,
                                                    const float* __restrict__ D, int ldd, int ndim,
-                                                   float* __restrict__ partial, int64_t N, Gather gt) {
+                                                   float* __restrict__ partial, int64_t N, Gather gt,
+                                                   int relu_x) {
     __shared__ float red[64 * 64 + 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -504,7 +525,11 @@ __global__ __launch_bounds__(512) void xtd9_kernel(const float* __restrict__ X, 
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const bool in = (cur.in >> t) & 1u;
-            const float xa[2] = {in && kx0 ? cur.x[t].x : 0.0f, in && kx1 ? cur.x[t].y : 0.0f};
+            float xa[2] = {in && kx0 ? cur.x[t].x : 0.0f, in && kx1 ? cur.x[t].y : 0.0f};
+            if (relu_x) {
+                xa[0] = fmaxf(xa[0], 0.0f);
+                xa[1] = fmaxf(xa[1], 0.0f);
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -656,12 +681,6 @@ __global__ void mask_mul_kernel(const float* __restrict__ in, const float* __res
         out[e] = ref[e] > 0.0f ? in[e] : 0.0f;
 }
 
-__global__ void relu_copy_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
-         e += (int64_t)gridDim.x * blockDim.x)
-        out[e] = fmaxf(in[e], 0.0f);
-}
-
 // synthetic_data_loss (model.py:449-514) and its gradient: loss_v = -log p(y_true; q)
 // Optional inverse-gamma prior on the two marginal variances (model.py:492-507, use_mvg branch):
 // loss -= log IG(exp(s_o)^2; a, b) + log IG(exp(s_d)^2 + q[4]^2; a, b) -- the RAW fifth parameter, as
@@ -785,7 +804,8 @@ struct Launcher {
             const int dx = tap / 3 - 1, dy = tap % 3 - 1;
             gather = make_gather(gm.X, gm.Y, gm.Z, flip ? -dx : dx, flip ? -dy : dy);
             (void)xw_ld(X, ld, U, K9 + (int64_t)tap * U * U, U, flip, tap == 0 ? b : nullptr, Y, ld, U,
-                        tap == 8 ? act : ACT_NONE, tap != 0, tap == 8 ? mask : nullptr);
+                        (tap == 8 ? (act & ACT_RELU) : ACT_NONE) | (act & ACT_RELU_IN), tap != 0,
+                        tap == 8 ? mask : nullptr);
         }
         gather = make_gather(0, 0, 0, 0, 0);
     }
@@ -795,21 +815,21 @@ struct Launcher {
     }
     // dW (+)= X^T D, db (+)= sum D: 64 x 64 slabs of the (kdim x ndim) product, one launch pair per slab
     void xtd(const float* X, int kdim, const float* D, int ndim, float* partial, int nblk, float* dW,
-             int ldw, float* db, int accum) const {
+             int ldw, float* db, int accum, int relu_x = 0) const {
         for (int a = 0; a < kdim; a += 64)
             for (int c = 0; c < ndim; c += 64) {
                 const int ka = kdim - a < 64 ? kdim - a : 64, nc = ndim - c < 64 ? ndim - c : 64;
                 hipLaunchKernelGGL(xtd_kernel, dim3(nblk), dim3(1024), 0, s, X + a, ld, ka, D + c, ld, nc, partial, N,
-                                   gather);
+                                   gather, relu_x);
                 hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64), dim3(1024), 0, s, partial,
                                    nblk, dW + (int64_t)a * ldw + c, ldw, ka, nc, a == 0 && db ? db + c : nullptr, accum);
             }
     }
     // all nine taps of a 3x3x1 kernel gradient in two launches: dK[tap] = X[nbr(., tap)]^T D, db = sum D
     void xtd9(const float* X, int U, const float* D, float* partial, int nblk, float* dK9, float* db,
-              const qbold_geometry& gm) const {
+              const qbold_geometry& gm, int relu_x = 0) const {
         hipLaunchKernelGGL(xtd9_kernel, dim3(nblk), dim3(512), 0, s, X, kLd, U, D, kLd, U, partial, N,
-                           make_gather(gm.X, gm.Y, gm.Z, 0, 0));
+                           make_gather(gm.X, gm.Y, gm.Z, 0, 0), relu_x);
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64, 9), dim3(1024), 0, s, partial,
                            nblk, dK9, U, U, U, db, 0);
     }
@@ -884,14 +904,13 @@ static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             float* skip = slot(2 + 5 * l), *t = slot(3 + 5 * l), *r = slot(4 + 5 * l);
             float* gl = slot(5 + 5 * l), *bout = slot(6 + 5 * l);
             k.xw(cur, ld, U, wb + c.Wc, U, 0, wb + c.bc, skip, U, ACT_RELU, 0, nullptr);
-            // relu(b) feeds the first residual conv; block 0's input h is already >= 0
-            hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, cur, bout, N * ld);
+            // relu(b) feeds the first residual conv (model.py:151): applied to the rows as they are loaded
             if (gm) {  // 3x3x1 'same' convolutions, model.py:152-157
-                k.conv3x3(bout, wb + c.Wr1, U, wb + c.br1, t, ACT_RELU, 0, nullptr, *gm);
+                k.conv3x3(cur, wb + c.Wr1, U, wb + c.br1, t, ACT_RELU | ACT_RELU_IN, 0, nullptr, *gm);
                 k.conv3x3(t, wb + c.Wr2, U, wb + c.br2, r, ACT_NONE, 0, nullptr, *gm);
             } else {   // voxel batch: centre tap only
                 const int ctr = c.taps == 9 ? 4 * U * U : 0;
-                k.xw(bout, ld, U, wb + c.Wr1 + ctr, U, 0, wb + c.br1, t, U, ACT_RELU, 0, nullptr);
+                k.xw(cur, ld, U, wb + c.Wr1 + ctr, U, 0, wb + c.br1, t, U, ACT_RELU | ACT_RELU_IN, 0, nullptr);
                 k.xw(t, ld, U, wb + c.Wr2 + ctr, U, 0, wb + c.br2, r, U, ACT_NONE, 0, nullptr);
             }
             k.xw(r, ld, U, wb + c.Wg, G, 0, wb + c.bg, gl, G, ACT_NONE, 0, nullptr);
@@ -1007,8 +1026,7 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                 k.xtd9(t, U, dD, partial, slabs9, gb + c.Wr2, gb + c.br2, *gm);
                 k.conv3x3(dD, wb + c.Wr2, U, nullptr, dE, ACT_NONE, 1, t, *gm);
                 // first residual conv: input relu(b_in)
-                hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, b_in, dD, N * ld);
-                k.xtd9(dD, U, dE, partial, slabs9, gb + c.Wr1, gb + c.br1, *gm);
+                k.xtd9(b_in, U, dE, partial, slabs9, gb + c.Wr1, gb + c.br1, *gm, 1);
                 k.conv3x3(dE, wb + c.Wr1, U, nullptr, dB, ACT_NONE, 1, b_in, *gm);
             } else {
                 const int ctr = c.taps == 9 ? 4 * U * U : 0;
@@ -1016,8 +1034,7 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                 k.xtd(t, U, dD, U, partial, slabs, gb + c.Wr2 + ctr, U, gb + c.br2, 0);
                 k.xw(dD, ld, U, wb + c.Wr2 + ctr, U, 1, nullptr, dE, U, ACT_NONE, 0, t);
                 // first residual conv: input relu(b_in): dWr1 = relu(b_in)^T dE; d b_in = (dE Wr1^T) * (b_in > 0)
-                hipLaunchKernelGGL(relu_copy_kernel, dim3(k.ew()), dim3(256), 0, k.s, b_in, dD, N * ld);
-                k.xtd(dD, U, dE, U, partial, slabs, gb + c.Wr1 + ctr, U, gb + c.br1, 0);
+                k.xtd(b_in, U, dE, U, partial, slabs, gb + c.Wr1 + ctr, U, gb + c.br1, 0, 1);
                 k.xw(dE, ld, U, wb + c.Wr1 + ctr, U, 1, nullptr, dB, U, ACT_NONE, 0, b_in);
             }
             // skip conv: dWc = b_in^T dC; d b_in += dC Wc^T
