@@ -81,9 +81,14 @@ __global__ __launch_bounds__(kGenBlock) void elbo_fwd_generic_kernel(
     float* is = yt + QB_MAX_T * kGenVox;                               // [T][kGenVox]
     __shared__ double red[3 * (kGenBlock / 64)];
     qb::fwd_lds_fill(L, g_tab, false);
+    if (threadIdx.x < QB_MAX_T) L->blood_B[threadIdx.x] = c.blood_B[threadIdx.x];
     __syncthreads();
 
     const int T = c.T, se = c.se_idx;
+    // tau = 0 at the spin echo and one-image normalisation (the reference's protocols): the signal is even
+    // in tau, so each pair tau_{se-j} = -tau_{se+j} is evaluated once, and the per-draw factors go into the
+    // exponents as in sample_sq_fast
+    const bool mirrored = !c.multi_norm && fmaf((float)se, c.tauh_step, c.tauh0) == 0.0f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int part = lane >> 4;
     const int vl = wave * QB_VOX_PER_WAVE + (lane & 15);  // voxel slot inside the block
@@ -135,6 +140,32 @@ __global__ __launch_bounds__(kGenBlock) void elbo_fwd_generic_kernel(
                     qb::reparam_logits(qm, d ? z[2] : z[0], d ? z[3] : z[1], a, b);
                     qb::forward_transform(a, b, oef, dbv);
                     const qb::FwdFast fv = qb::fwd_fast(c, oef, dbv);
+                    if (mirrored) {
+                        const float s_se = fmaf(fv.tissue_w, 1.0f, fv.blood_w * qb::exp2f_(fv.ng * L->blood_B[se]));
+                        const float inv_np = qb::rcpf_(s_se + 1e-3f);
+                        const float lt = qb::log2f_(fv.tissue_w * inv_np), lb = qb::log2f_(fv.blood_w * inv_np);
+                        auto signal = [&](int t) {
+                            const float u = fabsf(fmaf((float)t, fv.ub, fv.ua));
+                            const float4 kk = L->tab[(int)u];
+                            const float f = __builtin_amdgcn_fractf(u);
+                            const float F = fmaf(fmaf(fmaf(kk.w, f, kk.z), f, kk.y), f, kk.x);
+                            return qb::exp2f_(fmaf(fv.nd, F, lt)) + qb::exp2f_(fmaf(fv.ng, L->blood_B[t], lb));
+                        };
+                        float acc = 0.0f;
+                        auto residual = [&](int t, float yh) {
+                            const float r = (yt[t * kGenVox + vl] - yh) * is[t * kGenVox + vl];
+                            acc = fmaf(r, r, acc);
+                        };
+                        residual(se, s_se * inv_np);
+                        for (int t = se + 1; t < T; ++t) {
+                            const float yh = signal(t);
+                            residual(t, yh);
+                            if (2 * se - t >= 0) residual(2 * se - t, yh);
+                        }
+                        for (int t = 0; t < 2 * se - (T - 1); ++t) residual(t, signal(t));  // no partner on the grid
+                        nll_sum += acc;
+                        continue;
+                    }
                     float np_ = qb::fwd_signal_fast(L, c, fv, se);
                     if (c.multi_norm)
                         np_ = (np_ + qb::fwd_signal_fast(L, c, fv, se - 1) + qb::fwd_signal_fast(L, c, fv, se + 1)) / 3.0f;
