@@ -14,6 +14,10 @@
 #ifndef QB_PRIO_LIK
 #define QB_PRIO_LIK 1
 #endif
+#ifndef QB_LIK_BARRIER
+#define QB_LIK_BARRIER 2  // compiler barrier every this many evaluated taus of the likelihood loop (1: 0.517,
+                          // 2: 0.509, 3: 0.515, 4: 0.512, 8: 0.512, none: 0.514 ms)
+#endif
 #ifndef QB_PRIO_KL
 #define QB_PRIO_KL 3
 #endif
@@ -175,7 +179,7 @@ __device__ __forceinline__ float sample_sq_fast(const FwdLds* L, const QbDev& c,
                 const float yh = signal(t);
                 residual(t, yh);
                 if (2 * kSE - t >= 0) residual(2 * kSE - t, yh);
-                if (((t - kSE) & 1) == 0) asm volatile("" ::: "memory");
+                if (((t - kSE) % QB_LIK_BARRIER) == 0) asm volatile("" ::: "memory");
             }
 #pragma unroll
             for (int t = 0; t < 2 * kSE - (T - 1); ++t) residual(t, signal(t));  // no partner on the grid
