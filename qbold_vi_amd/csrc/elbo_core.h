@@ -68,7 +68,9 @@ __device__ __forceinline__ float se_norm(const QbDev& c, const float (&v)[T]) {
 
 // LOGSIG: `sigma` holds log sigma (the encoder's pre-activation, model.py:211-214) instead of sigma.
 // PRESCALE (fast path with a compile-time spin-echo index only): yt holds yt / sigma, see sample_sq_fast.
-template <int T, int SE, bool LOGSIG, bool PRESCALE = false>
+// LINEAR: the caller dispatched on the fast path (Gaussian likelihood on linear data), so the log-data and
+// Student-t switches are compiled out (left as run-time selects they cost 11 v_log + 50 selects per tile).
+template <int T, int SE, bool LOGSIG, bool PRESCALE = false, bool LINEAR = false>
 __device__ __forceinline__ void prepare_lik(const QbDev& c, const float (&x)[T],
                                             const float (&sigma)[T], float mask, VoxelLik<T>& k) {
     const float inv_nt = rcpf_(se_norm<T, SE>(c, x));
@@ -76,7 +78,7 @@ __device__ __forceinline__ void prepare_lik(const QbDev& c, const float (&x)[T],
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         float y = x[t] * inv_nt;
-        if (c.predict_log) y = mask > 0.0f ? __logf(y) : 0.0f;  // model.py:548
+        if (!LINEAR && c.predict_log) y = mask > 0.0f ? __logf(y) : 0.0f;  // model.py:548
         k.yt[t] = y;
         if (LOGSIG) {
             k.inv_s[t] = exp2f_(-QB_LOG2E * sigma[t]);
@@ -90,7 +92,7 @@ __device__ __forceinline__ void prepare_lik(const QbDev& c, const float (&x)[T],
 #pragma unroll
         for (int t = 0; t < T; ++t) k.yt[t] *= k.inv_s[t];
     }
-    k.log_s_sum = c.use_student_t ? ls : ls + (float)T * 0.9189385332046727f;  // log sqrt(2 pi)
+    k.log_s_sum = (!LINEAR && c.use_student_t) ? ls : ls + (float)T * 0.9189385332046727f;  // log sqrt(2 pi)
     k.mask = mask;
 }
 

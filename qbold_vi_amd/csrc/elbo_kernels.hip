@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void elbo_fwd_kernel(
             for (int i = 0; i < 5; ++i) qv[i] = q[v * 5 + i];
             const float m = mask ? mask[v] : 1.0f;
             qb::VoxelLik<T> lik;
-            qb::prepare_lik<T, SE, false, (FAST && SE >= 0)>(c, xv, sv, m, lik);
+            qb::prepare_lik<T, SE, false, (FAST && SE >= 0), FAST>(c, xv, sv, m, lik);
             const qb::LogitMvn qm = qb::make_mvn(qv);
             float nll_part, kl_part;
             qb::voxel_mc_sums<T, SE, FAST, LITERAL>(&L, c, lik, qm, prior + v * 5, S, K, zs ? zs + v * S * 2 : nullptr,

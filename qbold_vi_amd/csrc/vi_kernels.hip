@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
             for (int t = 0; t < T; ++t) sv[t] = o[5 + t];  // log sigma; sigma = exp(.), model.py:214
             const float m = mask ? mask[v] : 1.0f;
             qb::VoxelLik<T> lik;
-            qb::prepare_lik<T, SE, true, (FAST && SE >= 0)>(c, xv, sv, m, lik);
+            qb::prepare_lik<T, SE, true, (FAST && SE >= 0), FAST>(c, xv, sv, m, lik);
             const qb::LogitMvn qm = qb::make_mvn(qv);
             float nll_part, kl_part;
             qb::voxel_mc_sums<T, SE, FAST, LITERAL>(L, c, lik, qm, prior + v * 5, S, K, nullptr, nullptr, seed,
