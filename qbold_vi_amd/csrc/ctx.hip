@@ -130,6 +130,8 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
     const double td = (pow(2.6, 2.0) / 2.0) * 1e-3;     // signals.py:236-238
     d.td2 = (float)(td * td);
     d.e_r2b_te = expf((float)(-r2b * P->te));
+    d.bw_coef = d.include_blood ? d.m_bld_nb : 1.0f;
+    d.bwe_coef = d.include_blood ? d.e_r2b_te : 0.0f;
     {
         const float tef = (float)P->te, tdf = (float)td;
         const float te_td = (float)(P->te / td);

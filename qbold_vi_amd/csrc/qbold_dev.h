@@ -29,6 +29,8 @@ struct QbDev {
     float half_g2;   // 0.5 gamma^2                                     signals.py:241
     float td2;       // td^2                                            signals.py:241
     float e_r2b_te;  // exp(-r2b*te)                                    signals.py:241
+    float bw_coef;   // include_blood ? m_bld_nb : 1      (fast path: blood weight = bw_coef * dbv, no select)
+    float bwe_coef;  // include_blood ? e_r2b_te : 0      (fast path: blood_w = bw * bwe_coef)
     float tab_inv_h; // segments per unit x
     float tab_xmax;  // table covers |x| <= tab_xmax
     float dF_node0;  // slope of Simpson node 0 in dF/dx (see tissue_F)
@@ -419,9 +421,9 @@ __device__ __forceinline__ FwdFast fwd_fast(const QbDev& c, float oef, float dbv
     v.ua = c.tauh0 * dw;
     v.ub = c.tauh_step * dw;
     v.nd = -QB_LOG2E * dbv;
-    const float bw = c.include_blood ? c.m_bld_nb * dbv : dbv;
+    const float bw = c.bw_coef * dbv;  // m_bld_nb * dbv, or dbv without the blood compartment
     v.tissue_w = (1.0f - bw) * c.e_te_r2t;
-    v.blood_w = c.include_blood ? bw * c.e_r2b_te : 0.0f;
+    v.blood_w = bw * c.bwe_coef;       // bw * exp(-r2b te), or 0
     v.ng = c.ngk_l2e * (oef * oef);
     return v;
 }
