@@ -318,6 +318,15 @@ int qbold_encoder_train_bwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
 int qbold_synth_loss_bwd(const qbold_ctx* ctx, const float* y_true, int ld_y, const float* q, float* g_q,
                          float* loss_v, float scale, double inv_gamma_alpha, double inv_gamma_beta,
                          int64_t N, void* stream);
+/* The R2' term of synthetic_data_loss (use_r2p_loss, model.py:475-490): n_samples (reference: 10)
+ * reparameterised draws of (OEF, DBV) from q [N][5], r = dw(OEF) DBV (calculate_r2p :524-525), a normal
+ * fitted by the draws' mean and biased std, gaussian_nll (:403-404) of the true R2' y_true[:, 2] under it.
+ * ADDS the per-voxel value to loss_v [N] and scale * d / d q to g_q [N][5] (either may be NULL): call it
+ * after qbold_synth_loss_bwd.  z = explicit normals [N][n_samples][2] or NULL for the in-kernel Philox
+ * stream (seed, global voxel = voxel0 + i). */
+int qbold_r2p_loss_bwd(const qbold_ctx* ctx, const float* y_true, int ld_y, const float* q, const float* z,
+                       int n_samples, uint64_t seed, int64_t voxel0, float scale, float* g_q, float* loss_v,
+                       int64_t N, void* stream);
 /* One tfa.optimizers.AdamW step (train.py:308-310, 382-385) on a flat blob: decoupled decay
  * var -= weight_decay * var, Keras Adam moments and bias correction at step t >= 1, eps 1e-7. */
 int qbold_adamw_step(const qbold_ctx* ctx, float* params, const float* grads, float* m, float* v,

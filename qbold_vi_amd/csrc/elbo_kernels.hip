@@ -307,6 +307,90 @@ __global__ void moments_kernel(QbDev c, const float* __restrict__ q, const float
     }
 }
 
+// The R2' term of synthetic_data_loss (use_r2p_loss, model.py:475-490): n reparameterised draws of
+// (OEF, DBV) from the predicted distribution, r_k = dw(OEF_k) DBV_k, a normal fitted to the draws by their
+// mean and biased standard deviation (tf.math.reduce_std), and
+//   nll = log std + 0.5 ((y - mean) / std)^2                      gaussian_nll, model.py:403-404
+// for the true R2' y = y_true[:, 2].  Adds the value to loss_v and scale * d nll / d q to g_q [N][5]:
+//   d nll / d r_k = -(y - mean) / (n var) + (1 - (y - mean)^2 / var) (r_k - mean) / (n var),
+// chained through calculate_r2p, forward_transform, the reparameterisation and transform_std /
+// transform_offdiag.  Three passes over the same counter-generated draws (mean, variance, gradient).
+__global__ void r2p_loss_bwd_kernel(QbDev c, const float* __restrict__ y_true, int ldy,
+                                    const float* __restrict__ q, const float* __restrict__ z, int n,
+                                    uint64_t seed, int64_t voxel0, float scale, float* __restrict__ g_q,
+                                    float* __restrict__ loss_v, int64_t N) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float p[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) p[k] = q[i * 5 + k];
+        const qb::LogitMvn m = qb::make_mvn(p);
+        const float* zi = z ? z + i * n * 2 : nullptr;
+        const float y = y_true[i * ldy + 2];
+        const float inv_n = 1.0f / (float)n;
+        float mean = 0.0f, var = 0.0f, A = 0.0f, B = 0.0f;
+        float G[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // wrt mu_o, s_o, mu_d, s_d, c
+        for (int pass = 0; pass < 3; ++pass) {
+            float acc = 0.0f;
+            for (int j = 0; 2 * j < n; ++j) {
+                float zz[4];
+                const bool two = 2 * j + 1 < n;
+                if (zi) {
+                    zz[0] = zi[4 * j];
+                    zz[1] = zi[4 * j + 1];
+                    zz[2] = two ? zi[4 * j + 2] : 0.0f;
+                    zz[3] = two ? zi[4 * j + 3] : 0.0f;
+                } else {
+                    qb::normals4(seed, (uint64_t)(voxel0 + i), (uint32_t)j, qb::STREAM_R2P, zz);
+                }
+                for (int d = 0; d < (two ? 2 : 1); ++d) {
+                    const float z0 = zz[2 * d], z1 = zz[2 * d + 1];
+                    float a, b, oef, dbv;
+                    qb::reparam_logits(m, z0, z1, a, b);
+                    qb::forward_transform(a, b, oef, dbv);
+                    const float r = (c.dw_coef * oef) * dbv;  // calculate_r2p, model.py:524-525
+                    if (pass == 0) {
+                        acc += r;
+                    } else if (pass == 1) {
+                        acc += (r - mean) * (r - mean);
+                    } else {
+                        const float gr = A + B * (r - mean);
+                        // d sigmoid-range / d logit = (x - min) (1 - (x - min) / range)
+                        const float uo = oef - QB_MIN_OEF, ud = dbv - QB_MIN_DBV;
+                        const float da = gr * c.dw_coef * dbv * uo * (1.0f - uo * (1.0f / QB_OEF_RANGE));
+                        const float db = gr * c.dw_coef * oef * ud * (1.0f - ud * (1.0f / QB_DBV_RANGE));
+                        G[0] += da;
+                        G[1] += da * z0 * m.e_so;
+                        G[2] += db;
+                        G[3] += db * z1 * m.e_sd;
+                        G[4] += db * z0;
+                    }
+                }
+            }
+            if (pass == 0) {
+                mean = acc * inv_n;
+            } else if (pass == 1) {
+                var = acc * inv_n;
+                const float iv = 1.0f / var, dy = y - mean;
+                A = -dy * iv * inv_n;
+                B = (1.0f - dy * dy * iv) * iv * inv_n;
+                if (loss_v) loss_v[i] += 0.5f * __logf(var) + 0.5f * dy * dy * iv;
+                if (!g_q) break;
+            }
+        }
+        if (g_q) {
+            const float th1 = (m.s_o + 1.0f) * (1.0f / 3.0f), th3 = (m.s_d + 1.0f) * (1.0f / 3.0f);
+            const float th4 = m.c * 7.38905609893065f;
+            float* g = g_q + i * 5;
+            g[0] += scale * G[0];
+            g[1] += scale * G[1] * 3.0f * (1.0f - th1 * th1);                    // transform_std
+            g[2] += scale * G[2];
+            g[3] += scale * G[3] * 3.0f * (1.0f - th3 * th3);
+            g[4] += scale * G[4] * 0.1353352832366127f * (1.0f - th4 * th4);      // transform_offdiag
+        }
+    }
+}
+
 int ew_grid(const qbold_ctx* ctx, int64_t N, int block) {
     int64_t nb = (N + block - 1) / block;
     int64_t cap = (int64_t)ctx->num_cus * 8;
@@ -473,6 +557,19 @@ extern "C" int qbold_posterior_moments(const qbold_ctx* ctx, const float* q, con
     QB_REQUIRE(N > 0 && q && means && n_samples >= 1, "qbold_posterior_moments: bad argument");
     hipLaunchKernelGGL(moments_kernel, dim3(ew_grid(ctx, N, 128)), dim3(128), 0, (hipStream_t)stream,
                        ctx->dev, q, z, n_samples, seed, voxel0, means, vars, N);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
+extern "C" int qbold_r2p_loss_bwd(const qbold_ctx* ctx, const float* y_true, int ld_y, const float* q,
+                                  const float* z, int n_samples, uint64_t seed, int64_t voxel0, float scale,
+                                  float* g_q, float* loss_v, int64_t N, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    if (N == 0) return QBOLD_OK;
+    QB_REQUIRE(N > 0 && y_true && q && ld_y >= 3 && n_samples >= 2 && (g_q || loss_v),
+               "qbold_r2p_loss_bwd: bad argument (y_true rows need the R2' column, at least two draws)");
+    hipLaunchKernelGGL(r2p_loss_bwd_kernel, dim3(ew_grid(ctx, N, 128)), dim3(128), 0, (hipStream_t)stream,
+                       ctx->dev, y_true, ld_y, q, z, n_samples, seed, voxel0, scale, g_q, loss_v, N);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }

@@ -170,7 +170,7 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, fl
     z1 = r * __builtin_amdgcn_sinf(u2);
 }
 
-enum { STREAM_LIK = 0, STREAM_KL = 1, STREAM_MOMENTS = 2 };
+enum { STREAM_LIK = 0, STREAM_KL = 1, STREAM_MOMENTS = 2, STREAM_R2P = 3 };
 
 // normals of draws (2*pair, 2*pair+1) of `stream` for global voxel `vox`
 __device__ __forceinline__ void normals4(uint64_t seed, uint64_t vox, uint32_t pair,

@@ -33,6 +33,8 @@ def _flat(t, c):
     return t.reshape(-1, c)
 
 
+R2P_LOSS_SAMPLES = 10   # n_samples of the R2' term, model.py:479
+
 class EncoderModel:
     """Stands in for the Keras `outer_model` of create_encoder (model.py:222): model(x) ->
     [out1 (stream 1, [...,5]), out2 (stream 2, [...,5]), sigma ([...,T])]."""
@@ -357,8 +359,6 @@ class EncoderTrainer:
                             inv_gamma_beta=0.0):
         """Pre-training loss (model.py:449-514): mean negative log density of the true (OEF, DBV),
         plus the inverse-gamma prior on the marginal variances when alpha * beta > 0 (:492-507)."""
-        if use_r2p_loss:
-            raise NotImplementedError("use_r2p_loss (model.py:475-490) is disabled in optimal.yaml")
         if self._infer_inv_gamma:
             raise NotImplementedError("infer_inv_gamma (model.py:493-496) is disabled in optimal.yaml")
         y = y_true_orig.reshape(-1, 3).contiguous()
@@ -366,8 +366,13 @@ class EncoderTrainer:
         offset = 0.0 if self._use_mvg else 1.8378770664093453   # logit_gaussian_log_prob, model.py:470
         if inv_gamma_alpha * inv_gamma_beta > 0.0:
             lv = self._ctx.synth_loss(y, q, inv_gamma_alpha, inv_gamma_beta)
-            return lv.mean() - offset
-        return self._ctx.logit_mvn_nlogp(y[:, :2], q).mean() - offset
+        else:
+            lv = self._ctx.logit_mvn_nlogp(y[:, :2], q)
+        if use_r2p_loss:   # model.py:475-490: ten reparameterised draws, a normal fitted to their R2'
+            self._r2p_calls = getattr(self, "_r2p_calls", 0) + 1
+            lv = lv.clone()
+            self._ctx.r2p_loss_bwd(y, q, R2P_LOSS_SAMPLES, seed=self._r2p_calls, loss_v=lv, want_grad=False)
+        return lv.mean() - offset
 
     def calculate_dw(self, oef):  # model.py:516-522
         from .signals import SignalGenerationLayer

@@ -331,6 +331,29 @@ class Context:
                                                     N, _stream()), "qbold_posterior_moments")
         return means, var
 
+    def r2p_loss_bwd(self, y_true, q, n_samples=10, z=None, seed=1, voxel0=0, scale=1.0, g_q=None,
+                     loss_v=None, want_grad=True):
+        """The R2' term of synthetic_data_loss (use_r2p_loss, model.py:475-490): ADDS the per-voxel value
+        to loss_v [N] and scale * d / d q to g_q [N, 5] (fresh zero tensors when not given).  y_true
+        [N, >= 3] carries the true R2' in column 2."""
+        y = _f32(y_true, "y_true")
+        q = _f32(q, "q", 5)
+        N = q.numel() // 5
+        if y.dim() != 2 or y.shape[0] != N or y.shape[1] < 3:
+            raise ValueError("y_true must be [N, >= 3] (OEF, DBV, R2')")
+        if z is not None:
+            z = _f32(z, "z", 2)
+            if z.numel() != N * n_samples * 2:
+                raise ValueError("z must be [N, n_samples, 2]")
+        if loss_v is None:
+            loss_v = torch.zeros(N, dtype=torch.float32, device=q.device)
+        if g_q is None and want_grad:
+            g_q = torch.zeros((N, 5), dtype=torch.float32, device=q.device)
+        _lib.check(self.lib.qbold_r2p_loss_bwd(self.handle, _ptr(y), int(y.shape[1]), _ptr(q), _ptr(z),
+                                               int(n_samples), int(seed), int(voxel0), float(scale),
+                                               _ptr(g_q), _ptr(loss_v), N, _stream()), "qbold_r2p_loss_bwd")
+        return loss_v, g_q
+
     # -- ELBO ------------------------------------------------------------------------------
     def elbo_fwd(self, x, mask, q, prior, sigma, S=1, K=70, zs=None, zk=None, seed=1, voxel0=0,
                  per_voxel=True):

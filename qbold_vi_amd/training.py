@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import distributed as qd
-from .model import EncoderTrainer
+from .model import EncoderTrainer, R2P_LOSS_SAMPLES
 from .ops import TrainState
 from .signals import SignalGenerationLayer, create_synthetic_dataset
 
@@ -157,6 +157,7 @@ def create_and_train_on_synthetic_data(config_dict, params, log=None, sample_siz
     steps = 0
     ig_a = float(_get(config_dict, "inv_gamma_alpha", 0.0) or 0.0)   # train.py:131-135
     ig_b = float(_get(config_dict, "inv_gamma_beta", 0.0) or 0.0)
+    use_r2p = bool(_get(config_dict, "use_r2p_loss", False))       # train.py:125, 388
     for epoch in range(int(_get(config_dict, "no_pt_epochs"))):
         perm = torch.randperm(n, generator=g, device=tx.device)
         losses = []
@@ -166,6 +167,9 @@ def create_and_train_on_synthetic_data(config_dict, params, log=None, sample_siz
             xb, yb = tx[idx[a:b]], ty[idx[a:b]]
             q1, _ = state.forward(xb, 1)
             lv, gq = state.synth_loss_bwd(yb, q1, ig_a, ig_b)
+            if use_r2p:   # model.py:475-490; fresh draws every step, keyed by the step and the global voxel
+                trainer.context.r2p_loss_bwd(yb, q1, R2P_LOSS_SAMPLES, seed=steps + 1, voxel0=int(b0 + a),
+                                             scale=1.0 / q1.shape[0], g_q=gq, loss_v=lv)
             if not trainer._use_mvg:   # logit_gaussian_log_prob (model.py:406-421): no log 2 pi, no Cholesky term
                 gq[:, 4] = 0.0
                 lv = lv - 1.8378770664093453
@@ -181,7 +185,7 @@ def create_and_train_on_synthetic_data(config_dict, params, log=None, sample_siz
         out1 = model.predict(vx, want=("out1",))[0] if vx.shape[0] else None
         metrics = {"epoch": epoch, "loss": loss}
         if out1 is not None:
-            metrics["val_loss"] = float(trainer.synthetic_data_loss(vy, out1, False, ig_a, ig_b))
+            metrics["val_loss"] = float(trainer.synthetic_data_loss(vy, out1, use_r2p, ig_a, ig_b))
             metrics["val_oef_metric"] = float(trainer.oef_metric(vy, out1))
             metrics["val_dbv_metric"] = float(trainer.dbv_metric(vy, out1))
             metrics["val_r2p_metric"] = float(trainer.r2p_metric(vy, out1))

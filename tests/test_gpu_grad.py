@@ -234,8 +234,9 @@ def test_inverse_gamma_prior_loss_and_head_gradient(ctx, oracle32, oracle64):
                         use_population_prior=False, use_mvg=True, predict_log_data=False)
     got = float(tr.synthetic_data_loss(dev(y3).reshape(n, 1, 1, 1, 3), dev(q).reshape(n, 1, 1, 1, 5), False, a, b))
     assert abs(got - want) < 1e-5 * abs(want)
-    with pytest.raises(NotImplementedError):
-        tr.synthetic_data_loss(dev(y3), dev(q), True, 0.0, 0.0)
+    # use_r2p_loss adds the R2' term (its own test below): the value changes and stays finite
+    with_r2p = float(tr.synthetic_data_loss(dev(y3).reshape(n, 1, 1, 1, 3), dev(q).reshape(n, 1, 1, 1, 5), True, a, b))
+    assert np.isfinite(with_r2p) and abs(with_r2p - got) > 1e-3
 
 
 @pytest.mark.parametrize("U,L,cw", [(60, 2, True), (24, 1, False), (128, 1, True), (80, 2, False), (96, 1, True)])
@@ -345,3 +346,53 @@ def test_adamw_matches_numpy(ctx):
         v = b2 * v + (1 - b2) * g * g
         w = w - lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m / (np.sqrt(v) + eps)
         np.testing.assert_allclose(ew.flat.cpu().numpy(), w, rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_r2p_loss_term_value_and_gradient(ctx, oracle32, oracle64):
+    """use_r2p_loss (model.py:475-490): ten reparameterised draws, r = dw(OEF) DBV, a normal fitted by the
+    draws' mean and biased std, gaussian_nll (:403-404) of the true R2'.  Value against the oracle's
+    posterior moments (float32 and float64) on the same explicit normals; head gradient against central
+    differences of the float64 expression; the in-kernel Philox stream against the oracle's; accumulation
+    into caller buffers."""
+    rng = np.random.default_rng(33)
+    n, ns = 300, 10
+    q = (rng.normal(size=(n, 5)) * 0.5).astype(np.float32)
+    z = rng.normal(size=(n, ns, 2)).astype(np.float32)
+    y3 = np.stack([rng.uniform(0.1, 0.7, n), rng.uniform(0.01, 0.15, n), rng.uniform(1.0, 8.0, n)], -1).astype(np.float32)
+
+    def nll_ref(orc, qq):
+        m, v = orc.moments(qq, z.astype(orc.dtype))
+        m, v = m[:, 2].astype(np.float64), v[:, 2].astype(np.float64)
+        return 0.5 * np.log(v) + 0.5 * (y3[:, 2] - m) ** 2 / v
+
+    lv, gq = ctx.r2p_loss_bwd(dev(y3), dev(q), ns, z=dev(z))
+    want64 = nll_ref(oracle64, q.astype(np.float64))
+    got = lv.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got - want64) / (np.abs(want64) + 1.0)) < 2e-4
+    assert np.max(np.abs(got - nll_ref(oracle32, q)) / (np.abs(want64) + 1.0)) < 2e-4
+    g = gq.cpu().numpy().astype(np.float64)
+    eps = 1e-5
+    for k in range(5):
+        d = np.zeros((n, 5)); d[:, k] = eps
+        fd = (nll_ref(oracle64, q.astype(np.float64) + d) - nll_ref(oracle64, q.astype(np.float64) - d)) / (2 * eps)
+        scale = np.abs(fd) + 0.05 * np.abs(g).max(axis=1) + 1e-2
+        assert np.max(np.abs(g[:, k] - fd) / scale) < 5e-3, k
+    # accumulation and scale: adds scale * gradient and the value to the caller's buffers
+    lv2 = torch.full((n,), 2.0, device="cuda"); gq2 = torch.ones((n, 5), device="cuda")
+    ctx.r2p_loss_bwd(dev(y3), dev(q), ns, z=dev(z), scale=0.25, g_q=gq2, loss_v=lv2)
+    assert torch.allclose(lv2, lv + 2.0, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(gq2, 1.0 + 0.25 * gq, rtol=1e-5, atol=1e-6)
+    # in-kernel Philox stream 3 = the oracle's normals for (seed, voxel0)
+    zp = oracle32.philox_normals(5, 3, 1000, n, ns)
+    lv3, gq3 = ctx.r2p_loss_bwd(dev(y3), dev(q), ns, seed=5, voxel0=1000)
+    lv4, gq4 = ctx.r2p_loss_bwd(dev(y3), dev(q), ns, z=dev(zp))
+    assert torch.allclose(lv3, lv4, rtol=2e-4, atol=2e-4)
+    assert float((gq3 - gq4).abs().max()) < 2e-3 * float(gq4.abs().max())
+    # odd draw counts use half a Philox call; fewer than two draws have no spread
+    lv5, _ = ctx.r2p_loss_bwd(dev(y3), dev(q), 7, z=dev(z[:, :7].copy()))
+    m7, v7 = oracle64.moments(q.astype(np.float64), z[:, :7].astype(np.float64))
+    w7 = 0.5 * np.log(v7[:, 2]) + 0.5 * (y3[:, 2] - m7[:, 2]) ** 2 / v7[:, 2]
+    assert np.max(np.abs(lv5.cpu().numpy() - w7) / (np.abs(w7) + 1.0)) < 2e-4
+    with pytest.raises(Exception):
+        ctx.r2p_loss_bwd(dev(y3), dev(q), 1)

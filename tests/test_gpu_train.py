@@ -84,6 +84,19 @@ def test_sweep_style_configuration_trains(tmp_path, monkeypatch):
     assert trainer.context.lib is not None and trainer._student_t_df == 2
 
 
+def test_r2p_loss_pretraining(tmp_path, monkeypatch):
+    """use_r2p_loss=True (train.py:125, 388; model.py:475-490): the pre-training loss carries the R2' term
+    and its gradient; the R2' error of the stream-1 predictions falls along with the loss."""
+    from qbold_vi_amd import training
+    monkeypatch.chdir(ROOT)
+    cfg = small_config(tmp_path, use_r2p_loss=True, no_pt_epochs=40, no_ft_epochs=1)
+    model, trainer, hist = training.train_model(cfg, pt_sample_size=200)
+    pt = [h for h in hist if "val_oef_metric" in h]
+    assert len(pt) == 40 and all(np.isfinite(h["loss"]) for h in hist)
+    assert pt[-1]["loss"] < pt[0]["loss"] - 3.0
+    assert pt[-1]["val_r2p_metric"] < 0.75 * pt[0]["val_r2p_metric"]
+
+
 def test_reference_argparse_defaults_train(tmp_path, monkeypatch):
     """`python train.py` without a YAML uses get_defaults() (train.py:150-187): the diagonal family
     (use_mvg=False), Student-t df = 2, log data, 3-image normalisation, 30 units, one block."""
