@@ -396,3 +396,42 @@ def test_r2p_loss_term_value_and_gradient(ctx, oracle32, oracle64):
     assert np.max(np.abs(lv5.cpu().numpy() - w7) / (np.abs(w7) + 1.0)) < 2e-4
     with pytest.raises(Exception):
         ctx.r2p_loss_bwd(dev(y3), dev(q), 1)
+
+
+@pytest.mark.gpu
+def test_weight_gradients_add_over_ragged_batches(ctx, oracle32):
+    """Batch sizes that are no multiple of the kernels' 4-voxel MFMA steps or 16-voxel tiles: the weight
+    gradient of a batch is the size-weighted sum of its parts' gradients (both streams' GEMM, weight-gradient
+    and slab-reduction kernels with ragged tails; one voxel alone as the smallest case)."""
+    from oracle.oracle import synth_inputs
+    from qbold_vi_amd.ops import TrainState
+    w, ew = _weights(ctx, 60, 2, True)
+    n = 1003
+    x, y = synth_inputs(n, seed=8, oracle=oracle32)
+    y3 = dev(np.concatenate([y, y[:, :1]], -1).astype(np.float32))
+    xd = dev(x)
+    st = TrainState(ctx, ew)
+
+    def grad_of(lo, hi):
+        q1, _ = st.forward(xd[lo:hi].contiguous(), 1)
+        _, gq = st.synth_loss_bwd(y3[lo:hi].contiguous(), q1)      # already divided by hi - lo
+        return st.backward(1, gq).double().clone() * (hi - lo)
+
+    full = grad_of(0, n)
+    parts = grad_of(0, 333) + grad_of(333, 1002) + grad_of(1002, 1003)
+    scale = float(full.abs().max())
+    assert float((full - parts).abs().max()) < 2e-5 * scale
+    # stream 2 through the ELBO head gradients
+    mask = torch.ones(n, device="cuda")
+    prior = ctx.encoder_fwd(ew, xd, want=("out1",))[0]
+
+    def grad2_of(lo, hi):
+        xs = xd[lo:hi].contiguous()
+        q, ls = st.forward(xs, 2)
+        sums, gq, gls, _ = ctx.elbo_bwd(xs, mask[lo:hi].contiguous(), q, prior[lo:hi].contiguous(), ls, 1, 6,
+                                        seed=3, voxel0=lo)
+        return st.backward(2, gq, gls, sums).double().clone() * (hi - lo)
+
+    full2 = grad2_of(0, n)
+    parts2 = grad2_of(0, 333) + grad2_of(333, 1002) + grad2_of(1002, 1003)
+    assert float((full2 - parts2).abs().max()) < 5e-5 * float(full2.abs().max())
