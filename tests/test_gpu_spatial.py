@@ -137,3 +137,26 @@ def test_spatial_weight_gradient_directional(ctx, oracle32, oracle64, U, L, cw):
         fd = (loss(_perturbed(w, direction, eps)) - loss(_perturbed(w, direction, -eps))) / (2 * eps)
         got = float(grad @ dflat)
         assert abs(got - fd) < 1e-2 * (abs(fd) + 0.05), (trial, got, fd)
+
+
+def test_spatial_gradients_add_over_crops_with_odd_sizes(ctx, oracle32):
+    """Crops whose voxel counts are no multiple of 4 or 16 (3 x 5 x 3 x 1 = 45, singles of 15): crops are
+    independent, so the gradient of the batch is the sum of the single-crop gradients -- the nine-tap
+    weight-gradient and convolution kernels with ragged tails and padded taps on every border."""
+    from qbold_vi_amd.ops import TrainState
+    w, ew = make(ctx, 60, 2, True)
+    B, X, Y, Z = 3, 5, 3, 1
+    x = dev(crop_batch(oracle32, B, X, Y, Z, seed=6))
+    rng = np.random.default_rng(2)
+    gq_all = dev(rng.normal(size=(B, X * Y * Z, 5)).astype(np.float32))
+    gls_all = dev(rng.normal(size=(B, X * Y * Z, 11)).astype(np.float32))
+    st = TrainState(ctx, ew)
+
+    def grad_of(b0, b1):
+        st.forward_spatial(x[b0:b1].contiguous())
+        return st.backward_spatial(gq_all[b0:b1].reshape(-1, 5).contiguous(),
+                                   gls_all[b0:b1].reshape(-1, 11).contiguous(), None).double().clone()
+
+    full = grad_of(0, B)
+    parts = grad_of(0, 1) + grad_of(1, 2) + grad_of(2, 3)
+    assert float((full - parts).abs().max()) < 2e-5 * float(full.abs().max())
