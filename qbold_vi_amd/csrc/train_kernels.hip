@@ -349,42 +349,43 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
 // partial[blk][64*64 + 64]: dW[i][j] = sum_v X[v][i] D[v][j] over this block's voxels, then db[j]
 // gridDim.y == 9: blockIdx.y is the tap of a 3x3x1 kernel (gt carries the crop geometry only) and the
 // partials of tap t start at partial + t * gridDim.x * (64*64 + 64).
-// 1024 threads = 16 waves = 4 row groups x 4 output quadrants: wave (rg, qa, qc) accumulates the 32 x 32
-// quadrant (X columns 32 qa.., D columns 32 qc..) over the 4-voxel steps st = rg (mod 4) of its block --
-// 16 accumulator registers per lane instead of 64, so the in-block reduction over the row groups is 16
-// LDS adds per lane and phase (fixed order: bitwise reproducible, no float atomics), and one block per CU
-// keeps 4 waves per SIMD streaming rows.
+// 1024 threads = 16 waves, each accumulating the whole 64 x 64 product over its share of the 4-voxel steps
+// (64 accumulator registers per lane): 16 MFMAs per pair of 16-byte loads keep the per-step index / mask
+// arithmetic, which f32 MFMAs do not overlap, at a quarter of the MFMA time (a 32 x 32 quadrant per wave
+// spent more on it than on its 4 MFMAs).  One block per CU; the in-block reduction uses eight 16 KiB tiles
+// of dynamic LDS: waves 0-7 store their tiles, waves 8-15 add theirs on top (one writer per address), and all
+// threads add the eight tiles in a fixed order -- three barriers, bitwise reproducible, no float atomics.
+constexpr int kXtdTiles = 8;
+constexpr size_t kXtdSmem = sizeof(float) * kXtdTiles * (64 * 64 + 64);
+template <bool VEC>
 __global__ __launch_bounds__(1024) void xtd_kernel(const float* __restrict__ X, int ldx, int kdim,
                                                    const float* __restrict__ D, int ldd, int ndim,
                                                    float* __restrict__ partial, int64_t N, Gather gt,
                                                    int relu_x) {
-    __shared__ float red[64 * 64 + 64];
+    extern __shared__ float red8[];  // [kXtdTiles][64 * 64 + 64]
     if (gridDim.y == 9) {
         gt.dx = (int)blockIdx.y / 3 - 1;
         gt.dy = (int)blockIdx.y % 3 - 1;
         partial += (int64_t)blockIdx.y * gridDim.x * (64 * 64 + 64);
     }
-    for (int e = threadIdx.x; e < 64 * 64 + 64; e += 1024) red[e] = 0.0f;
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
-    const int rg = wave >> 2, qa = (wave >> 1) & 1, qc = wave & 1;
-    f32x4 acc[2][2];
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) acc[a][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    float dbsum[2] = {0.0f, 0.0f};
-    // tile a of lane i stands for X column 32 qa + 2 i + a (8-byte loads), tile c for D column 32 qc + 2 i + c
-    const int cx = 32 * qa + 2 * i, cd = 32 * qc + 2 * i;
-    const bool vec = ((ldx | ldd) & 1) == 0 &&
-                     ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D)) & 7) == 0;
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float dbsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // 16-byte aligned rows are read as float4: tile m of lane i then stands for column 4 i + m instead of
+    // 16 m + i (a permutation of the output rows / columns, undone where the tiles are reduced)
+    constexpr bool vec = VEC;  // the launcher checks alignment
     const int64_t nstep = (N + 3) / 4;  // 4 voxels per MFMA k-step
-    const int64_t stride = (int64_t)gridDim.x * 4;
+    const int64_t stride = (int64_t)gridDim.x * 16;
     // unconditional loads, zeroing deferred to the point of use (a select right behind a load makes the
-    // compiler wait for it and the prefetch would buy nothing); padded / invalid rows read row 0 or v itself
+    // compiler wait for it and the prefetch would buy nothing); padded / invalid rows read row 0 or v itself,
+    // columns beyond kdim / ndim stay inside the row stride
     struct Raw {
-        float2 x, d;
+        float x[4], d[4];
         unsigned in;  // bit 0: X row valid, bit 1: D row valid
     };
     auto load = [&](int64_t st, Raw& w) {
@@ -393,63 +394,95 @@ __global__ __launch_bounds__(1024) void xtd_kernel(const float* __restrict__ X, 
         const int64_t v = ok ? v0 : 0;
         const int64_t vx = ok ? gather_row(gt, v) : -1;
         w.in = (vx >= 0 ? 1u : 0u) | (ok ? 2u : 0u);
-        const float* xr = X + (vx >= 0 ? vx : v) * ldx + cx;
-        const float* dr = D + v * ldd + cd;
+        const float* xr = X + (vx >= 0 ? vx : v) * ldx;
+        const float* dr = D + v * ldd;
         if (vec) {
-            w.x = *reinterpret_cast<const float2*>(xr);
-            w.d = *reinterpret_cast<const float2*>(dr);
+            const float4 a = *reinterpret_cast<const float4*>(xr + 4 * i);
+            const float4 b = *reinterpret_cast<const float4*>(dr + 4 * i);
+            w.x[0] = a.x; w.x[1] = a.y; w.x[2] = a.z; w.x[3] = a.w;
+            w.d[0] = b.x; w.d[1] = b.y; w.d[2] = b.z; w.d[3] = b.w;
         } else {
-            w.x = make_float2(xr[0], xr[1]);
-            w.d = make_float2(dr[0], dr[1]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                w.x[m] = xr[16 * m + i];
+                w.d[m] = dr[16 * m + i];
+            }
         }
     };
-    const bool kx0 = cx < kdim, kx1 = cx + 1 < kdim, nd0 = cd < ndim, nd1 = cd + 1 < ndim;
-    Raw cur, nxt;
-    int64_t st = (int64_t)blockIdx.x * 4 + rg;
-    load(st, cur);
-    for (; st < nstep; st += stride) {
-        load(st + stride, nxt);  // next step's rows are in flight while this step's MFMAs run
-        const bool okx = (cur.in & 1u) != 0, okd = (cur.in & 2u) != 0;
-        float xa[2] = {okx && kx0 ? cur.x.x : 0.0f, okx && kx1 ? cur.x.y : 0.0f};
-        if (relu_x) {
-            xa[0] = fmaxf(xa[0], 0.0f);
-            xa[1] = fmaxf(xa[1], 0.0f);
-        }
-        const float dd[2] = {okd && nd0 ? cur.d.x : 0.0f, okd && nd1 ? cur.d.y : 0.0f};
-        dbsum[0] += dd[0];
-        dbsum[1] += dd[1];
+    bool kx[4], nd[4];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[a][c] = QB_MFMA16F(xa[a], dd[c], acc[a][c]);
-        cur = nxt;
+    for (int m = 0; m < 4; ++m) {
+        const int col = vec ? 4 * i + m : 16 * m + i;
+        kx[m] = col < kdim;
+        nd[m] = col < ndim;
     }
-    // MFMA output: acc[a][c][r] of lane (i, g) is row 4 g + r, column i of tile (a, c).  The four row
-    // groups add their quadrants one after the other; the four quadrant waves of a group write disjoint
-    // parts of red.
-    for (int ph = 0; ph < 4; ++ph) {
-        if (rg == ph) {
+    // Two buffers in rotation, the loop unrolled by two so that no buffer is ever copied: a register move
+    // out of an in-flight load makes the wave wait for it, which (with `cur = nxt` at the end of the trip)
+    // delayed the next load until the previous one had landed.  Steps past the end read row 0 and
+    // contribute zeros.
+    auto compute = [&](const Raw& w) {
+        const bool okx = (w.in & 1u) != 0, okd = (w.in & 2u) != 0;
+        float xa[4], dd[4];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+        for (int m = 0; m < 4; ++m) {
+            xa[m] = okx && kx[m] ? w.x[m] : 0.0f;
+            if (relu_x) xa[m] = fmaxf(xa[m], 0.0f);
+            dd[m] = okd && nd[m] ? w.d[m] : 0.0f;
+            dbsum[m] += dd[m];
+        }
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        red[(32 * qa + 2 * (4 * g + r) + a) * 64 + 32 * qc + 2 * i + c] += acc[a][c][r];
-            if (qa == 0) {
+            for (int c = 0; c < 4; ++c) acc[a][c] = QB_MFMA16F(xa[a], dd[c], acc[a][c]);
+    };
+    Raw b0, b1;
+    int64_t st = (int64_t)blockIdx.x * 16 + wave;
+    load(st, b0);
+    for (; st < nstep; st += 2 * stride) {
+        load(st + stride, b1);
+        compute(b0);
+        load(st + 2 * stride, b0);
+        compute(b1);
+    }
+    // MFMA output: acc[a][c][r] of lane (i, g) is row 4 g + r, column i of tile (a, c)
+    float sm[4];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    float sm = dbsum[m];
-                    sm += __shfl_xor(sm, 16, 64);
-                    sm += __shfl_xor(sm, 32, 64);
-                    if (g == 0) red[64 * 64 + cd + m] += sm;
+    for (int m = 0; m < 4; ++m) {
+        sm[m] = dbsum[m];
+        sm[m] += __shfl_xor(sm[m], 16, 64);
+        sm[m] += __shfl_xor(sm[m], 32, 64);
+    }
+    float* red = red8 + (wave & (kXtdTiles - 1)) * (64 * 64 + 64);
+    for (int ph = 0; ph < 2; ++ph) {
+        if ((wave >> 3) == ph) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = vec ? 4 * (4 * g + r) + a : 16 * a + 4 * g + r;
+                        const int col = vec ? 4 * i + c : 16 * c + i;
+                        float* p = red + row * 64 + col;
+                        *p = ph == 0 ? acc[a][c][r] : *p + acc[a][c][r];
+                    }
+            if (g == 0) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    float* p = red + 64 * 64 + (vec ? 4 * i + m : 16 * m + i);
+                    *p = ph == 0 ? sm[m] : *p + sm[m];
                 }
             }
         }
         __syncthreads();
     }
     float* out = partial + (int64_t)blockIdx.x * (64 * 64 + 64);
-    for (int e = threadIdx.x; e < 64 * 64 + 64; e += 1024) out[e] = red[e];
+    for (int e = threadIdx.x; e < 64 * 64 + 64; e += 1024) {
+        float t[kXtdTiles];
+#pragma unroll
+        for (int b = 0; b < kXtdTiles; ++b) t[b] = red8[b * (64 * 64 + 64) + e];
+        out[e] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
 }
 
 // All nine tap gradients of a 3x3x1 kernel in one pass over the rows: dK[tap] = X[nbr(., tap)]^T D.
@@ -819,7 +852,14 @@ struct Launcher {
         for (int a = 0; a < kdim; a += 64)
             for (int c = 0; c < ndim; c += 64) {
                 const int ka = kdim - a < 64 ? kdim - a : 64, nc = ndim - c < 64 ? ndim - c : 64;
-                hipLaunchKernelGGL(xtd_kernel, dim3(nblk), dim3(1024), 0, s, X + a, ld, ka, D + c, ld, nc, partial, N,
+                const float* Xa = X + a;
+                const float* Dc = D + c;
+                const bool vec = (ld & 3) == 0 &&
+                                 ((reinterpret_cast<uintptr_t>(Xa) | reinterpret_cast<uintptr_t>(Dc)) & 15) == 0;
+                auto kern = vec ? xtd_kernel<true> : xtd_kernel<false>;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXtdSmem);
+                hipLaunchKernelGGL(kern, dim3(nblk), dim3(1024), kXtdSmem, s, Xa, ld, ka, Dc, ld, nc, partial, N,
                                    gather, relu_x);
                 hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64), dim3(1024), 0, s, partial,
                                    nblk, dW + (int64_t)a * ldw + c, ldw, ka, nc, a == 0 && db ? db + c : nullptr, accum);
@@ -979,12 +1019,12 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     // dWf, dbf (and dWs, dbs), d_last = g_q Wf^T (+ g_ls Ws^T)
     // xtd slabs per launch: whole rounds of two 1024-thread blocks per CU, about 1024 voxels per block
     // and tap (fewer, longer blocks leave a ragged last round; more pay the 16 KiB epilogue too often)
+    // xtd slabs per launch: one 1024-thread block per CU, at least 16 four-voxel steps per wave
     auto slab_count = [&](int taps) {
-        const int64_t per_round = 2 * (int64_t)ctx->num_cus;
-        int64_t rounds = (N * taps / 1024) / per_round;
-        if (rounds < 1) rounds = 1;
-        int64_t nb = rounds * per_round / taps;
-        return (int)(nb < 1 ? 1 : (nb > kSlabBlocks ? kSlabBlocks : nb));
+        (void)taps;
+        int64_t nb = N / (16 * 16 * 4);
+        const int64_t cap = ctx->num_cus < kSlabBlocks ? ctx->num_cus : kSlabBlocks;
+        return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
     };
     const int slabs = slab_count(1);
     // the nine-tap kernel runs one 512-thread block per CU (144 accumulator registers per lane)
