@@ -546,19 +546,15 @@ __global__ __launch_bounds__(512) void xtd9_kernel(const float* __restrict__ X, 
         }
     };
     const bool kx0 = cx < kdim, kx1 = cx + 1 < kdim, nd0 = cd < ndim, nd1 = cd + 1 < ndim;
-    Raw cur, nxt;
-    int64_t st = (int64_t)blockIdx.x * 2 + rg;
-    load(st, cur);
-    for (; st < nstep; st += stride) {
-        load(st + stride, nxt);  // the next step's ten half-rows are in flight during these 36 MFMAs
-        const bool ok = (cur.in & 512u) != 0;
-        const float dd[2] = {ok && nd0 ? cur.d.x : 0.0f, ok && nd1 ? cur.d.y : 0.0f};
+    auto compute = [&](const Raw& w) {
+        const bool ok = (w.in & 512u) != 0;
+        const float dd[2] = {ok && nd0 ? w.d.x : 0.0f, ok && nd1 ? w.d.y : 0.0f};
         dbsum[0] += dd[0];
         dbsum[1] += dd[1];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const bool in = (cur.in >> t) & 1u;
-            float xa[2] = {in && kx0 ? cur.x[t].x : 0.0f, in && kx1 ? cur.x[t].y : 0.0f};
+            const bool in = (w.in >> t) & 1u;
+            float xa[2] = {in && kx0 ? w.x[t].x : 0.0f, in && kx1 ? w.x[t].y : 0.0f};
             if (relu_x) {
                 xa[0] = fmaxf(xa[0], 0.0f);
                 xa[1] = fmaxf(xa[1], 0.0f);
@@ -568,7 +564,16 @@ __global__ __launch_bounds__(512) void xtd9_kernel(const float* __restrict__ X, 
 #pragma unroll
                 for (int c = 0; c < 2; ++c) acc[t][a][c] = QB_MFMA16F(xa[a], dd[c], acc[t][a][c]);
         }
-        cur = nxt;
+    };
+    // two buffers in rotation, unrolled by two: no register copies out of in-flight loads (see xtd_kernel)
+    Raw b0, b1;
+    int64_t st = (int64_t)blockIdx.x * 2 + rg;
+    load(st, b0);
+    for (; st < nstep; st += 2 * stride) {
+        load(st + stride, b1);   // the next step's ten half-rows are in flight during these 36 MFMAs
+        compute(b0);
+        load(st + 2 * stride, b0);
+        compute(b1);
     }
     float sm[2];
 #pragma unroll
