@@ -236,6 +236,106 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
     }
 }
 
+// The common shape of xw_kernel as a leaner kernel: kdim, ndim <= 64, 16-byte aligned rows on both sides, no
+// gather.  Same staging and k / column permutations; ACCUM / MASK are compile-time, and the rows of Y and of
+// the mask that the epilogue needs are requested BEFORE the tile's 64 MFMAs (read right before their use
+// they cost four dependent memory latencies per tile -- half of the backward launches accumulate or mask).
+template <bool ACCUM, bool MASK>
+__global__ __launch_bounds__(256) void xw64_kernel(const float* __restrict__ X, int ldx, int kdim,
+                                                   const float* __restrict__ W, int ldw, int trans,
+                                                   const float* __restrict__ b, float* __restrict__ Y, int ldy,
+                                                   int ndim, int act, const float* __restrict__ mask, int ldm,
+                                                   int64_t N) {
+    extern __shared__ float Wl[];
+    const int kpad = (kdim + 15) & ~15;
+    for (int e = threadIdx.x; e < kpad * 64; e += 256) {
+        const int k = e >> 6, j = e & 63;
+        float v = 0.0f;
+        if (k < kdim && j < ndim) v = trans ? W[j * ldw + k] : W[k * ldw + j];
+        Wl[k * kWs + 16 * (j & 3) + (j >> 2)] = v;   // tile m of lane i = column 4 i + m
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int64_t ntile = (N + 15) / 16;
+    const int nq = (kdim + 15) >> 4;
+    const int j = 4 * i;
+    float bj[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) bj[m] = (b && j + m < ndim) ? b[j + m] : 0.0f;
+    float4 nxt[4];
+    auto fetch = [&](int64_t tile) {
+        const int64_t t = tile < ntile ? tile : ntile - 1;
+        const int64_t v = t * 16 + i < N ? t * 16 + i : N - 1;
+        const float* xr = X + v * ldx + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < nq) nxt[q] = *reinterpret_cast<const float4*>(xr + 16 * q);
+    };
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile < ntile) fetch(tile);
+    for (; tile < ntile; tile += stride) {
+        const int64_t v0 = tile * 16;
+        float4 cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        fetch(tile + stride);
+        float4 old[4], mk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t v = v0 + 4 * g + r < N ? v0 + 4 * g + r : N - 1;
+            if (ACCUM) old[r] = *reinterpret_cast<const float4*>(Y + v * ldy + j);
+            if (MASK) mk[r] = *reinterpret_cast<const float4*>(mask + v * ldm + j);
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q >= nq) break;
+            const int k0 = 16 * q + 4 * g;
+            float ac[4] = {k0 + 0 < kdim ? cur[q].x : 0.0f, k0 + 1 < kdim ? cur[q].y : 0.0f,
+                           k0 + 2 < kdim ? cur[q].z : 0.0f, k0 + 3 < kdim ? cur[q].w : 0.0f};
+            if (act & ACT_RELU_IN) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ac[c] = fmaxf(ac[c], 0.0f);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float* wr = Wl + (k0 + c) * kWs + i;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(ac[c], wr[16 * m], acc[m]);
+            }
+        }
+        if (j >= ndim) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t v = v0 + 4 * g + r;
+            if (v >= N) continue;
+            float y[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) y[m] = acc[m][r] + bj[m];
+            if (ACCUM) {
+                y[0] += old[r].x; y[1] += old[r].y; y[2] += old[r].z; y[3] += old[r].w;
+            }
+            if (act & ACT_RELU) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) y[m] = fmaxf(y[m], 0.0f);
+            }
+            if (MASK) {
+                y[0] = mk[r].x > 0.0f ? y[0] : 0.0f; y[1] = mk[r].y > 0.0f ? y[1] : 0.0f;
+                y[2] = mk[r].z > 0.0f ? y[2] : 0.0f; y[3] = mk[r].w > 0.0f ? y[3] : 0.0f;
+            }
+            if (j + 3 < ndim) {
+                *reinterpret_cast<float4*>(Y + v * ldy + j) = make_float4(y[0], y[1], y[2], y[3]);
+            } else {  // ragged last columns
+                for (int m = 0; m < 4 && j + m < ndim; ++m) Y[v * ldy + j + m] = y[m];
+            }
+        }
+    }
+}
+
 // The whole 3x3x1 'same' convolution of one layer in ONE launch (U <= 64):
 //   Y[v] = act(sum_tap X[nbr(v, tap)] K[tap] + b)            (flip = 0, model.py:152-157)
 //   Y[v] = (sum_tap X[nbr(v, -tap)] K[tap]^T) * (mask[v] > 0)  (flip = 1: adjoint wrt the input)
@@ -818,6 +918,16 @@ struct Launcher {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xw_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return qb::hip_fail(e, "hipFuncSetAttribute(xw_kernel)");
+        }
+        const bool aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (ldx & 3) == 0 && ldx >= 64 &&
+                             (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && (ldy & 3) == 0 && ldy >= 64 &&
+                             (!mask || ((reinterpret_cast<uintptr_t>(mask) & 15) == 0 && (ld & 3) == 0 && ld >= 64));
+        if (aligned && kdim <= 64 && ndim <= 64 && gather.Z == 0 && !(ctx->dev.debug_skip & 512)) {
+            auto kern = accum ? (mask ? xw64_kernel<true, true> : xw64_kernel<true, false>)
+                              : (mask ? xw64_kernel<false, true> : xw64_kernel<false, false>);
+            hipLaunchKernelGGL(kern, dim3(grid()), dim3(256), smem, s, X, ldx, kdim, W, ldw, trans, b, Y, ldy, ndim,
+                               act, mask, ld, N);
+            return QBOLD_OK;
         }
         hipLaunchKernelGGL(xw_kernel, dim3(grid(), (ndim + 63) / 64), dim3(256), smem, s, X, ldx, kdim, W,
                            ldw, trans, b, Y, ldy, ndim, act, accum, mask, ld, N, gather);
