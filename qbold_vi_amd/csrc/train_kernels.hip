@@ -461,7 +461,9 @@ template <bool VEC>
 __global__ __launch_bounds__(1024) void xtd_kernel(const float* __restrict__ X, int ldx, int kdim,
                                                    const float* __restrict__ D, int ldd, int ndim,
                                                    float* __restrict__ partial, int64_t N, Gather gt,
-                                                   int relu_x) {
+                                                   int relu_x, const float* __restrict__ Dref) {
+    // Dref (optional, laid out like D): D is taken as D * (Dref > 0) -- the step through a relu folded into
+    // the operand load instead of a masked copy of the delta tensor
     extern __shared__ float red8[];  // [kXtdTiles][64 * 64 + 64]
     if (gridDim.y == 9) {
         gt.dx = (int)blockIdx.y / 3 - 1;
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(1024) void xtd_kernel(const float* __restrict__ X, 
     // compiler wait for it and the prefetch would buy nothing); padded / invalid rows read row 0 or v itself,
     // columns beyond kdim / ndim stay inside the row stride
     struct Raw {
-        float x[4], d[4];
+        float x[4], d[4], r[4];
         unsigned in;  // bit 0: X row valid, bit 1: D row valid
     };
     auto load = [&](int64_t st, Raw& w) {
@@ -501,11 +503,16 @@ __global__ __launch_bounds__(1024) void xtd_kernel(const float* __restrict__ X, 
             const float4 b = *reinterpret_cast<const float4*>(dr + 4 * i);
             w.x[0] = a.x; w.x[1] = a.y; w.x[2] = a.z; w.x[3] = a.w;
             w.d[0] = b.x; w.d[1] = b.y; w.d[2] = b.z; w.d[3] = b.w;
+            if (Dref) {
+                const float4 c = *reinterpret_cast<const float4*>(Dref + v * ldd + 4 * i);
+                w.r[0] = c.x; w.r[1] = c.y; w.r[2] = c.z; w.r[3] = c.w;
+            }
         } else {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 w.x[m] = xr[16 * m + i];
                 w.d[m] = dr[16 * m + i];
+                if (Dref) w.r[m] = Dref[v * ldd + 16 * m + i];
             }
         }
     };
@@ -528,6 +535,7 @@ __global__ __launch_bounds__(1024) void xtd_kernel(const float* __restrict__ X, 
             xa[m] = okx && kx[m] ? w.x[m] : 0.0f;
             if (relu_x) xa[m] = fmaxf(xa[m], 0.0f);
             dd[m] = okd && nd[m] ? w.d[m] : 0.0f;
+            if (Dref) dd[m] = w.r[m] > 0.0f ? dd[m] : 0.0f;
             dbsum[m] += dd[m];
         }
 #pragma unroll
@@ -963,19 +971,21 @@ struct Launcher {
     }
     // dW (+)= X^T D, db (+)= sum D: 64 x 64 slabs of the (kdim x ndim) product, one launch pair per slab
     void xtd(const float* X, int kdim, const float* D, int ndim, float* partial, int nblk, float* dW,
-             int ldw, float* db, int accum, int relu_x = 0) const {
+             int ldw, float* db, int accum, int relu_x = 0, const float* dref = nullptr) const {
         for (int a = 0; a < kdim; a += 64)
             for (int c = 0; c < ndim; c += 64) {
                 const int ka = kdim - a < 64 ? kdim - a : 64, nc = ndim - c < 64 ? ndim - c : 64;
                 const float* Xa = X + a;
                 const float* Dc = D + c;
+                const float* Rc = dref ? dref + c : nullptr;
                 const bool vec = (ld & 3) == 0 &&
-                                 ((reinterpret_cast<uintptr_t>(Xa) | reinterpret_cast<uintptr_t>(Dc)) & 15) == 0;
+                                 ((reinterpret_cast<uintptr_t>(Xa) | reinterpret_cast<uintptr_t>(Dc) |
+                                   reinterpret_cast<uintptr_t>(Rc)) & 15) == 0;
                 auto kern = vec ? xtd_kernel<true> : xtd_kernel<false>;
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXtdSmem);
                 hipLaunchKernelGGL(kern, dim3(nblk), dim3(1024), kXtdSmem, s, Xa, ld, ka, Dc, ld, nc, partial, N,
-                                   gather, relu_x);
+                                   gather, relu_x, Rc);
                 hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64), dim3(1024), 0, s, partial,
                                    nblk, dW + (int64_t)a * ldw + c, ldw, ka, nc, a == 0 && db ? db + c : nullptr, accum);
             }
@@ -1198,8 +1208,7 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
         }
     }
     // first layer: delta_pre = dB * (h > 0); dW0 = n^T delta_pre
-    hipLaunchKernelGGL(mask_mul_kernel, dim3(k.ew()), dim3(256), 0, k.s, dB, slot(1), dC, N * ld);
-    k.xtd(slot(0), T, dC, U, partial, slabs, grad + c.W0, U, grad + c.b0, 0);
+    k.xtd(slot(0), T, dB, U, partial, slabs, grad + c.W0, U, grad + c.b0, 0, 0, slot(1));
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }
