@@ -871,19 +871,22 @@ __global__ void nlogp_bwd_kernel(const float* __restrict__ y_true, int ldy, cons
     }
 }
 
-// copy g_q [N][5] and g_ls [N][T] into one [N][64] delta tensor (cols 0-4, 5..5+T-1), scaled
+// copy g_q [N][5] and g_ls [N][T] into one [N][ld] delta tensor (cols 0-4, 5..5+T-1), scaled.  Only the
+// first 5 + T columns (rounded up to 4) of a row are written: the GEMMs that read this tensor take ndim /
+// kdim = 5 or T columns of it and zero everything beyond by select, so the rest of the row is never used.
 __global__ void head_delta_kernel(const float* __restrict__ g_q, const float* __restrict__ g_ls, int T,
                                   const double* __restrict__ sums, float* __restrict__ d, int ld, int64_t N) {
     const float scale = sums ? (float)(1.0 / sums[2]) : 1.0f;  // 1 / sum(mask)
-    const int64_t total = N * ld;
+    const int wcols = ((5 + T + 3) & ~3) < ld ? ((5 + T + 3) & ~3) : ld;
+    const int64_t total = N * wcols;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
-        const int j = (int)(e % ld);
-        const int64_t v = e / ld;
+        const int j = (int)(e % wcols);
+        const int64_t v = e / wcols;
         float o = 0.0f;
         if (j < 5) o = g_q[v * 5 + j] * scale;
         else if (g_ls && j < 5 + T) o = g_ls[v * T + j - 5] * scale;
-        d[e] = o;
+        d[v * ld + j] = o;
     }
 }
 
