@@ -758,17 +758,27 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
 // normalise_data into a [N][64] slot (model.py:97-113)
 __global__ void normalise64_kernel(QbDev c, const float* __restrict__ x, float* __restrict__ out,
                                    int ld, int64_t N) {
+    // one thread per (voxel, tau): coalesced reads and 4 wc-byte row heads written; columns T .. wc - 1 are
+    // zeroed, the rest of a row is never used (its readers take kdim = T columns and zero the others by select)
     const int T = c.T, se = c.se_idx;
-    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < N;
-         v += (int64_t)gridDim.x * blockDim.x) {
+    const int wc = ((T + 3) & ~3) < ld ? ((T + 3) & ~3) : ld;
+    const int64_t total = N * wc;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(e % wc);
+        const int64_t v = e / wc;
         const float* xv = x + v * T;
-        float den;
-        if (c.multi_norm)
-            den = (qb::clampf_(xv[se - 1], 1e-2f, 1e8f) + qb::clampf_(xv[se], 1e-2f, 1e8f) +
-                   qb::clampf_(xv[se + 1], 1e-2f, 1e8f)) / 3.0f;
-        else
-            den = qb::clampf_(xv[se], 1e-2f, 1e8f);
-        for (int t = 0; t < T; ++t) out[v * ld + t] = logf(qb::clampf_(xv[t], 1e-2f, 1e8f) / den);
+        float o = 0.0f;
+        if (t < T) {
+            float den;
+            if (c.multi_norm)
+                den = (qb::clampf_(xv[se - 1], 1e-2f, 1e8f) + qb::clampf_(xv[se], 1e-2f, 1e8f) +
+                       qb::clampf_(xv[se + 1], 1e-2f, 1e8f)) / 3.0f;
+            else
+                den = qb::clampf_(xv[se], 1e-2f, 1e8f);
+            o = logf(qb::clampf_(xv[t], 1e-2f, 1e8f) / den);
+        }
+        out[v * ld + t] = o;
     }
 }
 
@@ -1055,8 +1065,7 @@ static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     Launcher k{ctx, (hipStream_t)stream, N, ld};
     auto slot = [&](int i) { return ws + (int64_t)i * N * ld; };
     // slot 0 holds the normalised input with its own row stride (T may exceed ld only if T > 64: not allowed)
-    QB_HIP(hipMemsetAsync(slot(0), 0, sizeof(float) * N * ld, k.s));
-    hipLaunchKernelGGL(normalise64_kernel, dim3(k.grid()), dim3(256), 0, k.s, ctx->dev, x, slot(0), ld, N);
+    hipLaunchKernelGGL(normalise64_kernel, dim3(k.ew()), dim3(256), 0, k.s, ctx->dev, x, slot(0), ld, N);
     k.xw(slot(0), ld, T, w + c.W0, U, 0, w + c.b0, slot(1), U, ACT_RELU, 0, nullptr);
     const float* cur = slot(1);
     float* head = slot(2 + 5 * L);  // scratch slot for the head output
