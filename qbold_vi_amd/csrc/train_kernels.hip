@@ -336,6 +336,96 @@ __global__ __launch_bounds__(256) void xw64_kernel(const float* __restrict__ X, 
     }
 }
 
+// The gating layer of a residual block with its blend as the epilogue (channel-wise gating, model.py:164-170):
+//   gl = r Wg + bg            (kept: the backward needs the logits)
+//   bout = skip (1 - g) + r g,   g = sigmoid(gl + gate_offset)
+// instead of a second pass over gl, skip and r.  The rows of skip and r that the epilogue blends are requested
+// before the tile's MFMAs (r is the GEMM input itself: a cache hit in another lane layout).
+__global__ __launch_bounds__(256) void xw64_gate_kernel(const float* __restrict__ X, int ldx, int kdim,
+                                                        const float* __restrict__ W, int ldw,
+                                                        const float* __restrict__ b, float* __restrict__ GL,
+                                                        const float* __restrict__ skip, float* __restrict__ bout,
+                                                        int ldy, int ndim, float offset, int64_t N) {
+    extern __shared__ float Wl[];
+    const int kpad = (kdim + 15) & ~15;
+    for (int e = threadIdx.x; e < kpad * 64; e += 256) {
+        const int k = e >> 6, j = e & 63;
+        float v = 0.0f;
+        if (k < kdim && j < ndim) v = W[k * ldw + j];
+        Wl[k * kWs + 16 * (j & 3) + (j >> 2)] = v;   // tile m of lane i = column 4 i + m
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int64_t ntile = (N + 15) / 16;
+    const int nq = (kdim + 15) >> 4;
+    const int j = 4 * i;
+    float bj[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) bj[m] = (b && j + m < ndim) ? b[j + m] : 0.0f;
+    float4 nxt[4];
+    auto fetch = [&](int64_t tile) {
+        const int64_t t = tile < ntile ? tile : ntile - 1;
+        const int64_t v = t * 16 + i < N ? t * 16 + i : N - 1;
+        const float* xr = X + v * ldx + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < nq) nxt[q] = *reinterpret_cast<const float4*>(xr + 16 * q);
+    };
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile < ntile) fetch(tile);
+    for (; tile < ntile; tile += stride) {
+        const int64_t v0 = tile * 16;
+        float4 cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        fetch(tile + stride);
+        float4 sk[4], rr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t v = v0 + 4 * g + r < N ? v0 + 4 * g + r : N - 1;
+            sk[r] = *reinterpret_cast<const float4*>(skip + v * ldy + j);
+            rr[r] = *reinterpret_cast<const float4*>(X + v * ldx + j);
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q >= nq) break;
+            const int k0 = 16 * q + 4 * g;
+            const float ac[4] = {k0 + 0 < kdim ? cur[q].x : 0.0f, k0 + 1 < kdim ? cur[q].y : 0.0f,
+                                 k0 + 2 < kdim ? cur[q].z : 0.0f, k0 + 3 < kdim ? cur[q].w : 0.0f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float* wr = Wl + (k0 + c) * kWs + i;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(ac[c], wr[16 * m], acc[m]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t v = v0 + 4 * g + r;
+            if (v >= N) continue;
+            const float s4[4] = {sk[r].x, sk[r].y, sk[r].z, sk[r].w}, r4[4] = {rr[r].x, rr[r].y, rr[r].z, rr[r].w};
+            float gl[4], o[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                gl[m] = acc[m][r] + bj[m];
+                const float gate = 1.0f / (1.0f + expf(-(gl[m] + offset)));
+                o[m] = j + m < ndim ? s4[m] * (1.0f - gate) + r4[m] * gate : 0.0f;   // zero beyond U, as gate_fwd_kernel
+            }
+            *reinterpret_cast<float4*>(bout + v * ldy + j) = make_float4(o[0], o[1], o[2], o[3]);
+            if (j + 3 < ndim) {
+                *reinterpret_cast<float4*>(GL + v * ldy + j) = make_float4(gl[0], gl[1], gl[2], gl[3]);
+            } else {
+                for (int m = 0; m < 4 && j + m < ndim; ++m) GL[v * ldy + j + m] = gl[m];
+            }
+        }
+    }
+}
+
 // The whole 3x3x1 'same' convolution of one layer in ONE launch (U <= 64):
 //   Y[v] = act(sum_tap X[nbr(v, tap)] K[tap] + b)            (flip = 0, model.py:152-157)
 //   Y[v] = (sum_tap X[nbr(v, -tap)] K[tap]^T) * (mask[v] > 0)  (flip = 1: adjoint wrt the input)
@@ -1090,9 +1180,17 @@ static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                 k.xw(cur, ld, U, wb + c.Wr1 + ctr, U, 0, wb + c.br1, t, U, ACT_RELU | ACT_RELU_IN, 0, nullptr);
                 k.xw(t, ld, U, wb + c.Wr2 + ctr, U, 0, wb + c.br2, r, U, ACT_NONE, 0, nullptr);
             }
-            k.xw(r, ld, U, wb + c.Wg, G, 0, wb + c.bg, gl, G, ACT_NONE, 0, nullptr);
-            hipLaunchKernelGGL(gate_fwd_kernel, dim3(k.ew()), dim3(256), 0, k.s, gl, skip, r, bout,
-                               shape->gate_offset, U, G, ld, N);
+            const bool fuse_gate = G == U && U <= 64 && ld == kLd && !(ctx->dev.debug_skip & 2048) &&
+                                   ((reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(gl) |
+                                     reinterpret_cast<uintptr_t>(skip) | reinterpret_cast<uintptr_t>(bout)) & 15) == 0;
+            if (fuse_gate) {   // gating GEMM with the blend as its epilogue
+                hipLaunchKernelGGL(xw64_gate_kernel, dim3(k.grid()), dim3(256), sizeof(float) * 64 * kWs, k.s, r, ld,
+                                   U, wb + c.Wg, G, wb + c.bg, gl, skip, bout, ld, G, shape->gate_offset, N);
+            } else {
+                k.xw(r, ld, U, wb + c.Wg, G, 0, wb + c.bg, gl, G, ACT_NONE, 0, nullptr);
+                hipLaunchKernelGGL(gate_fwd_kernel, dim3(k.ew()), dim3(256), 0, k.s, gl, skip, r, bout,
+                                   shape->gate_offset, U, G, ld, N);
+            }
             cur = bout;
         }
     }
