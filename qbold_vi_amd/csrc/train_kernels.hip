@@ -336,6 +336,100 @@ __global__ __launch_bounds__(256) void xw64_kernel(const float* __restrict__ X, 
     }
 }
 
+// Backward-data of a residual block's two input branches in one pass (voxel batches):
+//   Y = (X1 W1^T) * (M > 0) + X2 W2^T        d b_in = (dE Wr1^T) * (b_in > 0) + dC Wc^T
+// instead of a masked GEMM into Y followed by an accumulating GEMM that reads Y back.  One accumulator set:
+// the first chain is masked in place before the second chain adds to it.  Both weight slabs stay in LDS.
+__global__ __launch_bounds__(256) void xw64_dual_kernel(const float* __restrict__ X1, const float* __restrict__ W1,
+                                                        const float* __restrict__ M, const float* __restrict__ X2,
+                                                        const float* __restrict__ W2, int ld, int kdim, int ndim,
+                                                        int ldw, float* __restrict__ Y, int64_t N) {
+    extern __shared__ float Wl[];  // [2][kpad][kWs]
+    const int kpad = (kdim + 15) & ~15;
+    float* Wl2 = Wl + kpad * kWs;
+    for (int e = threadIdx.x; e < 2 * kpad * 64; e += 256) {
+        const int which = e >= kpad * 64, ee = which ? e - kpad * 64 : e;
+        const int k = ee >> 6, j = ee & 63;
+        float v = 0.0f;
+        if (k < kdim && j < ndim) v = (which ? W2 : W1)[j * ldw + k];   // transposed: dX = dY W^T
+        (which ? Wl2 : Wl)[k * kWs + 16 * (j & 3) + (j >> 2)] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int64_t ntile = (N + 15) / 16;
+    const int nq = (kdim + 15) >> 4;
+    const int j = 4 * i;
+    float4 n1[4], n2[4];
+    auto fetch = [&](int64_t tile) {
+        const int64_t t = tile < ntile ? tile : ntile - 1;
+        const int64_t v = t * 16 + i < N ? t * 16 + i : N - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < nq) {
+                n1[q] = *reinterpret_cast<const float4*>(X1 + v * ld + 4 * g + 16 * q);
+                n2[q] = *reinterpret_cast<const float4*>(X2 + v * ld + 4 * g + 16 * q);
+            }
+    };
+    auto chain = [&](const float4 (&cur)[4], const float* Ws, f32x4 (&acc)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q >= nq) break;
+            const int k0 = 16 * q + 4 * g;
+            const float ac[4] = {k0 + 0 < kdim ? cur[q].x : 0.0f, k0 + 1 < kdim ? cur[q].y : 0.0f,
+                                 k0 + 2 < kdim ? cur[q].z : 0.0f, k0 + 3 < kdim ? cur[q].w : 0.0f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float* wr = Ws + (k0 + c) * kWs + i;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(ac[c], wr[16 * m], acc[m]);
+            }
+        }
+    };
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile < ntile) fetch(tile);
+    for (; tile < ntile; tile += stride) {
+        const int64_t v0 = tile * 16;
+        float4 c1[4], c2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            c1[q] = n1[q];
+            c2[q] = n2[q];
+        }
+        fetch(tile + stride);
+        float4 mk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t v = v0 + 4 * g + r < N ? v0 + 4 * g + r : N - 1;
+            mk[r] = *reinterpret_cast<const float4*>(M + v * ld + j);
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        chain(c1, Wl, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // through the relu of the first branch, before the second one is added
+            acc[0][r] = mk[r].x > 0.0f ? acc[0][r] : 0.0f;
+            acc[1][r] = mk[r].y > 0.0f ? acc[1][r] : 0.0f;
+            acc[2][r] = mk[r].z > 0.0f ? acc[2][r] : 0.0f;
+            acc[3][r] = mk[r].w > 0.0f ? acc[3][r] : 0.0f;
+        }
+        chain(c2, Wl2, acc);
+        if (j >= ndim) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t v = v0 + 4 * g + r;
+            if (v >= N) continue;
+            if (j + 3 < ndim) {
+                *reinterpret_cast<float4*>(Y + v * ld + j) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            } else {
+                for (int m = 0; m < 4 && j + m < ndim; ++m) Y[v * ld + j + m] = acc[m][r];
+            }
+        }
+    }
+}
+
 // The gating layer of a residual block with its blend as the epilogue (channel-wise gating, model.py:164-170):
 //   gl = r Wg + bg            (kept: the backward needs the logits)
 //   bout = skip (1 - g) + r g,   g = sigmoid(gl + gate_offset)
@@ -1290,6 +1384,7 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             const float* skip = slot(2 + 5 * l), *t = slot(3 + 5 * l), *r = slot(4 + 5 * l);
             const float* gl = slot(5 + 5 * l);
             const float* b_in = l == 0 ? slot(1) : slot(6 + 5 * (l - 1));
+            bool fused_in = false;
             // dB = d b_out.  dC = d skip_pre, dD = d r, dE = d gate logits
             hipLaunchKernelGGL(gate_bwd_kernel, dim3(k.grid()), dim3(256), 0, k.s, dB, gl, skip, r, dC, dD,
                                dE, shape->gate_offset, U, G, ld, N);
@@ -1310,11 +1405,19 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                 k.xw(dD, ld, U, wb + c.Wr2 + ctr, U, 1, nullptr, dE, U, ACT_NONE, 0, t);
                 // first residual conv: input relu(b_in): dWr1 = relu(b_in)^T dE; d b_in = (dE Wr1^T) * (b_in > 0)
                 k.xtd(b_in, U, dE, U, partial, slabs, gb + c.Wr1 + ctr, U, gb + c.br1, 0, 1);
-                k.xw(dE, ld, U, wb + c.Wr1 + ctr, U, 1, nullptr, dB, U, ACT_NONE, 0, b_in);
+                fused_in = U <= 64 && ld == kLd && !(ctx->dev.debug_skip & 4096);
+                if (!fused_in) k.xw(dE, ld, U, wb + c.Wr1 + ctr, U, 1, nullptr, dB, U, ACT_NONE, 0, b_in);
             }
             // skip conv: dWc = b_in^T dC; d b_in += dC Wc^T
             k.xtd(b_in, U, dC, U, partial, slabs, gb + c.Wc, U, gb + c.bc, 0);
-            k.xw(dC, ld, U, wb + c.Wc, U, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
+            if (fused_in) {   // d b_in = (dE Wr1^T) * (b_in > 0) + dC Wc^T in one pass
+                const int ctr = c.taps == 9 ? 4 * U * U : 0;
+                const size_t smem = sizeof(float) * 2 * 64 * kWs;
+                hipLaunchKernelGGL(xw64_dual_kernel, dim3(k.grid()), dim3(256), smem, k.s, dE, wb + c.Wr1 + ctr, b_in,
+                                   dC, wb + c.Wc, ld, U, U, U, dB, N);
+            } else {
+                k.xw(dC, ld, U, wb + c.Wc, U, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
+            }
         }
     }
     // first layer: delta_pre = dB * (h > 0); dW0 = n^T delta_pre
