@@ -336,6 +336,98 @@ __global__ __launch_bounds__(256) void xw64_kernel(const float* __restrict__ X, 
     }
 }
 
+// Forward of a residual block's two input branches in one pass over the input rows (voxel batches):
+//   Y1 = relu(X W1 + b1)              skip = relu(b Wc + bc)                       model.py:148
+//   Y2 = relu(relu(X) W2 + b2)        t = relu(relu(b) Wr1 + br1)                  model.py:151-155
+// Both weight slabs stay in LDS; the two chains run one after the other on the same row registers and
+// accumulator set.
+__global__ __launch_bounds__(256) void xw64_fork_kernel(const float* __restrict__ X, int ld, int kdim, int ndim,
+                                                        const float* __restrict__ W1, const float* __restrict__ b1,
+                                                        float* __restrict__ Y1, const float* __restrict__ W2,
+                                                        const float* __restrict__ b2, float* __restrict__ Y2,
+                                                        int ldw, int64_t N) {
+    extern __shared__ float Wl[];  // [2][kpad][kWs]
+    const int kpad = (kdim + 15) & ~15;
+    float* Wl2 = Wl + kpad * kWs;
+    for (int e = threadIdx.x; e < 2 * kpad * 64; e += 256) {
+        const int which = e >= kpad * 64, ee = which ? e - kpad * 64 : e;
+        const int k = ee >> 6, j = ee & 63;
+        float v = 0.0f;
+        if (k < kdim && j < ndim) v = (which ? W2 : W1)[k * ldw + j];
+        (which ? Wl2 : Wl)[k * kWs + 16 * (j & 3) + (j >> 2)] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int64_t ntile = (N + 15) / 16;
+    const int nq = (kdim + 15) >> 4;
+    const int j = 4 * i;
+    float bj1[4], bj2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        bj1[m] = (b1 && j + m < ndim) ? b1[j + m] : 0.0f;
+        bj2[m] = (b2 && j + m < ndim) ? b2[j + m] : 0.0f;
+    }
+    float4 nxt[4];
+    auto fetch = [&](int64_t tile) {
+        const int64_t t = tile < ntile ? tile : ntile - 1;
+        const int64_t v = t * 16 + i < N ? t * 16 + i : N - 1;
+        const float* xr = X + v * ld + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < nq) nxt[q] = *reinterpret_cast<const float4*>(xr + 16 * q);
+    };
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile < ntile) fetch(tile);
+    for (; tile < ntile; tile += stride) {
+        const int64_t v0 = tile * 16;
+        float4 cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        fetch(tile + stride);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const float* Ws = pass ? Wl2 : Wl;
+            f32x4 acc[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q >= nq) break;
+                const int k0 = 16 * q + 4 * g;
+                float ac[4] = {k0 + 0 < kdim ? cur[q].x : 0.0f, k0 + 1 < kdim ? cur[q].y : 0.0f,
+                               k0 + 2 < kdim ? cur[q].z : 0.0f, k0 + 3 < kdim ? cur[q].w : 0.0f};
+                if (pass) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ac[c] = fmaxf(ac[c], 0.0f);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float* wr = Ws + (k0 + c) * kWs + i;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(ac[c], wr[16 * m], acc[m]);
+                }
+            }
+            if (j >= ndim) continue;
+            float* Y = pass ? Y2 : Y1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t v = v0 + 4 * g + r;
+                if (v >= N) continue;
+                float y[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) y[m] = fmaxf(acc[m][r] + (pass ? bj2[m] : bj1[m]), 0.0f);
+                if (j + 3 < ndim) {
+                    *reinterpret_cast<float4*>(Y + v * ld + j) = make_float4(y[0], y[1], y[2], y[3]);
+                } else {
+                    for (int m = 0; m < 4 && j + m < ndim; ++m) Y[v * ld + j + m] = y[m];
+                }
+            }
+        }
+    }
+}
+
 // Backward-data of a residual block's two input branches in one pass (voxel batches):
 //   Y = (X1 W1^T) * (M > 0) + X2 W2^T        d b_in = (dE Wr1^T) * (b_in > 0) + dC Wc^T
 // instead of a masked GEMM into Y followed by an accumulating GEMM that reads Y back.  One accumulator set:
@@ -1264,14 +1356,19 @@ static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             const float* wb = w + c.blk0 + l * c.blk_stride;
             float* skip = slot(2 + 5 * l), *t = slot(3 + 5 * l), *r = slot(4 + 5 * l);
             float* gl = slot(5 + 5 * l), *bout = slot(6 + 5 * l);
-            k.xw(cur, ld, U, wb + c.Wc, U, 0, wb + c.bc, skip, U, ACT_RELU, 0, nullptr);
+            const bool fork = !gm && U <= 64 && ld == kLd && !(ctx->dev.debug_skip & 8192);
+            if (!fork) k.xw(cur, ld, U, wb + c.Wc, U, 0, wb + c.bc, skip, U, ACT_RELU, 0, nullptr);
             // relu(b) feeds the first residual conv (model.py:151): applied to the rows as they are loaded
             if (gm) {  // 3x3x1 'same' convolutions, model.py:152-157
                 k.conv3x3(cur, wb + c.Wr1, U, wb + c.br1, t, ACT_RELU | ACT_RELU_IN, 0, nullptr, *gm);
                 k.conv3x3(t, wb + c.Wr2, U, wb + c.br2, r, ACT_NONE, 0, nullptr, *gm);
             } else {   // voxel batch: centre tap only
                 const int ctr = c.taps == 9 ? 4 * U * U : 0;
-                k.xw(cur, ld, U, wb + c.Wr1 + ctr, U, 0, wb + c.br1, t, U, ACT_RELU | ACT_RELU_IN, 0, nullptr);
+                if (fork)   // skip and t from one pass over the block's input rows
+                    hipLaunchKernelGGL(xw64_fork_kernel, dim3(k.grid()), dim3(256), sizeof(float) * 2 * 64 * kWs, k.s,
+                                       cur, ld, U, U, wb + c.Wc, wb + c.bc, skip, wb + c.Wr1 + ctr, wb + c.br1, t, U, N);
+                else
+                    k.xw(cur, ld, U, wb + c.Wr1 + ctr, U, 0, wb + c.br1, t, U, ACT_RELU | ACT_RELU_IN, 0, nullptr);
                 k.xw(t, ld, U, wb + c.Wr2 + ctr, U, 0, wb + c.br2, r, U, ACT_NONE, 0, nullptr);
             }
             const bool fuse_gate = G == U && U <= 64 && ld == kLd && !(ctx->dev.debug_skip & 2048) &&
