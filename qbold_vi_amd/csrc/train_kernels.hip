@@ -1003,7 +1003,8 @@ __global__ __launch_bounds__(512) void xtd9_kernel(const float* __restrict__ X, 
 // bias gradient comes from tap 0 only.
 __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ partial, int nblk,
                                                             float* __restrict__ dW, int ldw, int kdim, int ndim,
-                                                            float* __restrict__ db, int accum) {
+                                                            float* __restrict__ db, int accum, int j0) {
+    // j0: the slab's columns j0 .. j0 + ndim - 1 go to dW[:, 0 .. ndim - 1] (two heads sharing one slab)
     // 64 elements per block x 16 interleaved parts of the slab range, added in a fixed order
     constexpr int kParts = 16;
     __shared__ double part[kParts][64];
@@ -1023,12 +1024,22 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
 #pragma unroll
     for (int q = 0; q < kParts; ++q) a += part[q][threadIdx.x];
     if (e < 64 * 64) {
-        const int i = e >> 6, j = e & 63;
-        if (i < kdim && j < ndim) dW[i * ldw + j] = (accum ? dW[i * ldw + j] : 0.0f) + (float)a;
+        const int i = e >> 6, j = (e & 63) - j0;
+        if (i < kdim && j >= 0 && j < ndim) dW[i * ldw + j] = (accum ? dW[i * ldw + j] : 0.0f) + (float)a;
     } else {
-        const int j = e - 64 * 64;
-        if (db && j < ndim) db[j] = (accum ? db[j] : 0.0f) + (float)a;
+        const int j = e - 64 * 64 - j0;
+        if (db && j >= 0 && j < ndim) db[j] = (accum ? db[j] : 0.0f) + (float)a;
     }
+}
+
+// Stacked head weights for the backward-data GEMM of both heads in one pass: Wst[k][j] (k < 5 + T rows of
+// U columns) = Wf[j][k] for k < 5, Ws[j][k - 5] beyond -- d last = [g_q | g_ls] Wst.
+__global__ void stack_heads_kernel(const float* __restrict__ Wf, const float* __restrict__ Ws, int T, int U,
+                                   float* __restrict__ Wst) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (5 + T) * U) return;
+    const int k = e / U, j = e % U;
+    Wst[e] = k < 5 ? Wf[j * 5 + k] : Ws[j * T + (k - 5)];
 }
 
 // normalise_data into a [N][64] slot (model.py:97-113)
@@ -1276,8 +1287,22 @@ struct Launcher {
                 hipLaunchKernelGGL(kern, dim3(nblk), dim3(1024), kXtdSmem, s, Xa, ld, ka, Dc, ld, nc, partial, N,
                                    gather, relu_x, Rc);
                 hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64), dim3(1024), 0, s, partial,
-                                   nblk, dW + (int64_t)a * ldw + c, ldw, ka, nc, a == 0 && db ? db + c : nullptr, accum);
+                                   nblk, dW + (int64_t)a * ldw + c, ldw, ka, nc, a == 0 && db ? db + c : nullptr, accum, 0);
             }
+    }
+    // one 64 x 64 slab (kdim, ndim <= 64) without its reduction, and the reduction of columns j0 .. of a slab
+    void xtd_only(const float* X, int kdim, const float* D, int ndim, float* partial, int nblk) const {
+        const bool vec = (ld & 3) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D)) & 15) == 0;
+        auto kern = vec ? xtd_kernel<true> : xtd_kernel<false>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)kXtdSmem);
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(1024), kXtdSmem, s, X, ld, kdim, D, ld, ndim, partial, N, gather, 0,
+                           static_cast<const float*>(nullptr));
+    }
+    void reduce_cols(const float* partial, int nblk, float* dW, int ldw, int kdim, int ndim, float* db, int j0) const {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64), dim3(1024), 0, s, partial, nblk, dW, ldw,
+                           kdim, ndim, db, 0, j0);
     }
     // all nine taps of a 3x3x1 kernel gradient in two launches: dK[tap] = X[nbr(., tap)]^T D, db = sum D
     void xtd9(const float* X, int U, const float* D, float* partial, int nblk, float* dK9, float* db,
@@ -1285,7 +1310,7 @@ struct Launcher {
         hipLaunchKernelGGL(xtd9_kernel, dim3(nblk), dim3(512), 0, s, X, kLd, U, D, kLd, U, partial, N,
                            make_gather(gm.X, gm.Y, gm.Z, 0, 0), relu_x);
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64, 9), dim3(1024), 0, s, partial,
-                           nblk, dK9, U, U, U, db, 0);
+                           nblk, dK9, U, U, U, db, 0, 0);
     }
     int ew() const {
         int64_t nb = (N * ld + 255) / 256;
@@ -1456,11 +1481,24 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     // the nine-tap kernel runs one 512-thread block per CU (144 accumulator registers per lane)
     const int slabs9 = (int)((N + 511) / 512 < ctx->num_cus ? ((N + 511) / 512 > 0 ? (N + 511) / 512 : 1)
                                                            : (ctx->num_cus < kSlabBlocks ? ctx->num_cus : kSlabBlocks));
-    k.xtd(last, U, dA, 5, partial, slabs, grad + c.Wf, 5, grad + c.bf, 0);
-    k.xw(dA, ld, 5, w + c.Wf, 5, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
-    if (stream_sel == 2 && g_ls) {
-        k.xtd(last, U, dA + 5, T, partial, slabs, grad + c.Ws, T, grad + c.bs, 0);
-        k.xw(dA + 5, ld, T, w + c.Ws, T, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
+    if (stream_sel == 2 && g_ls && U <= 64 && ld == kLd && 5 + T <= 64 && !(ctx->dev.debug_skip & 16384)) {
+        // both heads at once: one weight-gradient pass over the 5 + T delta columns (slab columns 0-4 -> Wf,
+        // 5 .. -> Ws) and one backward-data GEMM with the stacked weights [Wf^T; Ws^T] -- instead of two
+        // passes each, one of them over the unaligned column block dA + 5
+        float* Wst = partial + (int64_t)8 * kSlabBlocks * (64 * 64 + 64);   // scratch beyond the slabs in use
+        k.xtd_only(last, U, dA, 5 + T, partial, slabs);
+        k.reduce_cols(partial, slabs, grad + c.Wf, 5, U, 5, grad + c.bf, 0);
+        k.reduce_cols(partial, slabs, grad + c.Ws, T, U, T, grad + c.bs, 5);
+        hipLaunchKernelGGL(stack_heads_kernel, dim3(((5 + T) * U + 255) / 256), dim3(256), 0, k.s, w + c.Wf, w + c.Ws,
+                           T, U, Wst);
+        k.xw(dA, ld, 5 + T, Wst, U, 0, nullptr, dB, U, ACT_NONE, 0, nullptr);
+    } else {
+        k.xtd(last, U, dA, 5, partial, slabs, grad + c.Wf, 5, grad + c.bf, 0);
+        k.xw(dA, ld, 5, w + c.Wf, 5, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
+        if (stream_sel == 2 && g_ls) {
+            k.xtd(last, U, dA + 5, T, partial, slabs, grad + c.Ws, T, grad + c.bs, 0);
+            k.xw(dA + 5, ld, T, w + c.Ws, T, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
+        }
     }
     // dB = gradient wrt the last activation tensor
     if (stream_sel == 1) {
