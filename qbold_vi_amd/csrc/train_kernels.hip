@@ -336,6 +336,81 @@ __global__ __launch_bounds__(256) void xw64_kernel(const float* __restrict__ X, 
     }
 }
 
+// Both heads from one pass over the last activation rows, written straight into the caller's compact
+// [N][5] and [N][T] buffers: columns 0-4 of the stacked product are the q head, 5 .. 5 + T - 1 the log-sigma head.
+__global__ __launch_bounds__(256) void xw64_heads_kernel(const float* __restrict__ X, int ld, int kdim,
+                                                         const float* __restrict__ Wf, const float* __restrict__ bf,
+                                                         const float* __restrict__ Ws, const float* __restrict__ bs,
+                                                         int T, float* __restrict__ out_q, float* __restrict__ out_ls,
+                                                         int64_t N) {
+    extern __shared__ float Wl[];
+    const int ndim = 5 + T;
+    const int kpad = (kdim + 15) & ~15;
+    for (int e = threadIdx.x; e < kpad * 64; e += 256) {
+        const int k = e >> 6, j = e & 63;
+        float v = 0.0f;
+        if (k < kdim && j < ndim) v = j < 5 ? Wf[k * 5 + j] : Ws[k * T + (j - 5)];
+        Wl[k * kWs + 16 * (j & 3) + (j >> 2)] = v;   // tile m of lane i = column 4 i + m
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int64_t ntile = (N + 15) / 16;
+    const int nq = (kdim + 15) >> 4;
+    const int j = 4 * i;
+    float bj[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) bj[m] = j + m < 5 ? bf[j + m] : (j + m < ndim ? bs[j + m - 5] : 0.0f);
+    float4 nxt[4];
+    auto fetch = [&](int64_t tile) {
+        const int64_t t = tile < ntile ? tile : ntile - 1;
+        const int64_t v = t * 16 + i < N ? t * 16 + i : N - 1;
+        const float* xr = X + v * ld + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < nq) nxt[q] = *reinterpret_cast<const float4*>(xr + 16 * q);
+    };
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile < ntile) fetch(tile);
+    for (; tile < ntile; tile += stride) {
+        const int64_t v0 = tile * 16;
+        float4 cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        fetch(tile + stride);
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q >= nq) break;
+            const int k0 = 16 * q + 4 * g;
+            const float ac[4] = {k0 + 0 < kdim ? cur[q].x : 0.0f, k0 + 1 < kdim ? cur[q].y : 0.0f,
+                                 k0 + 2 < kdim ? cur[q].z : 0.0f, k0 + 3 < kdim ? cur[q].w : 0.0f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float* wr = Wl + (k0 + c) * kWs + i;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(ac[c], wr[16 * m], acc[m]);
+            }
+        }
+        if (j >= ndim) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t v = v0 + 4 * g + r;
+            if (v >= N) continue;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int col = j + m;
+                const float y = acc[m][r] + bj[m];
+                if (col < 5) out_q[v * 5 + col] = y;
+                else if (col < ndim) out_ls[v * T + (col - 5)] = y;
+            }
+        }
+    }
+}
+
 // Forward of a residual block's two input branches in one pass over the input rows (voxel batches):
 //   Y1 = relu(X W1 + b1)              skip = relu(b Wc + bc)                       model.py:148
 //   Y2 = relu(relu(X) W2 + b2)        t = relu(relu(b) Wr1 + br1)                  model.py:151-155
@@ -1411,12 +1486,18 @@ static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
         }
     }
     // heads straight into the caller's [N][5] / [N][T] buffers
-    rc = k.xw_ld(cur, ld, U, w + c.Wf, 5, 0, w + c.bf, out_q, 5, 5, ACT_NONE, 0, nullptr);
-    if (rc) return rc;
     (void)head;
-    if (stream_sel == 2 && out_log_sigma) {
-        rc = k.xw_ld(cur, ld, U, w + c.Ws, T, 0, w + c.bs, out_log_sigma, T, T, ACT_NONE, 0, nullptr);
+    if (stream_sel == 2 && out_log_sigma && U <= 64 && ld == kLd && 5 + T <= 64 &&
+        (reinterpret_cast<uintptr_t>(cur) & 15) == 0 && !(ctx->dev.debug_skip & 32768)) {
+        hipLaunchKernelGGL(xw64_heads_kernel, dim3(k.grid()), dim3(256), sizeof(float) * 64 * kWs, k.s, cur, ld, U,
+                           w + c.Wf, w + c.bf, w + c.Ws, w + c.bs, T, out_q, out_log_sigma, N);
+    } else {
+        rc = k.xw_ld(cur, ld, U, w + c.Wf, 5, 0, w + c.bf, out_q, 5, 5, ACT_NONE, 0, nullptr);
         if (rc) return rc;
+        if (stream_sel == 2 && out_log_sigma) {
+            rc = k.xw_ld(cur, ld, U, w + c.Ws, T, 0, w + c.bs, out_log_sigma, T, T, ACT_NONE, 0, nullptr);
+            if (rc) return rc;
+        }
     }
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
