@@ -797,6 +797,113 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
     }
 }
 
+// conv9_kernel on the f16 matrix pipe: Y^T[unit][voxel] with every operand split in two halves (x = hi +
+// 2^-11 lo; three v_mfma_f32_16x16x32_f16 per tile, tap and k-step, float32 accumulation -- encoder_core.h,
+// per-product error <= ~7e-7).  The exact-f32 form spends 9 x 64 x 32 = 18.4 k vector-pipe cycles per tile on
+// MFMAs; this one 9 x 24 x 16 = 3.5 k matrix-pipe cycles plus the operand splits.  The nine tap kernels are
+// converted once per workgroup into the weight image of encoder_core.h (9 x 16 KiB of LDS); a lane owns one
+// voxel: its crop coordinates are split once per tile, every tap reads the neighbour's row (or zeros).
+__global__ __launch_bounds__(1024) void conv9h_kernel(const float* __restrict__ X, int ldx, int U,
+                                                      const float* __restrict__ K9, int flip,
+                                                      const float* __restrict__ b, float* __restrict__ Y,
+                                                      int ldy, int act, const float* __restrict__ mask,
+                                                      int ldm, int64_t N, Gather g0) {
+    extern __shared__ __align__(16) float img[];  // [9][s 2][m 4][hi, lo][lane 64][8 halves], then bias[64]
+    float* bias = img + 9 * 4096;
+    for (int e = threadIdx.x; e < 9 * 8192; e += 1024) {
+        const int tap = e >> 13, ee = e & 8191;
+        const int j8 = ee & 7, ln = (ee >> 3) & 63, part = (ee >> 9) & 1, m = (ee >> 10) & 3, st = ee >> 12;
+        const int k = 16 * (2 * st + (j8 >> 2)) + 4 * (ln >> 4) + (j8 & 3), j = 16 * m + (ln & 15);
+        const float* W = K9 + (int64_t)tap * U * U;
+        float w = 0.0f;
+        if (k < U && j < U) w = flip ? W[j * U + k] : W[k * U + j];
+        const _Float16 hi = (_Float16)w;
+        reinterpret_cast<_Float16*>(img)[e] = part == 0 ? hi : (_Float16)((w - (float)hi) * QB_LO_SCALE);
+    }
+    if (threadIdx.x < 64) bias[threadIdx.x] = (b && (int)threadIdx.x < U) ? b[threadIdx.x] : 0.0f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int64_t ntile = (N + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 16 + wave; tile < ntile; tile += (int64_t)gridDim.x * 16) {
+        const int64_t v = tile * 16 + i;
+        const bool ok = v < N;
+        const int64_t vc = ok ? v : N - 1;
+        int64_t q2, q3, q4;
+        int z, y, x;
+        divmod(vc, g0.Z, g0.iZ, q2, z);
+        divmod(q2, g0.Y, g0.iY, q3, y);
+        divmod(q3, g0.X, g0.iX, q4, x);
+        (void)z;
+        (void)q4;
+        f32x4 out[4], cross[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            out[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            cross[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dx = flip ? 1 - tap / 3 : tap / 3 - 1, dy = flip ? 1 - tap % 3 : tap % 3 - 1;
+            const int xx = x + dx, yy = y + dy;
+            const bool in = xx >= 0 && xx < g0.X && yy >= 0 && yy < g0.Y;
+            if (__builtin_amdgcn_ballot_w64(in) == 0) continue;  // the whole tile reads padding
+            const float* xr = X + (in ? vc + ((int64_t)dx * g0.Y + dy) * g0.Z : vc) * ldx + 4 * g;
+            float4 rows[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rows[q] = *reinterpret_cast<const float4*>(xr + 16 * q);
+            qb::f16x8 bhi[2], blo[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                float x8[8] = {rows[2 * st].x, rows[2 * st].y, rows[2 * st].z, rows[2 * st].w,
+                               rows[2 * st + 1].x, rows[2 * st + 1].y, rows[2 * st + 1].z, rows[2 * st + 1].w};
+#pragma unroll
+                for (int j8 = 0; j8 < 8; ++j8) {
+                    const int k = 16 * (2 * st + (j8 >> 2)) + 4 * g + (j8 & 3);
+                    x8[j8] = in && k < U ? x8[j8] : 0.0f;
+                    if (act & ACT_RELU_IN) x8[j8] = fmaxf(x8[j8], 0.0f);
+                }
+                qb::split8<false>(x8, bhi[st], blo[st]);
+            }
+            const float* A = img + tap * 4096;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const qb::f16x8 whi = qb::lds_frag(A, (st * 4 + m) * 2 + 0, lane);
+                    const qb::f16x8 wlo = qb::lds_frag(A, (st * 4 + m) * 2 + 1, lane);
+                    out[m] = QB_MFMA_F16(whi, bhi[st], out[m]);
+                    cross[m] = QB_MFMA_F16(whi, blo[st], cross[m]);
+                    cross[m] = QB_MFMA_F16(wlo, bhi[st], cross[m]);
+                }
+            }
+        }
+        if (!ok) continue;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int j = 16 * m + 4 * g;
+            if (j >= U) continue;
+            const f32x4 bj = qb::load4(bias + j);
+            float yv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                yv[r] = fmaf(cross[m][r], QB_LO_UNSCALE, out[m][r]) + bj[r];
+                if (act & ACT_RELU) yv[r] = fmaxf(yv[r], 0.0f);
+            }
+            if (j + 3 < U) {
+                if (mask) {
+                    const float4 mk = *reinterpret_cast<const float4*>(mask + v * ldm + j);
+                    yv[0] = mk.x > 0.0f ? yv[0] : 0.0f; yv[1] = mk.y > 0.0f ? yv[1] : 0.0f;
+                    yv[2] = mk.z > 0.0f ? yv[2] : 0.0f; yv[3] = mk.w > 0.0f ? yv[3] : 0.0f;
+                }
+                *reinterpret_cast<float4*>(Y + v * ldy + j) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+            } else {
+                for (int r = 0; r < 4 && j + r < U; ++r)
+                    Y[v * ldy + j + r] = (mask && !(mask[v * ldm + j + r] > 0.0f)) ? 0.0f : yv[r];
+            }
+        }
+    }
+}
+
 // partial[blk][64*64 + 64]: dW[i][j] = sum_v X[v][i] D[v][j] over this block's voxels, then db[j]
 // gridDim.y == 9: blockIdx.y is the tap of a 3x3x1 kernel (gt carries the crop geometry only) and the
 // partials of tap t start at partial + t * gridDim.x * (64*64 + 64).
@@ -1326,6 +1433,17 @@ struct Launcher {
             const size_t smem = sizeof(float) * 9 * 64 * kWs;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            const bool aligned = ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) |
+                                   reinterpret_cast<uintptr_t>(mask)) & 15) == 0;
+            if (aligned && !(ctx->dev.debug_skip & 65536)) {   // split-f16 matrix pipe (bit 65536: the exact-f32 form)
+                const size_t smh = sizeof(float) * (9 * 4096 + 64);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9h_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smh);
+                hipLaunchKernelGGL(conv9h_kernel, dim3((unsigned)(nb < cap ? (nb > 0 ? nb : 1) : cap)), dim3(1024), smh, s,
+                                   X, ld, U, K9, flip, b, Y, ld, act, mask, ld, N, make_gather(gm.X, gm.Y, gm.Z, 0, 0));
+                gather = make_gather(0, 0, 0, 0, 0);
+                return;
+            }
             hipLaunchKernelGGL(conv9_kernel, dim3((unsigned)(nb < cap ? (nb > 0 ? nb : 1) : cap)), dim3(1024), smem, s,
                                X, ld, U, K9, flip, b, Y, ld, act, mask, ld, N, make_gather(gm.X, gm.Y, gm.Z, 0, 0));
             gather = make_gather(0, 0, 0, 0, 0);
