@@ -1100,13 +1100,17 @@ __global__ __launch_bounds__(512) void xtd9_kernel(const float* __restrict__ X, 
         const float* dr = D + v * ldd + cd;
         if (vec) w.d = *reinterpret_cast<const float2*>(dr);
         else w.d = make_float2(dr[0], dr[1]);
+        // one base pointer per voxel and nine uniform row offsets; the neighbour is inside the crop iff its
+        // x-neighbour and its y-neighbour are (three + three comparisons instead of four per tap)
+        const float* x0 = X + v * ldx + cx;
+        const bool okx[3] = {ok && x > 0, ok, ok && x + 1 < gt.X};
+        const bool oky[3] = {y > 0, true, y + 1 < gt.Y};
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int dx = t / 3 - 1, dy = t % 3 - 1;
-            const int xx = x + dx, yy = y + dy;
-            const bool in = ok && xx >= 0 && xx < gt.X && yy >= 0 && yy < gt.Y;
+            const bool in = okx[t / 3] && oky[t % 3];
             w.in |= in ? 1u << t : 0u;
-            const float* xr = X + (in ? v + ((int64_t)dx * gt.Y + dy) * gt.Z : v) * ldx + cx;
+            const int64_t off = ((int64_t)(t / 3 - 1) * gt.Y + (t % 3 - 1)) * gt.Z * ldx;   // wave-uniform
+            const float* xr = x0 + (in ? off : 0);
             if (vec) w.x[t] = *reinterpret_cast<const float2*>(xr);
             else w.x[t] = make_float2(xr[0], xr[1]);
         }
