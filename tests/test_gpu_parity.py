@@ -413,6 +413,43 @@ def test_vi_fwd_random_configurations(params, oracle32):
         assert abs(got - ref) < 1e-4 * abs(ref), (case, U, L, cw, S, K, n, got, ref)
 
 
+def test_vi_fwd_random_configurations_24_tau(params):
+    """The same sweep on the reference's 24-tau protocol (spin-echo index 7: seven mirrored tau pairs in the
+    likelihood loop), plus per-voxel agreement of the fused kernel with the unfused ELBO kernel and -- in
+    literal mode -- with the oracle's literal Simpson sums (exactly mirrored pairs share a tissue factor)."""
+    from oracle.oracle import Oracle, init_weights, synth_inputs
+    from qbold_vi_amd.ops import Context, EncoderWeights
+    p = dict(params, tau_start="-0.028", tau_end="0.065", tau_step="0.004")
+    orc = Oracle("f32", p)
+    ctx = Context(p, True, True)
+    rng = np.random.default_rng(77)
+    for case in range(8):
+        U, L, cw = int(rng.choice([17, 32, 60, 64])), int(rng.choice([1, 2])), bool(rng.integers(0, 2))
+        S, K = int(rng.integers(1, 12)), int(rng.integers(0, 30))
+        n = int(rng.integers(1, 500))
+        v0, seed = int(rng.integers(0, 2 ** 40)), int(rng.integers(0, 2 ** 62))
+        w = init_weights(T=24, U=U, L=L, channelwise_gating=cw, seed=case)
+        w["gate_offset"] = -2.0
+        ew = EncoderWeights(ctx, 24, U, L, cw, -2.0).set_from_arrays(w)
+        x, _ = synth_inputs(n, p, seed=case, oracle=orc)
+        prior, q_want, sigma = orc.encoder_fwd(w, x)
+        mask = (rng.uniform(size=n) > 0.3).astype(np.float32)
+        mask[0] = 1.0
+        zs = orc.philox_normals(seed, 0, v0, n, S)
+        zk = orc.philox_normals(seed, 1, v0, n, max(K, 1)) if K else np.zeros((n, 1, 2), np.float32)
+        for mode in ("table", "literal") if case < 3 else ("table",):
+            ctx.set_tissue_mode(mode)
+            sums, q, nk = ctx.vi_fwd(ew, dev(x), dev(mask), dev(prior), S, K, seed=seed, voxel0=v0)
+            want = orc.elbo(x, mask, q_want, prior, sigma, zs, zk)
+            sums = sums.cpu().numpy()
+            got = (sums[0] + sums[1]) / sums[2]
+            ref = want["elbo"] if K else want["sums"][0] / want["sums"][2]
+            assert abs(got - ref) < 1e-4 * abs(ref), (case, mode, U, L, cw, S, K, n, got, ref)
+            s2, nk2 = ctx.elbo_fwd(dev(x), dev(mask), q, dev(prior), dev(sigma), S, K, seed=seed, voxel0=v0)
+            assert torch.allclose(nk, nk2, rtol=2e-4, atol=2e-4), (case, mode)
+        ctx.set_tissue_mode("table")
+
+
 def test_full_size_properties_one_million_voxels(ctx, weights, oracle32, params):
     """BASELINE config 2 at its full size (1,048,576 voxels x 11 tau, S=32, K=70), through the
     properties that do not need the oracle on every voxel: determinism, shard additivity, masking,
