@@ -450,6 +450,35 @@ def test_vi_fwd_random_configurations_24_tau(params):
         ctx.set_tissue_mode("table")
 
 
+def test_protocol_whose_spin_echo_image_is_not_at_tau_zero(params):
+    """tau_start = -0.017 s with 8 ms steps: model.py:95 still picks image 2 as the normaliser, but its tau is
+    -1 ms, so the grid does not mirror about it -- the compile-time spin-echo kernels must take their general
+    path (no table-free spin-echo signal, no shared pairs).  Fused, unfused and literal against the oracle."""
+    from oracle.oracle import Oracle, init_weights, synth_inputs
+    from qbold_vi_amd.ops import Context, EncoderWeights
+    p = dict(params, tau_start="-0.017", tau_end="0.071", tau_step="0.008")
+    orc = Oracle("f32", p)
+    ctx = Context(p, True, True)
+    assert ctx.T == orc.T == 11 and ctx.se_idx == 2
+    w = init_weights(T=11, U=60, L=2, seed=9)
+    w["gate_offset"] = -3.0
+    ew = EncoderWeights(ctx, 11, 60, 2, True, -3.0).set_from_arrays(w)
+    n, S, K, seed = 700, 6, 11, 5
+    x, _ = synth_inputs(n, p, seed=3, oracle=orc)
+    prior, q_want, sigma = orc.encoder_fwd(w, x)
+    mask = np.ones(n, np.float32)
+    want = orc.elbo(x, mask, q_want, prior, sigma, orc.philox_normals(seed, 0, 0, n, S),
+                    orc.philox_normals(seed, 1, 0, n, K))
+    for mode in ("table", "literal"):
+        ctx.set_tissue_mode(mode)
+        sums, q, nk = ctx.vi_fwd(ew, dev(x), dev(mask), dev(prior), S, K, seed=seed)
+        sums = sums.cpu().numpy()
+        assert abs((sums[0] + sums[1]) / sums[2] - want["elbo"]) < 1e-4 * abs(want["elbo"]), mode
+        s2, nk2 = ctx.elbo_fwd(dev(x), dev(mask), q, dev(prior), dev(sigma), S, K, seed=seed)
+        assert torch.allclose(nk, nk2, rtol=2e-4, atol=2e-4), mode
+        assert np.max(np.abs(nk.cpu().numpy()[:, 0] - want["nll_v"]) / (np.abs(want["nll_v"]) + 1.0)) < 2e-4, mode
+
+
 def test_full_size_properties_one_million_voxels(ctx, weights, oracle32, params):
     """BASELINE config 2 at its full size (1,048,576 voxels x 11 tau, S=32, K=70), through the
     properties that do not need the oracle on every voxel: determinism, shard additivity, masking,
