@@ -107,6 +107,111 @@ def cpu_baseline(params, weights_np, S, K, budget_s=15.0):
                       f"+ Cephes j0f as the reference computes it; {t:.1f} s"}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks, argv):
+    """`python3 bench.py --gpus N` without torchrun: start N rank processes (one per GPU, the launch
+    contract's RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment) and wait for them.  This parent
+    never imports torch and never touches the GPU, nothing is exec'ed; the children inherit stdout, so
+    rank 0's JSON line is this command's JSON line.  Any child failing ends the others (exact PIDs)
+    and makes the exit code non-zero."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
+                   LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in live:      # a rank died: its peers would wait in the rendezvous forever
+                    q.terminate()
+    if rc != 0:
+        print(f"bench.py: a rank exited with code {rc}", file=sys.stderr)
+    return rc
+
+
+def rehearse_launch(args, world, rank):
+    """--rehearse_launch: the launcher, rendezvous, all-reduce ring, barrier-bracketed timing and the JSON
+    line of the N-rank path with NO kernel in the step (host tensors, gloo) -- what a CPU-only container
+    can check of `bench.py --gpus N`.  It reports no throughput ("value": null)."""
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("QBOLD_DIST_BACKEND", "gloo")
+    if world > 1:
+        dist.init_process_group(backend)
+    RING = 4
+    outs = [torch.zeros(3, dtype=torch.float64) for _ in range(RING)]
+    pending = [None] * RING
+
+    def step(k):
+        slot = k % RING
+        if pending[slot] is not None:
+            pending[slot].wait()
+            pending[slot] = None
+        outs[slot][:] = torch.tensor([1.0 + rank, 2.0, 1.0], dtype=torch.float64)
+        if world > 1:
+            pending[slot] = dist.all_reduce(outs[slot], async_op=True)
+        return outs[slot]
+
+    def drain():
+        for slot in range(RING):
+            if pending[slot] is not None:
+                pending[slot].wait()
+                pending[slot] = None
+
+    for k in range(args.warmup):
+        step(k)
+    drain()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        sums = step(k)
+    drain()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ms = torch.tensor([elapsed / max(args.steps, 1) * 1e3], dtype=torch.float64)
+    all_ms = [torch.zeros_like(ms) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(all_ms, ms)
+    else:
+        all_ms = [ms]
+    all_ms = [float(t.item()) for t in all_ms]
+    want = sum(1.0 + r for r in range(world))
+    assert abs(float(sums[0]) - want) < 1e-12 and float(sums[2]) == world, "all-reduce of the sums is wrong"
+    if rank == 0:
+        print(json.dumps({"metric": "voxel-ELBO evals/sec", "value": None, "unit": "voxel-ELBO evals/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": max(all_ms), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "rehearsal": "launcher / rendezvous / all-reduce ring only: no kernel ran, no throughput",
+                          "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                          "backend": dist.get_backend() if world > 1 else "none",
+                          "rank_ms_per_step": {"min": min(all_ms), "max": max(all_ms)},
+                          "config": {"workload": "none (launcher rehearsal)", "global_voxels": 0,
+                                     "parallelism": f"voxel-shard x{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,6 +232,9 @@ def main():
     ap.add_argument("--encoder_precision", choices=["f32", "bf16"], default="f32",
                     help="f32 (headline): float32-grade split-f16 MFMA; bf16: BASELINE config 5's "
                          "'bf16 forward / fp32 ELBO accum' (encoder products on bf16 operands)")
+    ap.add_argument("--rehearse_launch", action="store_true",
+                    help="run the N-rank launcher, rendezvous, all-reduce ring and JSON line with no kernel in the step "
+                         "(host tensors over gloo; reports no throughput) -- the CPU-container check of --gpus N")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_budget_s", type=float, default=15.0)
     args = ap.parse_args()
@@ -136,16 +244,22 @@ def main():
         print("bench.py: QBOLD_DEBUG_SKIP is set -- kernels would skip work; this run is an ablation, not a "
               "benchmark", file=sys.stderr)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: become the launcher BEFORE anything touches the GPU (torch is not even imported)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
+    if args.rehearse_launch:
+        return rehearse_launch(args, world, rank)
+
     import torch
     import torch.distributed as dist
     from qbold_vi_amd.init import init_encoder_weights
     from qbold_vi_amd.ops import EncoderWeights
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
     ndev = torch.cuda.device_count()
     if ndev == 0:
         raise SystemExit("bench.py needs an MI355X: no ROCm device is visible (there is no CPU fallback)")
@@ -239,11 +353,16 @@ def main():
     drain()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    # every rank's own wall time and kernel time; the step time of the job is the MAX over ranks
+    mine = torch.tensor([elapsed / args.steps * 1e3, kernel_ms], dtype=torch.float64, device=device)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, mine)
+    else:
+        per_rank = [mine]
+    per_rank = torch.stack(per_rank).cpu().numpy()
+    elapsed = float(per_rank[:, 0].max()) * 1e-3 * args.steps
     s = sums.cpu().numpy()
     neg_elbo = float((s[0] + s[1]) / s[2])
     if not np.isfinite(neg_elbo):
@@ -296,6 +415,10 @@ def main():
                        "global_voxels": total_vox, "parallelism": f"voxel-shard x{world}",
                        "collective": "all_reduce(3 x f64)/step, overlapped with the next step" if world > 1 else "none"},
             "neg_elbo": neg_elbo,
+            "ranks_seen": dist.get_world_size() if world > 1 else 1,
+            "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none",
+            "rank_ms_per_step": {"min": float(per_rank[:, 0].min()), "max": float(per_rank[:, 0].max())},
+            "rank_kernel_ms": {"min": float(per_rank[:, 1].min()), "max": float(per_rank[:, 1].max())},
             **({"ablation": "QBOLD_DEBUG_SKIP=" + os.environ["QBOLD_DEBUG_SKIP"] + " (NOT a benchmark result)"}
                if os.environ.get("QBOLD_DEBUG_SKIP", "0") not in ("", "0") else {}),
             "roofline": {"kernel": "vi_fwd_kernel" if args.config == 2 else "wide_dense_kernel (one launch per layer) + elbo_fwd_generic_kernel", "bound": "mfma", "achieved": ach_tf,

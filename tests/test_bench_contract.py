@@ -59,6 +59,70 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
 
 
+def _json_lines(out):
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+def test_self_launcher_starts_the_ranks_and_prints_one_line():
+    """`python3 bench.py --gpus 2` with no torchrun around it: the parent spawns the ranks before anything
+    touches a GPU, the ranks rendezvous (gloo here), run the all-reduce ring and rank 0 prints ONE line that
+    says how many ranks the process group saw.  --rehearse_launch puts no kernel in the step (no GPU here)."""
+    env = dict(os.environ, QBOLD_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--rehearse_launch"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["steps"] == 6
+    assert d["value"] is None and "rehearsal" in d          # no kernel ran: no throughput is claimed
+    assert d["rank_ms_per_step"]["min"] <= d["rank_ms_per_step"]["max"] == d["ms_per_step"]
+
+
+def test_driver_launch_line_reaches_the_same_path():
+    """The driver's own N > 1 command (torch.distributed.run around bench.py) must not spawn a second layer."""
+    env = dict(os.environ, QBOLD_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse_launch"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks_seen"] == 2
+
+
+def test_self_launcher_fails_when_a_rank_fails():
+    torch = pytest.importorskip("torch")
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode != 0 and not _json_lines(r.stdout)
+
+
+@pytest.mark.gpu
+def test_self_launched_two_ranks_on_one_card():
+    """The real step under the self-launcher: two ranks share this box's one card (gloo carries the three sums;
+    on a node each rank has its own GPU and the backend is RCCL)."""
+    env = dict(os.environ, QBOLD_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--voxels", "65536", "--ramp_ms", "20"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1
+    d = lines[0]
+    check_line(d, expect_cpu_baseline=False)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo"
+    assert d["config"]["global_voxels"] == 2 * 65536
+    assert d["rank_ms_per_step"]["max"] == pytest.approx(d["ms_per_step"])
+
+
 @pytest.mark.gpu
 def test_live_bench_line_keeps_the_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--voxels",
