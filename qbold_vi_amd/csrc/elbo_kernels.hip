@@ -5,6 +5,8 @@
 // Roofline (qbold_elbo_fwd, T=11): reads 4T+4+20+20+4T = 132 B per voxel, writes 8 B; work is
 // S forward-model evaluations + K log-density pairs + (S+K)/2 Philox calls per voxel
 // (~25 kFLOP-equivalent at S=32, K=70) -> f32 VALU-bound by two orders of magnitude.
+#include <cmath>
+
 #include "elbo_core.h"
 #include "qbold_ctx.h"
 
@@ -199,6 +201,161 @@ __global__ __launch_bounds__(kGenBlock) void elbo_fwd_generic_kernel(
                 kl_sum += qb::kl_swr_diff(qm, pm, z[0], z[1]);
                 if (two) kl_sum += qb::kl_swr_diff(qm, pm, z[2], z[3]);
             }
+            kl_sum = fmaf(0.5f, kl_sum, (float)n_kl * ((pm.s_o + pm.s_d) - (qm.s_o + qm.s_d)));
+            const float nll = qb::voxel_sum(nll_sum) / (float)S;
+            const float kl = K > 0 ? qb::voxel_sum(kl_sum) / (float)K : 0.0f;
+            if (part == 0) {
+                if (nll_kl) nll_kl[v] = make_float2(nll, kl);
+                s_nll += nll * m;
+                s_kl += m > 0.0f ? kl : 0.0f;
+                s_m += m;
+            }
+        }
+    }
+    qb::block_partials(red, s_nll, s_kl, s_m, partials);
+}
+
+// Long protocols with a compile-time tau count and spin-echo index (BASELINE config 3: T = 64, tau = 0 at
+// index 12).  2 T values per voxel do not fit the register budget of a VALU-bound kernel (as registers the
+// T = 64 instance of elbo_fwd_kernel takes 257 VGPRs: one wave per SIMD), so the pre-scaled data and the
+// inverse sigmas live in LDS as float2 rows [t][voxel] -- one conflict-free ds_read_b64 per scored tau at an
+// immediate offset -- and everything else is the fast path of elbo_core.h: the tau loop unrolled, mirrored
+// pairs evaluated once (52 signal evaluations per draw for 64 taus), per-draw factors in the exponents.
+// A voxel's row is read as four float4 per lane (the four lanes of a voxel own a quarter of the taus each).
+// LOGSIG: `sigma` holds log sigma, the sigma head before its exp (model.py:211-214).
+constexpr int kLdsBlock = 256;
+constexpr int kLdsVox = kLdsBlock / QB_LANES_PER_VOXEL;
+
+template <int T, int SE, bool LOGSIG>
+__global__ __launch_bounds__(kLdsBlock) void elbo_fwd_lds_kernel(
+    QbDev c, const float4* __restrict__ g_tab, const float* __restrict__ x,
+    const float* __restrict__ mask, const float* __restrict__ q, const float* __restrict__ prior,
+    const float* __restrict__ sigma, const float* __restrict__ zs, const float* __restrict__ zk,
+    int S, int K, uint64_t seed, int64_t voxel0, float2* __restrict__ nll_kl,
+    double* __restrict__ partials, int64_t N) {
+    static_assert(T % 16 == 0 && SE >= 0 && SE < T, "a lane owns T / 4 taus as float4 loads");
+    __shared__ qb::FwdLds L;
+    __shared__ float2 dat[T * kLdsVox];  // (y_t / sigma_t, 1 / sigma_t) at [t][voxel slot]
+    __shared__ double red[3 * (kLdsBlock / 64)];
+    qb::fwd_lds_fill(&L, g_tab, false);
+    if (threadIdx.x < QB_MAX_T) L.blood_B[threadIdx.x] = c.blood_B[threadIdx.x];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int part = lane >> 4;
+    const int vl = wave * QB_VOX_PER_WAVE + (lane & 15);
+    float2* my = dat + vl;
+    float s_nll = 0.0f, s_kl = 0.0f, s_m = 0.0f;
+    const int64_t ntile = (N + kLdsVox - 1) / kLdsVox;
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int64_t v = tile * kLdsVox + vl;
+        const bool live = v < N;
+        const int64_t vc = live ? v : N - 1;
+        const float4* xq = reinterpret_cast<const float4*>(x + vc * T) + (T / 16) * part;
+        const float4* sq = reinterpret_cast<const float4*>(sigma + vc * T) + (T / 16) * part;
+        const float inv_nt = qb::rcpf_(x[vc * T + SE] + 1e-3f);  // model.py:545
+        float ls = 0.0f;
+        __syncthreads();  // the previous tile's draws are done with dat (first trip: the table is filled)
+#pragma unroll
+        for (int k4 = 0; k4 < T / 16; ++k4) {
+            const float4 xx = xq[k4], ss = sq[k4];
+            const float xa[4] = {xx.x, xx.y, xx.z, xx.w}, sa[4] = {ss.x, ss.y, ss.z, ss.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float is;
+                if (LOGSIG) {
+                    is = qb::exp2f_(-QB_LOG2E * sa[e]);
+                    ls += sa[e];
+                } else {
+                    is = qb::rcpf_(sa[e]);
+                    ls += QB_LN2 * qb::log2f_(sa[e]);
+                }
+                my[((T / 4) * part + 4 * k4 + e) * kLdsVox] = make_float2(xa[e] * inv_nt * is, is);
+            }
+        }
+        const float log_s_sum = qb::voxel_sum(ls) + (float)T * 0.9189385332046727f;  // + T log sqrt(2 pi)
+        __syncthreads();
+        if (live) {
+            float qv[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) qv[i] = q[v * 5 + i];
+            const float m = mask ? mask[v] : 1.0f;
+            const qb::LogitMvn qm = qb::make_mvn(qv);
+            const uint64_t vox = (uint64_t)(voxel0 + v);
+            const float* zsv = zs ? zs + v * S * 2 : nullptr;
+            const float* zkv = zk ? zk + v * K * 2 : nullptr;
+            float nll_sum = 0.0f, kl_sum = 0.0f;
+            int n_lik = 0, n_kl = 0;
+            __builtin_amdgcn_s_setprio(QB_PRIO_LIK);
+            for (int j = part; 2 * j < S; j += QB_LANES_PER_VOXEL) {
+                float z[4];
+                const bool two = 2 * j + 1 < S;
+                if (zsv) {
+                    z[0] = zsv[4 * j];
+                    z[1] = zsv[4 * j + 1];
+                    z[2] = two ? zsv[4 * j + 2] : 0.0f;
+                    z[3] = two ? zsv[4 * j + 3] : 0.0f;
+                } else {
+                    qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_LIK, z);
+                }
+                n_lik += two ? 2 : 1;
+#pragma unroll 1
+                for (int d = 0; d < (two ? 2 : 1); ++d) {
+                    float a, b, oef, dbv;
+                    qb::reparam_logits(qm, d ? z[2] : z[0], d ? z[3] : z[1], a, b);
+                    qb::forward_transform(a, b, oef, dbv);
+                    const qb::FwdFast fv = qb::fwd_fast(c, oef, dbv);
+                    // tau = 0 at the spin echo (checked by the host dispatch): F(0) = 0, no table row
+                    const float s_se = fmaf(fv.tissue_w, 1.0f, fv.blood_w * qb::exp2f_(fv.ng * L.blood_B[SE]));
+                    const float inv_np = qb::rcpf_(s_se + 1e-3f);
+                    const float lt = qb::log2f_(fv.tissue_w * inv_np), lb = qb::log2f_(fv.blood_w * inv_np);
+                    float acc = 0.0f;
+                    auto signal = [&](int t) -> float {
+                        const float u = fabsf(fmaf((float)t, fv.ub, fv.ua));
+                        const float4 kk = L.tab[(int)u];
+                        const float f = __builtin_amdgcn_fractf(u);
+                        const float F = fmaf(fmaf(fmaf(kk.w, f, kk.z), f, kk.y), f, kk.x);
+                        return qb::exp2f_(fmaf(fv.nd, F, lt)) + qb::exp2f_(fmaf(fv.ng, L.blood_B[t], lb));
+                    };
+                    auto residual = [&](int t, float yh) {
+                        const float2 dd = my[t * kLdsVox];
+                        const float r = fmaf(-yh, dd.y, dd.x);
+                        acc = fmaf(r, r, acc);
+                    };
+                    residual(SE, s_se * inv_np);
+#pragma unroll
+                    for (int t = SE + 1; t < T; ++t) {
+                        const float yh = signal(t);
+                        residual(t, yh);
+                        if (2 * SE - t >= 0) residual(2 * SE - t, yh);
+                        if (((t - SE) % QB_LIK_BARRIER) == 0) asm volatile("" ::: "memory");
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2 * SE - (T - 1); ++t) residual(t, signal(t));  // no partner on the grid
+                    nll_sum += acc;
+                }
+            }
+            nll_sum = fmaf(0.5f, nll_sum, (float)n_lik * log_s_sum);
+            float pv[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) pv[i] = prior[v * 5 + i];
+            const qb::LogitMvn pm = qb::make_mvn(pv);
+            __builtin_amdgcn_s_setprio(QB_PRIO_KL);
+            for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
+                float z[4];
+                const bool two = 2 * j + 1 < K;
+                if (zkv) {
+                    z[0] = zkv[4 * j];
+                    z[1] = zkv[4 * j + 1];
+                    z[2] = two ? zkv[4 * j + 2] : 0.0f;
+                    z[3] = two ? zkv[4 * j + 3] : 0.0f;
+                } else {
+                    qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_KL, z);
+                }
+                n_kl += two ? 2 : 1;
+                kl_sum += qb::kl_swr_diff(qm, pm, z[0], z[1]);
+                if (two) kl_sum += qb::kl_swr_diff(qm, pm, z[2], z[3]);
+            }
+            __builtin_amdgcn_s_setprio(QB_PRIO_AFTER);
             kl_sum = fmaf(0.5f, kl_sum, (float)n_kl * ((pm.s_o + pm.s_d) - (qm.s_o + qm.s_d)));
             const float nll = qb::voxel_sum(nll_sum) / (float)S;
             const float kl = K > 0 ? qb::voxel_sum(kl_sum) / (float)K : 0.0f;
@@ -414,15 +571,13 @@ extern "C" int64_t qbold_elbo_workspace_bytes(const qbold_ctx* ctx) {
     return (int64_t)sizeof(double) * 3 * (int64_t)qb::elbo_grid(ctx);
 }
 
-extern "C" int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float* mask, const float* q,
-                              const float* prior, const float* sigma, const float* zs,
-                              const float* zk, int S, int K, uint64_t seed, int64_t voxel0,
-                              float* nll_kl, double* sums, void* workspace, int64_t N, void* stream) {
-    QB_NEED_DEVICE(ctx);
-    QB_REQUIRE(N >= 0 && S >= 1 && K >= 0, "qbold_elbo_fwd: need N >= 0, S >= 1, K >= 0");
-    QB_REQUIRE(sums && workspace, "qbold_elbo_fwd: null sums/workspace");
-    QB_REQUIRE(N == 0 || (x && q && prior && sigma), "qbold_elbo_fwd: null input buffer");
-    hipStream_t s = (hipStream_t)stream;
+// sigma_is_log: `sigma` holds the sigma head before its exp (the wide fused path hands its head over
+// that way); built for the protocols that take the LDS-data kernel.
+namespace qb {
+int elbo_fwd_launch(const qbold_ctx* ctx, const float* x, const float* mask, const float* q,
+                    const float* prior, const float* sigma, bool sigma_is_log, const float* zs,
+                    const float* zk, int S, int K, uint64_t seed, int64_t voxel0, float* nll_kl,
+                    double* sums, void* workspace, int64_t N, hipStream_t s) {
     double* partials = reinterpret_cast<double*>(workspace);
     const int64_t ntile = (N + kVoxPerBlock - 1) / kVoxPerBlock;
     int grid = (int)(ntile < qb::elbo_grid(ctx) ? (ntile > 0 ? ntile : 1) : qb::elbo_grid(ctx));
@@ -433,7 +588,28 @@ extern "C" int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float*
                        ctx->dev, ctx->d_tab, x, mask, q, prior, sigma, zs, zk, S, K, seed, voxel0, \
                        out, partials, N)
     const bool fast = qb::elbo_fast_path(ctx);
-    switch (ctx->dev.T) {
+    // long protocols: compile-time tau count and spin-echo index when tau = 0 there (mirrored pairs).  On the
+    // float32 grid start + i step the spin-echo tau of config 3 (-0.015 + 12 * 0.00125) is zero only up to
+    // rounding: within 1e-6 of a table segment (|dF| < 1e-7, below the table's own float32 rounding) it counts
+    // as the spin echo, and tau_{se+j}, tau_{se-j} as a mirrored pair.
+    const bool lds64 = ctx->dev.T == 64 && fast && ctx->dev.se_idx == 12 && !ctx->dev.multi_norm &&
+                       !(ctx->dev.debug_skip & 4) &&
+                       std::fabs(std::fmaf(12.0f, ctx->dev.tauh_step, ctx->dev.tauh0)) < 1e-6f;
+    if (sigma_is_log && !lds64) {
+        qb::set_error("elbo_fwd_launch: log-sigma input is built for the 64-tau protocol with tau = 0 at index 12 "
+                      "(table mode, Gaussian likelihood, one-image normalisation)");
+        return QBOLD_ERR_UNSUPPORTED;
+    }
+    if (lds64) {
+        const int64_t gt = (N + kLdsVox - 1) / kLdsVox;
+        grid = (int)(gt < qb::elbo_grid(ctx) ? (gt > 0 ? gt : 1) : qb::elbo_grid(ctx));
+        if (sigma_is_log)
+            hipLaunchKernelGGL((elbo_fwd_lds_kernel<64, 12, true>), dim3(grid), dim3(kLdsBlock), 0, s, ctx->dev,
+                               ctx->d_tab, x, mask, q, prior, sigma, zs, zk, S, K, seed, voxel0, out, partials, N);
+        else
+            hipLaunchKernelGGL((elbo_fwd_lds_kernel<64, 12, false>), dim3(grid), dim3(kLdsBlock), 0, s, ctx->dev,
+                               ctx->d_tab, x, mask, q, prior, sigma, zs, zk, S, K, seed, voxel0, out, partials, N);
+    } else switch (ctx->dev.T) {
         case 11:
             if (fast && ctx->dev.se_idx == 2 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(11, 2, true, false);
             else if (fast) QB_LAUNCH_ELBO(11, -1, true, false);
@@ -467,6 +643,19 @@ extern "C" int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float*
     hipLaunchKernelGGL(qb::reduce_partials_kernel, dim3(1), dim3(192), 0, s, partials, grid, sums);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
+}
+}  // namespace qb
+
+extern "C" int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float* mask, const float* q,
+                              const float* prior, const float* sigma, const float* zs,
+                              const float* zk, int S, int K, uint64_t seed, int64_t voxel0,
+                              float* nll_kl, double* sums, void* workspace, int64_t N, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    QB_REQUIRE(N >= 0 && S >= 1 && K >= 0, "qbold_elbo_fwd: need N >= 0, S >= 1, K >= 0");
+    QB_REQUIRE(sums && workspace, "qbold_elbo_fwd: null sums/workspace");
+    QB_REQUIRE(N == 0 || (x && q && prior && sigma), "qbold_elbo_fwd: null input buffer");
+    return qb::elbo_fwd_launch(ctx, x, mask, q, prior, sigma, false, zs, zk, S, K, seed, voxel0, nll_kl, sums,
+                               workspace, N, (hipStream_t)stream);
 }
 
 // kl_loss for the diagonal family (use_mvg = False, per-voxel prior): model.py:686-716 with
