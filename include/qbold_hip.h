@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define QBOLD_MAX_T 64
-#define QBOLD_ABI_VERSION 2
+#define QBOLD_ABI_VERSION 3
 
 typedef enum {
     QBOLD_OK = 0,
@@ -165,6 +165,18 @@ int qbold_encoder_wide_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shap
                            const float* x, int stream_sel, float* workspace, float* out_q,
                            float* out_log_sigma, int64_t N, void* stream);
 
+/* The stream-2 encoder of the same wide shapes in ONE launch, activations resident in registers from the
+ * first layer to the heads (HBM sees x once and the heads once; create_encoder, model.py:122-223).  Built for
+ * U = 256, L = 1 or 2, T <= 16 or 49 <= T <= 64, channel-wise gating, QBOLD_ENC_F32; *_packed_floats returns
+ * the image size in floats or a negative qbold_status for other shapes.  x [N][T] -> out_q [N][5] (model.py:208),
+ * out_log_sigma [N][T] (the sigma head before its exp, :211-214).  packed, and x / out_log_sigma when T is a
+ * multiple of 4, must be 16-byte aligned. */
+int64_t qbold_encoder_fused_packed_floats(const qbold_encoder_shape* shape);
+int qbold_encoder_fused_pack(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* weights,
+                             float* packed, void* stream);
+int qbold_encoder_fused_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* packed,
+                            const float* x, float* out_q, float* out_log_sigma, int64_t N, void* stream);
+
 /* ---- logit-Normal pieces -------------------------------------------------------------------- */
 /* ReparamTrickLayer.call + forward_transform (model.py:15-50, 299-305): q [N][5], z [N][2] ->
  * oef_dbv [N][2]. */
@@ -263,6 +275,11 @@ int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float* mask, cons
 /* The whole hot path in one launch: encoder stream 2 (model.py:122-223) -> S reparameterised
  * samples -> forward model -> NLL, K-sample KL against `prior`, masked sums.  q_out [N][5]
  * receives the posterior parameters (NULL to skip); other arguments as qbold_elbo_fwd. */
+/* Wide shapes (qbold_encoder_fused_packed_floats(shape) > 0 on the 64-tau protocol, BASELINE config 3) run as
+ * two launches -- the one-launch encoder, then the ELBO kernel on its heads: `packed` is then the image of
+ * qbold_encoder_fused_pack and `workspace` must hold qbold_vi_workspace_bytes(ctx, shape, N) bytes, 256-byte
+ * aligned (for the LDS-resident shapes that is qbold_elbo_workspace_bytes()). */
+int64_t qbold_vi_workspace_bytes(const qbold_ctx* ctx, const qbold_encoder_shape* shape, int64_t N);
 int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* packed,
                  const float* x, const float* mask, const float* prior, int S, int K, uint64_t seed,
                  int64_t voxel0, float* q_out, float* nll_kl, double* sums, void* workspace,

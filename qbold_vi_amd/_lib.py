@@ -93,6 +93,10 @@ SIGNATURES = {
     "qbold_encoder_wide_workspace_floats": (C.c_int64, [C.POINTER(EncoderShape), C.c_int64]),
     "qbold_encoder_wide_pack": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, _P]),
     "qbold_encoder_wide_fwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, C.c_int, _P, _P, _P, C.c_int64, _P]),
+    "qbold_encoder_fused_packed_floats": (C.c_int64, [C.POINTER(EncoderShape)]),
+    "qbold_encoder_fused_pack": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, _P]),
+    "qbold_encoder_fused_fwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, _P, _P, C.c_int64, _P]),
+    "qbold_vi_workspace_bytes": (C.c_int64, [_P, C.POINTER(EncoderShape), C.c_int64]),
     "qbold_signal_fwd_ex": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "qbold_kl_diag": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "qbold_wls_fit": (C.c_int, [_P, _P, C.c_double, _P, C.c_int64, _P]),

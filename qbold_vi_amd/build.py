@@ -14,8 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libqbold_hip.so")
 SOURCES = ["ctx.hip", "signal_kernels.hip", "elbo_kernels.hip", "encoder_kernels.hip",
-           "vi_kernels.hip", "misc_kernels.hip", "elbo_bwd_kernels.hip", "train_kernels.hip", "wide_kernels.hip"]
-HEADERS = ["canon_layout.h", "qbold_dev.h", "qbold_ctx.h", "elbo_core.h", "encoder_core.h",
+           "vi_kernels.hip", "misc_kernels.hip", "elbo_bwd_kernels.hip", "train_kernels.hip", "wide_kernels.hip", "wide_fused_kernels.hip"]
+HEADERS = ["canon_layout.h", "qbold_dev.h", "qbold_ctx.h", "elbo_core.h", "encoder_core.h", "wide_common.h",
            os.path.join("..", "..", "include", "qbold_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]

@@ -571,6 +571,14 @@ extern "C" int64_t qbold_elbo_workspace_bytes(const qbold_ctx* ctx) {
     return (int64_t)sizeof(double) * 3 * (int64_t)qb::elbo_grid(ctx);
 }
 
+namespace qb {
+// the 64-tau protocol with tau = 0 (up to float32 rounding of the grid) at index 12: see elbo_fwd_launch
+bool elbo_logsigma_path(const qbold_ctx* ctx) {
+    return ctx->dev.T == 64 && elbo_fast_path(ctx) && ctx->dev.se_idx == 12 && !ctx->dev.multi_norm &&
+           !(ctx->dev.debug_skip & 4) && std::fabs(std::fmaf(12.0f, ctx->dev.tauh_step, ctx->dev.tauh0)) < 1e-6f;
+}
+}  // namespace qb
+
 // sigma_is_log: `sigma` holds the sigma head before its exp (the wide fused path hands its head over
 // that way); built for the protocols that take the LDS-data kernel.
 namespace qb {
@@ -592,9 +600,7 @@ int elbo_fwd_launch(const qbold_ctx* ctx, const float* x, const float* mask, con
     // float32 grid start + i step the spin-echo tau of config 3 (-0.015 + 12 * 0.00125) is zero only up to
     // rounding: within 1e-6 of a table segment (|dF| < 1e-7, below the table's own float32 rounding) it counts
     // as the spin echo, and tau_{se+j}, tau_{se-j} as a mirrored pair.
-    const bool lds64 = ctx->dev.T == 64 && fast && ctx->dev.se_idx == 12 && !ctx->dev.multi_norm &&
-                       !(ctx->dev.debug_skip & 4) &&
-                       std::fabs(std::fmaf(12.0f, ctx->dev.tauh_step, ctx->dev.tauh0)) < 1e-6f;
+    const bool lds64 = qb::elbo_logsigma_path(ctx);
     if (sigma_is_log && !lds64) {
         qb::set_error("elbo_fwd_launch: log-sigma input is built for the 64-tau protocol with tau = 0 at index 12 "
                       "(table mode, Gaussian likelihood, one-image normalisation)");

@@ -33,6 +33,14 @@
 namespace qb {
 int check_encoder_shape(const qbold_ctx* ctx, const qbold_encoder_shape* s);
 bool elbo_fast_path(const qbold_ctx* ctx);
+bool elbo_logsigma_path(const qbold_ctx* ctx);
+int elbo_fwd_launch(const qbold_ctx* ctx, const float* x, const float* mask, const float* q, const float* prior,
+                    const float* sigma, bool sigma_is_log, const float* zs, const float* zk, int S, int K,
+                    uint64_t seed, int64_t voxel0, float* nll_kl, double* sums, void* workspace, int64_t N,
+                    hipStream_t s);
+bool wide_fused_supported(const qbold_encoder_shape* s);
+int wide_fused_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* packed, const float* x,
+                   float* out_q, float* out_log_sigma, int64_t N, hipStream_t s);
 }
 
 namespace {
@@ -125,12 +133,47 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
 
 }  // namespace
 
+namespace {
+// Wide encoders (BASELINE config 3): the path is two launches -- the one-launch encoder of
+// wide_fused_kernels.hip, then the ELBO kernel reading the heads (q, log sigma) back from the workspace.
+// Workspace: [per-workgroup partials][log sigma N T floats][q N 5 floats (used when q_out is NULL)].
+inline int64_t align256(int64_t b) { return (b + 255) & ~(int64_t)255; }
+bool wide_vi_path(const qbold_ctx* ctx, const qbold_encoder_shape* shape) {
+    return qb::wide_fused_supported(shape) && ctx && shape->T == ctx->dev.T && qb::elbo_logsigma_path(ctx);
+}
+}  // namespace
+
+extern "C" int64_t qbold_vi_workspace_bytes(const qbold_ctx* ctx, const qbold_encoder_shape* shape, int64_t N) {
+    if (!ctx || !shape || N < 0) return QBOLD_ERR_INVALID;
+    const int64_t part = align256(qbold_elbo_workspace_bytes(ctx));
+    if (!wide_vi_path(ctx, shape)) return part;
+    return part + align256(N * (int64_t)shape->T * 4) + align256(N * 5 * 4);
+}
+
 extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
                             const float* packed, const float* x, const float* mask,
                             const float* prior, int S, int K, uint64_t seed, int64_t voxel0,
                             float* q_out, float* nll_kl, double* sums, void* workspace, int64_t N,
                             void* stream) {
     QB_NEED_DEVICE(ctx);
+    if (wide_vi_path(ctx, shape)) {
+        QB_REQUIRE(N >= 0 && S >= 1 && K >= 0, "qbold_vi_fwd: need N >= 0, S >= 1, K >= 0");
+        QB_REQUIRE(sums && workspace, "qbold_vi_fwd: null sums/workspace");
+        QB_REQUIRE(N == 0 || (packed && x && prior), "qbold_vi_fwd: null input buffer");
+        QB_REQUIRE(reinterpret_cast<uintptr_t>(workspace) % 256 == 0 && reinterpret_cast<uintptr_t>(packed) % 16 == 0 &&
+                       reinterpret_cast<uintptr_t>(x) % 16 == 0,
+                   "qbold_vi_fwd: wide shapes need a 256-byte aligned workspace of qbold_vi_workspace_bytes() and "
+                   "16-byte aligned packed / x");
+        char* w = reinterpret_cast<char*>(workspace);
+        float* ls = reinterpret_cast<float*>(w + align256(qbold_elbo_workspace_bytes(ctx)));
+        float* qbuf = q_out ? q_out : reinterpret_cast<float*>(reinterpret_cast<char*>(ls) + align256(N * (int64_t)shape->T * 4));
+        if (N > 0) {
+            const int rc = qb::wide_fused_fwd(ctx, shape, packed, x, qbuf, ls, N, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+        return qb::elbo_fwd_launch(ctx, x, mask, qbuf, prior, ls, true, nullptr, nullptr, S, K, seed, voxel0, nll_kl,
+                                   sums, workspace, N, (hipStream_t)stream);
+    }
     int rc = qb::check_encoder_shape(ctx, shape);
     if (rc) return rc;
     QB_REQUIRE(N >= 0 && S >= 1 && K >= 0, "qbold_vi_fwd: need N >= 0, S >= 1, K >= 0");

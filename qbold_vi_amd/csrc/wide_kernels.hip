@@ -30,11 +30,13 @@
 #include "canon_layout.h"
 #include "encoder_core.h"
 #include "qbold_ctx.h"
+#include "wide_common.h"
 
 namespace {
 
 using qb::f16x8;
 using qb::f32x4;
+using namespace qbw;
 
 constexpr int kWB = 512;  // threads per block: 2 waves per SIMD at <= 256 registers
 enum { EPI_LINEAR = 0, EPI_RELU = 1, EPI_GATE = 2, EPI_HEAD = 3 };
@@ -130,37 +132,6 @@ __global__ void wide_pack_kernel(OpImage o, const float* __restrict__ W, const f
         const _Float16 hi = (_Float16)w;
         ph[h] = part == 0 ? hi : (_Float16)((w - (float)hi) * QB_LO_SCALE);
     }
-}
-
-__device__ __forceinline__ f16x8 as_frag(const uint4& u) { return __builtin_bit_cast(f16x8, u); }
-
-__device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
-    // LDS-direct load: lane l's 16 bytes at src land at lds_dst + 16 l (lds_dst is wave-uniform)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
-// LDS reads of the staged images go through inline asm: the compiler orders an LDS load it can see
-// behind EVERY LDS-direct load in flight (s_waitcnt vmcnt(0): it cannot tell the ring slots apart),
-// which would drain the activation stream at every k-step.  An asm read is invisible to that
-// bookkeeping, so its completion is waited for explicitly (lds_wait ties the s_waitcnt to the
-// registers, which keeps consumers behind it).
-__device__ __forceinline__ uint32_t lds_addr(const void* p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-}
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // one VGPR quad (asm "v" operand)
-template <int OFF>
-__device__ __forceinline__ u32x4 lds_read16(uint32_t addr) {
-    static_assert(OFF >= 0 && OFF < 65536, "ds_read_b128 immediate offset is 16 bits");
-    u32x4 r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-    return r;
-}
-__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
 // s_waitcnt vmcnt(4 n): at most n steps' worth of this wave's four-instruction groups still in flight

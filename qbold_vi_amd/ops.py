@@ -58,7 +58,7 @@ class EncoderWeights:
         self.flat = torch.zeros(self.num_params, dtype=torch.float32, device=ctx.device)
         self.packed = torch.zeros(int(lib.qbold_encoder_packed_floats(C.byref(self.shape))),
                                   dtype=torch.float32, device=ctx.device)
-        self._dirty = True
+        self._dirty = {"packed", "wide", "fused"}   # device images to rebuild from the canonical blob
         # weight-streaming image for widths beyond the LDS-resident kernels (U = 128 / 256)
         n_wide = int(lib.qbold_encoder_wide_packed_floats(C.byref(self.shape)))
         self.wide = n_wide > 0 and not Context.fits_fused(self.shape)
@@ -66,6 +66,11 @@ class EncoderWeights:
                             if self.wide else None)
         self._wide_ws = None
         self._wide_ws_n = 0
+        # one-launch form of the wide stream-2 encoder (wide_fused_kernels.hip: activations in registers)
+        n_fused = int(lib.qbold_encoder_fused_packed_floats(C.byref(self.shape)))
+        self.fused_wide = self.wide and n_fused > 0
+        self.fused_packed = (torch.zeros(n_fused, dtype=torch.float32, device=ctx.device)
+                             if self.fused_wide else None)
 
     # canonical blob views -------------------------------------------------------------------
     def _slices(self):
@@ -97,7 +102,7 @@ class EncoderWeights:
                 src = arr[l] if len(pieces) > 1 or arr.dim() == len(shape) + 1 else arr
                 flat[off:off + int(np.prod(shape))] = src.reshape(-1)
         self.flat.copy_(flat.to(self.flat.device))
-        self._dirty = True
+        self.mark_dirty()
         return self
 
     def to_arrays(self):
@@ -111,7 +116,7 @@ class EncoderWeights:
         return out
 
     def mark_dirty(self):
-        self._dirty = True
+        self._dirty = {"packed", "wide", "fused"}
 
     def set_precision(self, precision):
         """'f32' (split-f16 MFMA, float32-grade) or 'bf16' (single bf16 MFMA pass) for the fused
@@ -119,16 +124,24 @@ class EncoderWeights:
         if precision != "f32" and not Context.fits_fused(self.shape):
             raise ValueError("precision='bf16' exists for the fused voxel kernels (U <= 64, L <= 2, T in {11, 24})")
         self.shape.precision = self.PRECISIONS[precision]
-        self._dirty = True
+        self.mark_dirty()
         return self
 
     def wide_ptr(self):
-        if self._dirty:
+        if "wide" in self._dirty:
             _lib.check(_lib.load().qbold_encoder_wide_pack(self.ctx.handle, C.byref(self.shape), _ptr(self.flat),
                                                            _ptr(self.wide_packed), _stream()),
                        "qbold_encoder_wide_pack")
-            self._dirty = False
+            self._dirty.discard("wide")
         return _ptr(self.wide_packed)
+
+    def fused_ptr(self):
+        if "fused" in self._dirty:
+            _lib.check(_lib.load().qbold_encoder_fused_pack(self.ctx.handle, C.byref(self.shape), _ptr(self.flat),
+                                                            _ptr(self.fused_packed), _stream()),
+                       "qbold_encoder_fused_pack")
+            self._dirty.discard("fused")
+        return _ptr(self.fused_packed)
 
     def wide_workspace(self, N):
         if self._wide_ws is None or self._wide_ws_n < N:
@@ -138,11 +151,11 @@ class EncoderWeights:
         return self._wide_ws
 
     def packed_ptr(self):
-        if self._dirty:
+        if "packed" in self._dirty:
             _lib.check(_lib.load().qbold_encoder_pack(self.ctx.handle, C.byref(self.shape),
                                                       _ptr(self.flat), _ptr(self.packed), _stream()),
                        "qbold_encoder_pack")
-            self._dirty = False
+            self._dirty.discard("packed")
         return _ptr(self.packed)
 
 
@@ -179,6 +192,7 @@ class Context:
         self.taus = taus
         self._ws = None
         self._sums = None
+        self.force_layerwise_wide = False   # tests: compare the one-launch wide encoder with the layer-wise one
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -269,9 +283,15 @@ class Context:
                     continue
                 q = torch.empty((N, 5), dtype=torch.float32, device=x.device)
                 ls = torch.empty((N, self.T), dtype=torch.float32, device=x.device) if sel == 2 else None
-                _lib.check(self.lib.qbold_encoder_wide_fwd(self.handle, C.byref(weights.shape), weights.wide_ptr(),
-                                                           _ptr(x2), sel, _ptr(weights.wide_workspace(N)), _ptr(q),
-                                                           _ptr(ls), N, _stream()), "qbold_encoder_wide_fwd")
+                if sel == 2 and weights.fused_wide and not self.force_layerwise_wide:
+                    _lib.check(self.lib.qbold_encoder_fused_fwd(self.handle, C.byref(weights.shape),
+                                                                weights.fused_ptr(), _ptr(x2), _ptr(q), _ptr(ls), N,
+                                                                _stream()), "qbold_encoder_fused_fwd")
+                else:
+                    _lib.check(self.lib.qbold_encoder_wide_fwd(self.handle, C.byref(weights.shape),
+                                                               weights.wide_ptr(), _ptr(x2), sel,
+                                                               _ptr(weights.wide_workspace(N)), _ptr(q), _ptr(ls), N,
+                                                               _stream()), "qbold_encoder_wide_fwd")
                 if sel == 1:
                     o1 = q.reshape(lead + (5,))
                 else:
@@ -385,6 +405,23 @@ class Context:
         N = x.numel() // self.T
         prior = _f32(prior, "prior", 5)
         mask = _f32(mask, "mask") if mask is not None else None
+        if weights.fused_wide and not self.force_layerwise_wide:
+            nws = int(self.lib.qbold_vi_workspace_bytes(self.handle, C.byref(weights.shape), N))
+            if nws > int(self.lib.qbold_elbo_workspace_bytes(self.handle)) + 256:  # the two-launch wide path applies
+                ws = getattr(weights, "_vi_ws", None)
+                if ws is None or ws.numel() < nws:
+                    ws = weights._vi_ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+                if out is None:
+                    sums = torch.empty(3, dtype=torch.float64, device=x.device)
+                    qo = torch.empty((N, 5), dtype=torch.float32, device=x.device) if want_q else None
+                    nk = torch.empty((N, 2), dtype=torch.float32, device=x.device) if per_voxel else None
+                else:
+                    sums, qo, nk = out
+                _lib.check(self.lib.qbold_vi_fwd(self.handle, C.byref(weights.shape), weights.fused_ptr(),
+                                                 _ptr(x), _ptr(mask), _ptr(prior), int(S), int(K), int(seed),
+                                                 int(voxel0), _ptr(qo), _ptr(nk), _ptr(sums), _ptr(ws), N, _stream()),
+                           "qbold_vi_fwd")
+                return sums, qo, nk
         if not self.fits_fused(weights.shape):  # unfused composition of the same pieces
             _, q2, sg = self.encoder_fwd(weights, x.reshape(N, self.T), want=("out2", "sigma"))
             sums, nk = self.elbo_fwd(x, mask, q2, prior, sg, S, K, seed=seed, voxel0=voxel0)
