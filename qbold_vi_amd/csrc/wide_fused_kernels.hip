@@ -42,6 +42,9 @@ namespace {
 
 using namespace qbw;
 
+#ifndef QB_FUSED_VALU_PER_MFMA
+#define QB_FUSED_VALU_PER_MFMA 8
+#endif
 constexpr int kFB = 256;          // threads per block: one wave per SIMD
 constexpr int kRing = 4;          // LDS ring slots of 16 fragments
 constexpr int kAhead = 3;         // stages in flight beyond the one being read
@@ -203,81 +206,108 @@ __device__ __forceinline__ void lds_wait3(u32x4& a, u32x4& b, u32x4& c) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
 }
 
-// k-steps S .. KSOP-1 of one 16-row output tile, both voxel tiles.  FO: index inside the stage of the tile's
-// first fragment.  The fragment pair of step S+1 is requested before the six MFMAs of step S and waited
-// for after them.  (Recursive template: every LDS offset is an instruction immediate.)
-template <int KSOP, int FO, int S_>
-__device__ __forceinline__ void tile_steps(Stream& S, u32x4 whi, u32x4 wlo, const Panel<KSOP>& in,
-                                           f32x4 (&out)[2], f32x4 (&cross)[2]) {
+struct Frag {   // one (hi, lo) fragment pair of the weight stream
+    u32x4 hi, lo;
+};
+struct Acc {    // a finished (or running) output tile: both voxel tiles' accumulators and the tile's bias rows
+    f32x4 out[2], cross[2];
+    u32x4 bias;
+};
+template <int V>
+struct IC {
+    static constexpr int value = V;
+};
+
+// Request the fragment pair that starts at fragment F of the pass; F == FP is the first pair of the NEXT pass
+// (same weights: the stream wraps).  By the end of a stage the next one has landed (mid-stage handshake), so
+// the read-ahead never stalls at a tile, stage or pass boundary.
+template <int F, int FP>
+__device__ __forceinline__ void frag_fetch(Stream& S, Frag& w) {
+    constexpr int FO = (F % FP) % kStageFrags;
+    if constexpr (FO == 0) stream_next_stage(S);
+    w.hi = lds_read16<(FO + 0) * 1024>(S.cur);
+    w.lo = lds_read16<(FO + 1) * 1024>(S.cur);
+}
+
+// k-steps S_ .. KSOP-1 of one 16-row output tile, both voxel tiles.  `w` enters holding the pair of step S_
+// (already waited for) and leaves holding the first pair of whatever follows the tile.  The pair of step
+// S_+1 is requested before the six MFMAs of step S_ and waited for after them; the previous tile's epilogue
+// (prev: four pieces) is spread over the k-steps so that its VALU work issues between this tile's MFMAs.
+// (Recursive template: every LDS offset is an instruction immediate.)
+template <int KSOP, int F0, int FP, int BOFF, int S_, class Prev>
+__device__ __forceinline__ void tile_steps(Stream& S, uint32_t bias_lds, Frag& w, const Panel<KSOP>& in, Acc& acc,
+                                           const Prev& prev) {
     if constexpr (S_ < KSOP) {
-        if constexpr ((FO + 2 * S_) % kStageFrags == kStageFrags / 2) stream_sync(S);
-        u32x4 nhi = whi, nlo = wlo;
-        if constexpr (S_ + 1 < KSOP) {
-            nhi = lds_read16<(FO + 2 * S_ + 2) * 1024>(S.cur);
-            nlo = lds_read16<(FO + 2 * S_ + 3) * 1024>(S.cur);
-        }
-        const f16x8 h = __builtin_bit_cast(f16x8, whi), l = __builtin_bit_cast(f16x8, wlo);
+        if constexpr ((F0 + 2 * S_) % kStageFrags == kStageFrags / 2) stream_sync(S);
+        if constexpr (S_ == 0) acc.bias = lds_read16<BOFF * 4>(bias_lds);
+        Frag n;
+        frag_fetch<F0 + 2 * S_ + 2, FP>(S, n);
+        // the reads are in flight BEFORE this step's MFMAs and waited for AFTER them: nothing crosses either fence
+        __builtin_amdgcn_sched_barrier(0);
+        const f16x8 h = __builtin_bit_cast(f16x8, w.hi), l = __builtin_bit_cast(f16x8, w.lo);
         const f16x8 h0 = frag_hi(in, S_, 0), h1 = frag_hi(in, S_, 1), l0 = frag_lo(in, S_, 0), l1 = frag_lo(in, S_, 1);
-        out[0] = QB_MFMA_F16(h, h0, out[0]);
-        out[1] = QB_MFMA_F16(h, h1, out[1]);
-        cross[0] = QB_MFMA_F16(h, l0, cross[0]);
-        cross[1] = QB_MFMA_F16(h, l1, cross[1]);
-        cross[0] = QB_MFMA_F16(l, h0, cross[0]);
-        cross[1] = QB_MFMA_F16(l, h1, cross[1]);
-        if constexpr (S_ + 1 < KSOP) lds_wait(nhi, nlo);
-        tile_steps<KSOP, FO, S_ + 1>(S, nhi, nlo, in, out, cross);
+        acc.out[0] = QB_MFMA_F16(h, h0, acc.out[0]);
+        acc.out[1] = QB_MFMA_F16(h, h1, acc.out[1]);
+        acc.cross[0] = QB_MFMA_F16(h, l0, acc.cross[0]);
+        acc.cross[1] = QB_MFMA_F16(h, l1, acc.cross[1]);
+        acc.cross[0] = QB_MFMA_F16(l, h0, acc.cross[0]);
+        acc.cross[1] = QB_MFMA_F16(l, h1, acc.cross[1]);
+        if constexpr ((0 * KSOP) / 4 == S_) prev(IC<0>{});
+        if constexpr ((1 * KSOP) / 4 == S_) prev(IC<1>{});
+        if constexpr ((2 * KSOP) / 4 == S_) prev(IC<2>{});
+        if constexpr ((3 * KSOP) / 4 == S_) prev(IC<3>{});
+        // issue order inside the step: one MFMA, then a share of the epilogue's vector instructions (which
+        // issue while the matrix pipe works on it), six times over
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, QB_FUSED_VALU_PER_MFMA, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (S_ == 0) lds_wait3(n.hi, n.lo, acc.bias);
+        else lds_wait(n.hi, n.lo);
+        w = n;
+        tile_steps<KSOP, F0, FP, BOFF, S_ + 1>(S, bias_lds, w, in, acc, prev);
     }
 }
 
-// One output tile: y[vt][r] = (W in + bias)[16 m + 4 g + r] for voxel tile vt.  F0: fragment index within
-// the pass of the tile's first fragment (a tile never straddles a stage); BOFF: float offset of the tile's
-// bias rows in the LDS bias image.
-template <int KSOP, int F0, int BOFF>
-__device__ __forceinline__ void tile_mma(Stream& S, uint32_t bias_lds, const Panel<KSOP>& in, float (&y)[2][4]) {
-    constexpr int FO = F0 % kStageFrags;
-    static_assert(FO + 2 * KSOP <= kStageFrags, "a tile's fragments stay inside one stage");
+// One output tile into acc.  F0: fragment index within the pass of the tile's first fragment (a tile never
+// straddles a stage); BOFF: float offset of the tile's bias rows in the LDS bias image.
+template <int KSOP, int F0, int FP, int BOFF, class Prev>
+__device__ __forceinline__ void tile_mma(Stream& S, uint32_t bias_lds, Frag& w, const Panel<KSOP>& in, Acc& acc,
+                                         const Prev& prev) {
+    static_assert(F0 % kStageFrags + 2 * KSOP <= kStageFrags, "a tile's fragments stay inside one stage");
     static_assert(BOFF * 4 + 64 < 65536, "bias offset is a ds_read immediate");
     __builtin_amdgcn_sched_barrier(0);  // tiles are scheduled one at a time: three panels leave no slack
-    if constexpr (FO == 0 && F0 != 0) stream_next_stage(S);
-    u32x4 whi = lds_read16<(FO + 0) * 1024>(S.cur), wlo = lds_read16<(FO + 1) * 1024>(S.cur);
-    u32x4 braw = lds_read16<BOFF * 4>(bias_lds);
-    lds_wait3(whi, wlo, braw);
-    const float4 bi = __builtin_bit_cast(float4, braw);
-    f32x4 out[2], cross[2];
-    out[0] = out[1] = f32x4{bi.x, bi.y, bi.z, bi.w};
-    cross[0] = cross[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    tile_steps<KSOP, FO, 0>(S, whi, wlo, in, out, cross);
-#pragma unroll
-    for (int vt = 0; vt < 2; ++vt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y[vt][r] = fmaf(cross[vt][r], QB_LO_UNSCALE, out[vt][r]);
+    acc.out[0] = acc.out[1] = acc.cross[0] = acc.cross[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    tile_steps<KSOP, F0, FP, BOFF, 0>(S, bias_lds, w, in, acc, prev);
 }
 
-// tile M of a panel <-> float32 values (unit 16 M + 4 g + r sits in k-slot 4 (M & 1) + r of k-step M / 2)
-template <int M, int KS>
-__device__ __forceinline__ void put_tile(Panel<KS>& P, const float (&y)[2][4]) {
-#pragma unroll
-    for (int vt = 0; vt < 2; ++vt)
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const float a = y[vt][2 * d], b = y[vt][2 * d + 1];
-            const _Float16 ha = (_Float16)a, hb = (_Float16)b;
-            P.hi[M / 2][vt][2 * (M & 1) + d] = pack2(ha, hb);
-            P.lo[M / 2][vt][2 * (M & 1) + d] =
-                pack2((_Float16)((a - (float)ha) * QB_LO_SCALE), (_Float16)((b - (float)hb) * QB_LO_SCALE));
-        }
+// (W in + b)[16 M + 4 g + 2 d + e], e = 0, 1, of voxel tile vt: piece C = 2 vt + d of a finished tile
+template <int C>
+__device__ __forceinline__ void acc_pair(const Acc& a, float& y0, float& y1) {
+    constexpr int vt = C / 2, d = C % 2;
+    const float4 b4 = __builtin_bit_cast(float4, a.bias);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+    y0 = fmaf(a.cross[vt][2 * d], QB_LO_UNSCALE, a.out[vt][2 * d]) + bb[2 * d];
+    y1 = fmaf(a.cross[vt][2 * d + 1], QB_LO_UNSCALE, a.out[vt][2 * d + 1]) + bb[2 * d + 1];
 }
-template <int M, int KS>
-__device__ __forceinline__ void get_tile(const Panel<KS>& P, float (&y)[2][4]) {
-#pragma unroll
-    for (int vt = 0; vt < 2; ++vt)
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const qb::f16x2 h = __builtin_bit_cast(qb::f16x2, P.hi[M / 2][vt][2 * (M & 1) + d]);
-            const qb::f16x2 l = __builtin_bit_cast(qb::f16x2, P.lo[M / 2][vt][2 * (M & 1) + d]);
-            y[vt][2 * d] = fmaf((float)l[0], QB_LO_UNSCALE, (float)h[0]);
-            y[vt][2 * d + 1] = fmaf((float)l[1], QB_LO_UNSCALE, (float)h[1]);
-        }
+// k-slots 4 (M & 1) + 2 d, + 1 of k-step M / 2 hold units 16 M + 4 g + 2 d, + 1
+template <int M, int C, int KS>
+__device__ __forceinline__ void put_pair(Panel<KS>& P, float a, float b) {
+    constexpr int vt = C / 2, d = C % 2;
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    P.hi[M / 2][vt][2 * (M & 1) + d] = pack2(ha, hb);
+    P.lo[M / 2][vt][2 * (M & 1) + d] =
+        pack2((_Float16)((a - (float)ha) * QB_LO_SCALE), (_Float16)((b - (float)hb) * QB_LO_SCALE));
+}
+template <int M, int C, int KS>
+__device__ __forceinline__ void get_pair(const Panel<KS>& P, float& a, float& b) {
+    constexpr int vt = C / 2, d = C % 2;
+    const qb::f16x2 h = __builtin_bit_cast(qb::f16x2, P.hi[M / 2][vt][2 * (M & 1) + d]);
+    const qb::f16x2 l = __builtin_bit_cast(qb::f16x2, P.lo[M / 2][vt][2 * (M & 1) + d]);
+    a = fmaf((float)l[0], QB_LO_UNSCALE, (float)h[0]);
+    b = fmaf((float)l[1], QB_LO_UNSCALE, (float)h[1]);
 }
 
 // relu on a split panel, in place (the Activation in front of the first 3x3x1 convolution, model.py:151):
@@ -300,35 +330,43 @@ __device__ __forceinline__ void relu_panel(Panel<KS>& P) {
 
 enum { EPI_RELU = 0, EPI_LINEAR = 1, EPI_GATE = 2 };
 
-// A dense op: tiles M .. MT-1 of out = epi(W in + b).  EPI_GATE: out = skip (1 - g) + r g with
-// g = sigmoid(W in + b), `in` being r itself (model.py:164-170).
-template <int KS, int KSIN, int MT, int F0, int BOFF, int EPI, int M = 0>
-__device__ __forceinline__ void dense_op(Stream& S, uint32_t bias_lds, const Panel<KSIN>& in, Panel<KS>& out,
-                                         const Panel<KS>& skip, const Panel<KS>& rr) {
+// Piece C of tile M's epilogue.  EPI_GATE: out = skip (1 - g) + r g with g = sigmoid(W r + b) (model.py:164-170).
+template <int EPI, int M, int C, int KS>
+__device__ __forceinline__ void epi_pair(const Acc& a, Panel<KS>& out, const Panel<KS>& skip, const Panel<KS>& rr) {
+    float y0, y1;
+    acc_pair<C>(a, y0, y1);
+    if constexpr (EPI == EPI_RELU) {
+        y0 = fmaxf(y0, 0.0f);
+        y1 = fmaxf(y1, 0.0f);
+    }
+    if constexpr (EPI == EPI_GATE) {
+        float s0, s1, r0, r1;
+        get_pair<M, C>(skip, s0, s1);
+        get_pair<M, C>(rr, r0, r1);
+        const float g0 = qb::sigmoidf_(y0), g1 = qb::sigmoidf_(y1);  // model.py:169
+        y0 = s0 * (1.0f - g0) + r0 * g0;                               // model.py:170
+        y1 = s1 * (1.0f - g1) + r1 * g1;
+    }
+    put_pair<M, C>(out, y0, y1);
+}
+
+// A dense op: tiles M .. MT-1 of out = epi(W in + b).  Tile M-1's epilogue runs inside tile M's MFMA stream
+// (two accumulator sets in rotation); the last tile's runs after the op.
+template <int KS, int KSIN, int MT, int F0, int FP, int BOFF, int EPI, int M = 0>
+__device__ __forceinline__ void dense_op(Stream& S, uint32_t bias_lds, Frag& w, const Panel<KSIN>& in,
+                                         Panel<KS>& out, const Panel<KS>& skip, const Panel<KS>& rr, Acc (&acc)[2]) {
     if constexpr (M < MT) {
-        float y[2][4];
-        tile_mma<KSIN, F0 + M * 2 * KSIN, BOFF + 16 * M>(S, bias_lds, in, y);
-        if constexpr (EPI == EPI_RELU) {
-#pragma unroll
-            for (int vt = 0; vt < 2; ++vt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[vt][r] = fmaxf(y[vt][r], 0.0f);
-        }
-        if constexpr (EPI == EPI_GATE) {
-            float sk[2][4], r4[2][4];
-            get_tile<M>(skip, sk);
-            get_tile<M>(rr, r4);
-#pragma unroll
-            for (int vt = 0; vt < 2; ++vt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float gate = qb::sigmoidf_(y[vt][r]);               // model.py:169
-                    y[vt][r] = sk[vt][r] * (1.0f - gate) + r4[vt][r] * gate;  // model.py:170
-                }
-        }
-        put_tile<M>(out, y);
+        auto prev = [&](auto c) {
+            if constexpr (M > 0) epi_pair<EPI, (M > 0 ? M - 1 : 0), decltype(c)::value>(acc[(M + 1) & 1], out, skip, rr);
+        };
+        tile_mma<KSIN, F0 + M * 2 * KSIN, FP, BOFF + 16 * M>(S, bias_lds, w, in, acc[M & 1], prev);
+        dense_op<KS, KSIN, MT, F0, FP, BOFF, EPI, M + 1>(S, bias_lds, w, in, out, skip, rr, acc);
+    } else {
         __builtin_amdgcn_sched_barrier(0);
-        dense_op<KS, KSIN, MT, F0, BOFF, EPI, M + 1>(S, bias_lds, in, out, skip, rr);
+        epi_pair<EPI, MT - 1, 0>(acc[(MT - 1) & 1], out, skip, rr);
+        epi_pair<EPI, MT - 1, 1>(acc[(MT - 1) & 1], out, skip, rr);
+        epi_pair<EPI, MT - 1, 2>(acc[(MT - 1) & 1], out, skip, rr);
+        epi_pair<EPI, MT - 1, 3>(acc[(MT - 1) & 1], out, skip, rr);
     }
 }
 
@@ -342,54 +380,64 @@ struct FusedArgs {
     int T, se_idx, multi_norm;
 };
 
-// Heads: tiles 0 .. TT-1 are log-sigma rows 16 M + 4 g + r, tile TT holds the five q rows.
-template <int KS, int TT, int F0, int BOFF, int M = 0>
-__device__ __forceinline__ void head_op(Stream& S, uint32_t bias_lds, const Panel<KS>& b, const FusedArgs& a,
-                                        const int64_t (&v)[2], int g) {
-    if constexpr (M <= TT) {
-        float y[2][4];
-        tile_mma<KS, F0 + M * 2 * KS, BOFF + 16 * M>(S, bias_lds, b, y);
-#pragma unroll
-        for (int vt = 0; vt < 2; ++vt) {
-            if (v[vt] < a.N) {
-                if constexpr (M < TT) {
-                    const int row = 16 * M + 4 * g;
-                    float* dst = a.ls + v[vt] * a.T + row;
-                    if ((a.T & 3) == 0 && row + 3 < a.T) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(y[vt][0], y[vt][1], y[vt][2], y[vt][3]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (row + r < a.T) dst[r] = y[vt][r];
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (4 * g + r < 5) a.q[v[vt] * 5 + 4 * g + r] = y[vt][r];
-                }
-            }
+// Piece C of head tile M: tiles 0 .. TT-1 are log-sigma rows 16 M + 4 g + r, tile TT holds the five q rows.
+template <int TT, int M, int C>
+__device__ __forceinline__ void head_pair(const Acc& acc, const FusedArgs& a, const int64_t (&v)[2], int g) {
+    constexpr int vt = C / 2, d = C % 2;
+    float y0, y1;
+    acc_pair<C>(acc, y0, y1);
+    if (v[vt] >= a.N) return;
+    if constexpr (M < TT) {
+        const int row = 16 * M + 4 * g + 2 * d;
+        float* dst = a.ls + v[vt] * a.T + row;
+        if ((a.T & 1) == 0 && row + 1 < a.T) {
+            *reinterpret_cast<float2*>(dst) = make_float2(y0, y1);
+        } else {
+            if (row < a.T) dst[0] = y0;
+            if (row + 1 < a.T) dst[1] = y1;
         }
-        head_op<KS, TT, F0, BOFF, M + 1>(S, bias_lds, b, a, v, g);
+    } else {
+        const int row = 4 * g + 2 * d;
+        if (row < 5) a.q[v[vt] * 5 + row] = y0;
+        if (row + 1 < 5) a.q[v[vt] * 5 + row + 1] = y1;
+    }
+}
+template <int KS, int TT, int F0, int FP, int BOFF, int M = 0>
+__device__ __forceinline__ void head_op(Stream& S, uint32_t bias_lds, Frag& w, const Panel<KS>& b, const FusedArgs& a,
+                                        const int64_t (&v)[2], int g, Acc (&acc)[2]) {
+    if constexpr (M <= TT) {
+        auto prev = [&](auto c) {
+            if constexpr (M > 0) head_pair<TT, (M > 0 ? M - 1 : 0), decltype(c)::value>(acc[(M + 1) & 1], a, v, g);
+        };
+        tile_mma<KS, F0 + M * 2 * KS, FP, BOFF + 16 * M>(S, bias_lds, w, b, acc[M & 1], prev);
+        head_op<KS, TT, F0, FP, BOFF, M + 1>(S, bias_lds, w, b, a, v, g, acc);
+    } else {
+        __builtin_amdgcn_sched_barrier(0);
+        head_pair<TT, TT, 0>(acc[TT & 1], a, v, g);
+        head_pair<TT, TT, 1>(acc[TT & 1], a, v, g);
+        head_pair<TT, TT, 2>(acc[TT & 1], a, v, g);
+        head_pair<TT, TT, 3>(acc[TT & 1], a, v, g);
     }
 }
 
 // Gated residual blocks LB .. L-1 (model.py:147-172): b comes in P0 and leaves in P1; the panels rotate by
 // name from block to block, nothing is copied.
-template <int KS, int MT, int L, int TT, int FB0, int LB>
-__device__ __forceinline__ void blocks_and_head(Stream& S, uint32_t bias_lds, Panel<KS>& P0, Panel<KS>& P1,
-                                                Panel<KS>& P2, const FusedArgs& a, const int64_t (&v)[2], int g) {
+template <int KS, int MT, int L, int TT, int FB0, int FP, int LB>
+__device__ __forceinline__ void blocks_and_head(Stream& S, uint32_t bias_lds, Frag& w, Panel<KS>& P0, Panel<KS>& P1,
+                                                Panel<KS>& P2, const FusedArgs& a, const int64_t (&v)[2], int g,
+                                                Acc (&acc)[2]) {
     constexpr int FOP = MT * KS * 2;  // fragments per dense op
     constexpr int U = 16 * MT;
     if constexpr (LB < L) {
         constexpr int F = FB0 + LB * 4 * FOP, B = U + LB * 4 * U;
-        dense_op<KS, KS, MT, F, B, EPI_RELU>(S, bias_lds, P0, P2, P2, P2);                // skip, :148
-        if constexpr (LB > 0) relu_panel(P0);  // block 0's input is a relu output already             :151
-        dense_op<KS, KS, MT, F + FOP, B + U, EPI_RELU>(S, bias_lds, P0, P1, P1, P1);       // t, :152-155
-        dense_op<KS, KS, MT, F + 2 * FOP, B + 2 * U, EPI_LINEAR>(S, bias_lds, P1, P0, P0, P0);  // r, :156
-        dense_op<KS, KS, MT, F + 3 * FOP, B + 3 * U, EPI_GATE>(S, bias_lds, P0, P1, P2, P0);    // :164-170
-        blocks_and_head<KS, MT, L, TT, FB0, LB + 1>(S, bias_lds, P1, P0, P2, a, v, g);
+        dense_op<KS, KS, MT, F, FP, B, EPI_RELU>(S, bias_lds, w, P0, P2, P2, P2, acc);                 // skip, :148
+        if constexpr (LB > 0) relu_panel(P0);  // block 0's input is a relu output already                :151
+        dense_op<KS, KS, MT, F + FOP, FP, B + U, EPI_RELU>(S, bias_lds, w, P0, P1, P1, P1, acc);        // t, :152-155
+        dense_op<KS, KS, MT, F + 2 * FOP, FP, B + 2 * U, EPI_LINEAR>(S, bias_lds, w, P1, P0, P0, P0, acc);  // r, :156
+        dense_op<KS, KS, MT, F + 3 * FOP, FP, B + 3 * U, EPI_GATE>(S, bias_lds, w, P0, P1, P2, P0, acc);    // :164-170
+        blocks_and_head<KS, MT, L, TT, FB0, FP, LB + 1>(S, bias_lds, w, P1, P0, P2, a, v, g, acc);
     } else {
-        head_op<KS, TT, FB0 + L * 4 * FOP, U + L * 4 * U>(S, bias_lds, P0, a, v, g);
+        head_op<KS, TT, FB0 + L * 4 * FOP, FP, U + L * 4 * U>(S, bias_lds, w, P0, a, v, g, acc);
     }
 }
 
@@ -397,6 +445,8 @@ template <int TT, int L>
 __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
     constexpr int U = 256, KS = U / 32, MT = U / 16, KS1 = (TT + 1) / 2;
     constexpr FusedLayout fl = make_fused_layout(16 * TT, U, L);  // T only pads inside its 16-row tile
+    constexpr int FP = fl.frags_pass;
+    static_assert(FP % kStageFrags == 0, "a pass is a whole number of stages");
     extern __shared__ __align__(16) uint4 smem[];
     uint4* ring = smem;                                                      // [kRing][16][64]
     float* lbias = reinterpret_cast<float*>(smem + kRing * kStageFrags * 64);  // [bias_total]
@@ -420,15 +470,13 @@ __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
     for (int k = 0; k < kAhead; ++k) stream_issue(S);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kAhead - 1)) : "memory");  // stage 0 has landed (my quarter)
     __syncthreads();                                                          // ... everyone's; the biases too
+    Frag w;
+    w.hi = lds_read16<0>(S.cur);
+    w.lo = lds_read16<1024>(S.cur);
+    lds_wait(w.hi, w.lo);
 
     const int64_t nblk = (a.N + kVoxPerPass - 1) / kVoxPerPass;
-    bool first_pass = true;
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        if (!first_pass) {
-            // the stream wrapped: the next pass's first stage follows the head's last one in the ring
-            stream_next_stage(S);
-        }
-        first_pass = false;
         int64_t v[2];
         Panel<KS1> X;
 #pragma unroll
@@ -469,8 +517,9 @@ __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
             }
         }
         Panel<KS> P0, P1, P2;
-        dense_op<KS, KS1, MT, 0, 0, EPI_RELU>(S, bias_lds, X, P0, P0, P0);  // first layer, model.py:181
-        blocks_and_head<KS, MT, L, TT, MT * KS1 * 2, 0>(S, bias_lds, P0, P1, P2, a, v, g);
+        Acc acc[2];
+        dense_op<KS, KS1, MT, 0, FP, 0, EPI_RELU>(S, bias_lds, w, X, P0, P0, P0, acc);  // first layer, model.py:181
+        blocks_and_head<KS, MT, L, TT, MT * KS1 * 2, FP, 0>(S, bias_lds, w, P0, P1, P2, a, v, g, acc);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-direct load may land after the block has gone
 }
