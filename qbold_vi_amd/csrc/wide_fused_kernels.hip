@@ -19,8 +19,12 @@
 // f16 halves hi / lo of every value, 8 k-steps x 2 voxel tiles x (4 + 4) VGPRs = 128 VGPRs -- and a gated
 // block needs three panels (b / relu b, skip, t -> r), 384 VGPRs, plus one output tile's accumulators.
 // The loop nest is output tile outermost: the B operands of all k-steps are register-resident, so a tile's
-// accumulators (out + cross, 16 VGPRs) live for 48 MFMAs only and its result goes straight into the next
-// panel (bias, activation, split) -- same arithmetic as wide_dense_kernel (hi.hi + 2^-11 (hi.lo + lo.hi)).
+// accumulators live for 48 MFMAs only and its result goes straight into the next panel (bias, activation,
+// split).  Arithmetic: x = hi + lo with hi = f16(x), lo = f16(x - hi) UNSCALED, so that all three products
+// (hi.hi, hi.lo, lo.hi) add into ONE accumulator per voxel tile and the epilogue has nothing to combine;
+// weights are pre-multiplied per dense op by a power of two that puts max |w| in [2^12, 2^13) (their lo halves
+// stay normal f16 numbers down to |w| = 2^-15 max |w|), undone for free in the epilogue's y = acc 2^-e + bias.
+// An activation's lo half is a normal number for |x| >= 2^-3 and carries an absolute error <= 2^-25 below.
 //
 // Weights.  All dense ops of one pass over 128 voxels form one flat stream of 1 KiB MFMA fragments in
 // consumption order ([op][out tile][k-step][hi, lo]; 2.2 MB for config 3, L2-resident).  Stages of 16
@@ -43,11 +47,11 @@ namespace {
 using namespace qbw;
 
 #ifndef QB_FUSED_VALU_PER_MFMA
-#define QB_FUSED_VALU_PER_MFMA 8
+#define QB_FUSED_VALU_PER_MFMA 3
 #endif
 constexpr int kFB = 256;          // threads per block: one wave per SIMD
-constexpr int kRing = 4;          // LDS ring slots of 16 fragments
-constexpr int kAhead = 3;         // stages in flight beyond the one being read
+constexpr int kRing = 8;          // LDS ring slots of 16 fragments (128 KiB)
+constexpr int kAhead = 7;         // stages requested beyond the one being read
 constexpr int kStageFrags = 16;   // 1 KiB fragments per stage
 constexpr int kVoxPerPass = 128;  // 4 waves x 32 voxels
 
@@ -57,7 +61,8 @@ struct FusedLayout {
     int KS1, KS, MT, TT, HT;  // first-layer k-steps, body k-steps, body tiles, log-sigma tiles, head tiles
     int frags_first, frags_op, frags_head, frags_pass, stages_pass;
     int bias_first, bias_blk0, bias_head, bias_total;  // float offsets inside the bias image
-    int64_t img_floats, total_floats;                   // weight fragments, + biases
+    int scale_off, n_ops, aux_floats;                   // per-op (2^e, 2^-e) pairs behind the biases
+    int64_t img_floats, total_floats;                   // weight fragments, + biases and scales
 };
 __host__ __device__ constexpr inline FusedLayout make_fused_layout(int T, int U, int L) {
     FusedLayout f{};
@@ -76,8 +81,11 @@ __host__ __device__ constexpr inline FusedLayout make_fused_layout(int T, int U,
     f.bias_blk0 = U;
     f.bias_head = U + 4 * L * U;
     f.bias_total = f.bias_head + 16 * f.HT;
+    f.scale_off = (f.bias_total + 3) & ~3;
+    f.n_ops = 2 + 4 * L;  // first layer, four per block, heads
+    f.aux_floats = (f.scale_off + 2 * f.n_ops + 3) & ~3;
     f.img_floats = (int64_t)f.stages_pass * kStageFrags * 256;
-    f.total_floats = f.img_floats + ((f.bias_total + 3) & ~3);
+    f.total_floats = f.img_floats + f.aux_floats;
     return f;
 }
 inline bool fused_supported(const qbold_encoder_shape* s) {
@@ -87,15 +95,41 @@ inline bool fused_supported(const qbold_encoder_shape* s) {
            s->channelwise_gating && s->precision == QBOLD_ENC_F32;
 }
 
+// Power-of-two scale of one dense op: 2^e with max |w| 2^e in [2^12, 2^13); (2^e, 2^-e) -> scale[0..1].
+__global__ void fused_scale_kernel(const float* __restrict__ W, int64_t n, const float* __restrict__ W2, int64_t n2,
+                                   float* __restrict__ scale) {
+    __shared__ float red[256];
+    float m = 0.0f;
+    for (int64_t k = threadIdx.x; k < n; k += 256) m = fmaxf(m, fabsf(W[k]));
+    for (int64_t k = threadIdx.x; k < n2; k += 256) m = fmaxf(m, fabsf(W2[k]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mx = red[0];
+        int e = 0;
+        if (mx > 0.0f && mx < 3.0e38f) e = 12 - ilogbf(mx);
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        scale[0] = ldexpf(1.0f, e);
+        scale[1] = ldexpf(1.0f, -e);
+    }
+}
+
 // One dense op into the fused image.  korder 0: in = 32 s + 8 g + j (first layer: rows of x); 1: the
 // accumulator order unit(s, g, j) = 16 (2 s + (j >> 2)) + 4 g + (j & 3) of encoder_core.h.  Head (W2 != null):
-// output row < 16 TT -> log-sigma row of W (Ws), else q row (row - 16 TT) of W2 (Wf).
+// output row < 16 TT -> log-sigma row of W (Ws), else q row (row - 16 TT) of W2 (Wf).  Weights are stored
+// times scale[0] as hi = f16(w'), lo = f16(w' - hi); biases unscaled.
 __global__ void fused_pack_kernel(int frag0, int KS, int MT, int korder, const float* __restrict__ W,
                                   const float* __restrict__ b, int nin, int nout, const float* __restrict__ W2,
                                   const float* __restrict__ b2, int nout2, int split_row, float bias_add,
-                                  int bias_off, int64_t img_floats, float* __restrict__ packed) {
+                                  int bias_off, const float* __restrict__ scale, int64_t img_floats,
+                                  float* __restrict__ packed) {
     _Float16* ph = reinterpret_cast<_Float16*>(packed) + (int64_t)frag0 * 512;
     const int64_t halves = (int64_t)MT * KS * 2 * 512;
+    const float sc = scale[0];
     for (int64_t h = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; h < halves + 16 * MT;
          h += (int64_t)gridDim.x * blockDim.x) {
         if (h >= halves) {  // bias rows in the same (possibly remapped) order
@@ -125,8 +159,9 @@ __global__ void fused_pack_kernel(int frag0, int KS, int MT, int korder, const f
                 w = W[(int64_t)in * nout + out];
             }
         }
+        w *= sc;  // exact: a power of two
         const _Float16 hi = (_Float16)w;
-        ph[h] = part == 0 ? hi : (_Float16)((w - (float)hi) * QB_LO_SCALE);
+        ph[h] = part == 0 ? hi : (_Float16)(w - (float)hi);
     }
 }
 
@@ -194,7 +229,9 @@ __device__ __forceinline__ void stream_issue(Stream& S) {
 // are done), everyone has left the previous stage, whose slot the new issue overwrites.
 __device__ __forceinline__ void stream_sync(Stream& S) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kAhead - 2)) : "memory");
+#ifndef QB_FUSED_X_NOBARRIER  // timing experiments only (scripts/dev/fused_variants.sh): results are invalid
     __builtin_amdgcn_s_barrier();
+#endif
     stream_issue(S);
 }
 __device__ __forceinline__ void stream_next_stage(Stream& S) {
@@ -202,25 +239,33 @@ __device__ __forceinline__ void stream_next_stage(Stream& S) {
     S.cur = S.ring_lds + (uint32_t)S.read_slot * (kStageFrags * 1024);
 }
 
-__device__ __forceinline__ void lds_wait3(u32x4& a, u32x4& b, u32x4& c) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
-}
-
 struct Frag {   // one (hi, lo) fragment pair of the weight stream
     u32x4 hi, lo;
 };
-struct Acc {    // a finished (or running) output tile: both voxel tiles' accumulators and the tile's bias rows
-    f32x4 out[2], cross[2];
+struct Acc {    // a finished (or running) output tile: one accumulator per voxel tile and the tile's bias rows
+    f32x4 o[2];
     u32x4 bias;
 };
 template <int V>
 struct IC {
     static constexpr int value = V;
 };
+// all LDS reads but the two youngest (the pair requested last) have returned
+#ifdef QB_FUSED_X_NOLDSWAIT  // timing experiments only: results are invalid
+#define QB_FUSED_WAIT_BUT2 ""
+#else
+#define QB_FUSED_WAIT_BUT2 "s_waitcnt lgkmcnt(2)"
+#endif
+__device__ __forceinline__ void lds_wait_but2(u32x4& a, u32x4& b) {
+    asm volatile(QB_FUSED_WAIT_BUT2 : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lds_wait_but2(u32x4& a, u32x4& b, u32x4& c) {
+    asm volatile(QB_FUSED_WAIT_BUT2 : "+v"(a), "+v"(b), "+v"(c));
+}
 
-// Request the fragment pair that starts at fragment F of the pass; F == FP is the first pair of the NEXT pass
-// (same weights: the stream wraps).  By the end of a stage the next one has landed (mid-stage handshake), so
-// the read-ahead never stalls at a tile, stage or pass boundary.
+// Request the fragment pair that starts at fragment F of the pass; F >= FP: a pair of the NEXT pass (same
+// weights: the stream wraps).  By the last quarter of a stage the next one has landed (mid-stage handshake),
+// so the read-ahead never stalls at a tile, stage or pass boundary.
 template <int F, int FP>
 __device__ __forceinline__ void frag_fetch(Stream& S, Frag& w) {
     constexpr int FO = (F % FP) % kStageFrags;
@@ -229,33 +274,40 @@ __device__ __forceinline__ void frag_fetch(Stream& S, Frag& w) {
     w.lo = lds_read16<(FO + 1) * 1024>(S.cur);
 }
 
-// k-steps S_ .. KSOP-1 of one 16-row output tile, both voxel tiles.  `w` enters holding the pair of step S_
-// (already waited for) and leaves holding the first pair of whatever follows the tile.  The pair of step
-// S_+1 is requested before the six MFMAs of step S_ and waited for after them; the previous tile's epilogue
-// (prev: four pieces) is spread over the k-steps so that its VALU work issues between this tile's MFMAs.
-// (Recursive template: every LDS offset is an instruction immediate.)
+// k-steps S_ .. KSOP-1 of one 16-row output tile, both voxel tiles.  wa holds the pair of step S_ (returned),
+// wb the pair of step S_+1 (requested); the pair of step S_+2 is requested before the six MFMAs of step S_,
+// and after them the wait leaves only that youngest pair outstanding.  The previous tile's epilogue (prev:
+// eight pieces, one per output value of a lane) is spread over the k-steps so that its vector instructions
+// issue between this tile's MFMAs, two or three per MFMA.
+// oa / ob: the two pairs that follow the tile.  (Recursive template: every LDS offset is an immediate.)
 template <int KSOP, int F0, int FP, int BOFF, int S_, class Prev>
-__device__ __forceinline__ void tile_steps(Stream& S, uint32_t bias_lds, Frag& w, const Panel<KSOP>& in, Acc& acc,
-                                           const Prev& prev) {
+__device__ __forceinline__ void tile_steps(Stream& S, uint32_t bias_lds, Frag wa, Frag wb, Frag& oa, Frag& ob,
+                                           const Panel<KSOP>& in, Acc& acc, const Prev& prev) {
     if constexpr (S_ < KSOP) {
         if constexpr ((F0 + 2 * S_) % kStageFrags == kStageFrags / 2) stream_sync(S);
         if constexpr (S_ == 0) acc.bias = lds_read16<BOFF * 4>(bias_lds);
         Frag n;
-        frag_fetch<F0 + 2 * S_ + 2, FP>(S, n);
+        frag_fetch<F0 + 2 * S_ + 4, FP>(S, n);
         // the reads are in flight BEFORE this step's MFMAs and waited for AFTER them: nothing crosses either fence
         __builtin_amdgcn_sched_barrier(0);
-        const f16x8 h = __builtin_bit_cast(f16x8, w.hi), l = __builtin_bit_cast(f16x8, w.lo);
+        const f16x8 h = __builtin_bit_cast(f16x8, wa.hi), l = __builtin_bit_cast(f16x8, wa.lo);
         const f16x8 h0 = frag_hi(in, S_, 0), h1 = frag_hi(in, S_, 1), l0 = frag_lo(in, S_, 0), l1 = frag_lo(in, S_, 1);
-        acc.out[0] = QB_MFMA_F16(h, h0, acc.out[0]);
-        acc.out[1] = QB_MFMA_F16(h, h1, acc.out[1]);
-        acc.cross[0] = QB_MFMA_F16(h, l0, acc.cross[0]);
-        acc.cross[1] = QB_MFMA_F16(h, l1, acc.cross[1]);
-        acc.cross[0] = QB_MFMA_F16(l, h0, acc.cross[0]);
-        acc.cross[1] = QB_MFMA_F16(l, h1, acc.cross[1]);
-        if constexpr ((0 * KSOP) / 4 == S_) prev(IC<0>{});
-        if constexpr ((1 * KSOP) / 4 == S_) prev(IC<1>{});
-        if constexpr ((2 * KSOP) / 4 == S_) prev(IC<2>{});
-        if constexpr ((3 * KSOP) / 4 == S_) prev(IC<3>{});
+        acc.o[0] = QB_MFMA_F16(h, h0, acc.o[0]);
+        acc.o[1] = QB_MFMA_F16(h, h1, acc.o[1]);
+        acc.o[0] = QB_MFMA_F16(h, l0, acc.o[0]);
+        acc.o[1] = QB_MFMA_F16(h, l1, acc.o[1]);
+        acc.o[0] = QB_MFMA_F16(l, h0, acc.o[0]);
+        acc.o[1] = QB_MFMA_F16(l, h1, acc.o[1]);
+#ifndef QB_FUSED_X_NOEPI
+        if constexpr ((0 * KSOP) / 8 == S_) prev(IC<0>{});
+        if constexpr ((1 * KSOP) / 8 == S_) prev(IC<1>{});
+        if constexpr ((2 * KSOP) / 8 == S_) prev(IC<2>{});
+        if constexpr ((3 * KSOP) / 8 == S_) prev(IC<3>{});
+        if constexpr ((4 * KSOP) / 8 == S_) prev(IC<4>{});
+        if constexpr ((5 * KSOP) / 8 == S_) prev(IC<5>{});
+        if constexpr ((6 * KSOP) / 8 == S_) prev(IC<6>{});
+        if constexpr ((7 * KSOP) / 8 == S_) prev(IC<7>{});
+#endif
         // issue order inside the step: one MFMA, then a share of the epilogue's vector instructions (which
         // issue while the matrix pipe works on it), six times over
 #pragma unroll
@@ -264,50 +316,61 @@ __device__ __forceinline__ void tile_steps(Stream& S, uint32_t bias_lds, Frag& w
             __builtin_amdgcn_sched_group_barrier(0x002, QB_FUSED_VALU_PER_MFMA, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (S_ == 0) lds_wait3(n.hi, n.lo, acc.bias);
-        else lds_wait(n.hi, n.lo);
-        w = n;
-        tile_steps<KSOP, F0, FP, BOFF, S_ + 1>(S, bias_lds, w, in, acc, prev);
+        if constexpr (S_ == 0) lds_wait_but2(wb.hi, wb.lo, acc.bias);
+        else lds_wait_but2(wb.hi, wb.lo);
+        tile_steps<KSOP, F0, FP, BOFF, S_ + 1>(S, bias_lds, wb, n, oa, ob, in, acc, prev);
+    } else {
+        oa = wa;
+        ob = wb;
     }
 }
 
 // One output tile into acc.  F0: fragment index within the pass of the tile's first fragment (a tile never
-// straddles a stage); BOFF: float offset of the tile's bias rows in the LDS bias image.
+// straddles a stage); BOFF: float offset of the tile's bias rows in the LDS bias image.  wa / wb: in, the
+// tile's first two pairs; out, the two pairs that follow it.
 template <int KSOP, int F0, int FP, int BOFF, class Prev>
-__device__ __forceinline__ void tile_mma(Stream& S, uint32_t bias_lds, Frag& w, const Panel<KSOP>& in, Acc& acc,
-                                         const Prev& prev) {
+__device__ __forceinline__ void tile_mma(Stream& S, uint32_t bias_lds, Frag& wa, Frag& wb, const Panel<KSOP>& in,
+                                         Acc& acc, const Prev& prev) {
     static_assert(F0 % kStageFrags + 2 * KSOP <= kStageFrags, "a tile's fragments stay inside one stage");
     static_assert(BOFF * 4 + 64 < 65536, "bias offset is a ds_read immediate");
     __builtin_amdgcn_sched_barrier(0);  // tiles are scheduled one at a time: three panels leave no slack
-    acc.out[0] = acc.out[1] = acc.cross[0] = acc.cross[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    tile_steps<KSOP, F0, FP, BOFF, 0>(S, bias_lds, w, in, acc, prev);
+    acc.o[0] = acc.o[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    tile_steps<KSOP, F0, FP, BOFF, 0>(S, bias_lds, wa, wb, wa, wb, in, acc, prev);
 }
 
-// (W in + b)[16 M + 4 g + 2 d + e], e = 0, 1, of voxel tile vt: piece C = 2 vt + d of a finished tile
-template <int C>
-__device__ __forceinline__ void acc_pair(const Acc& a, float& y0, float& y1) {
-    constexpr int vt = C / 2, d = C % 2;
+// (W in + b)[16 M + 4 g + r] of voxel tile vt: piece E = 4 vt + r of a finished tile.  inv_scale undoes the
+// dense op's power-of-two weight scale.
+template <int E>
+__device__ __forceinline__ float acc_elem(const Acc& a, float inv_scale) {
+    constexpr int vt = E / 4, r = E % 4;
     const float4 b4 = __builtin_bit_cast(float4, a.bias);
     const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-    y0 = fmaf(a.cross[vt][2 * d], QB_LO_UNSCALE, a.out[vt][2 * d]) + bb[2 * d];
-    y1 = fmaf(a.cross[vt][2 * d + 1], QB_LO_UNSCALE, a.out[vt][2 * d + 1]) + bb[2 * d + 1];
+    return fmaf(a.o[vt][r], inv_scale, bb[r]);
 }
-// k-slots 4 (M & 1) + 2 d, + 1 of k-step M / 2 hold units 16 M + 4 g + 2 d, + 1
+// x = hi + lo, hi = f16(x), lo = f16(x - hi): the packed hi pair is converted once and its halves are read
+// back for the residual (x - hi is exact in float32)
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = pack2((_Float16)a, (_Float16)b);
+    const qb::f16x2 h = __builtin_bit_cast(qb::f16x2, hi);
+    lo = pack2((_Float16)__builtin_fmaf((float)h[0], -1.0f, a), (_Float16)__builtin_fmaf((float)h[1], -1.0f, b));
+}
+// k-slots 4 (M & 1) + 2 d, + 1 of k-step M / 2 hold units 16 M + 4 g + 2 d, + 1 (C = 2 vt + d)
 template <int M, int C, int KS>
 __device__ __forceinline__ void put_pair(Panel<KS>& P, float a, float b) {
     constexpr int vt = C / 2, d = C % 2;
-    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
-    P.hi[M / 2][vt][2 * (M & 1) + d] = pack2(ha, hb);
-    P.lo[M / 2][vt][2 * (M & 1) + d] =
-        pack2((_Float16)((a - (float)ha) * QB_LO_SCALE), (_Float16)((b - (float)hb) * QB_LO_SCALE));
+    split_pair(a, b, P.hi[M / 2][vt][2 * (M & 1) + d], P.lo[M / 2][vt][2 * (M & 1) + d]);
 }
-template <int M, int C, int KS>
-__device__ __forceinline__ void get_pair(const Panel<KS>& P, float& a, float& b) {
-    constexpr int vt = C / 2, d = C % 2;
-    const qb::f16x2 h = __builtin_bit_cast(qb::f16x2, P.hi[M / 2][vt][2 * (M & 1) + d]);
-    const qb::f16x2 l = __builtin_bit_cast(qb::f16x2, P.lo[M / 2][vt][2 * (M & 1) + d]);
-    a = fmaf((float)l[0], QB_LO_UNSCALE, (float)h[0]);
-    b = fmaf((float)l[1], QB_LO_UNSCALE, (float)h[1]);
+// value E = 4 vt + r of tile M, read back from a panel
+template <int M, int E, int KS>
+__device__ __forceinline__ float get_elem(const Panel<KS>& P) {
+    constexpr int vt = E / 4, d = (E % 4) / 2, e = E % 2;
+    // laundered: otherwise the float32 values of the hi halves computed when the panel was written (split_pair)
+    // are kept alive from that op to this one -- a second, spilled copy of the panel
+    uint32_t dh = P.hi[M / 2][vt][2 * (M & 1) + d], dl = P.lo[M / 2][vt][2 * (M & 1) + d];
+    asm volatile("" : "+v"(dh), "+v"(dl));
+    const qb::f16x2 h = __builtin_bit_cast(qb::f16x2, dh);
+    const qb::f16x2 l = __builtin_bit_cast(qb::f16x2, dl);
+    return __builtin_fmaf((float)l[e], 1.0f, (float)h[e]);
 }
 
 // relu on a split panel, in place (the Activation in front of the first 3x3x1 convolution, model.py:151):
@@ -330,43 +393,55 @@ __device__ __forceinline__ void relu_panel(Panel<KS>& P) {
 
 enum { EPI_RELU = 0, EPI_LINEAR = 1, EPI_GATE = 2 };
 
-// Piece C of tile M's epilogue.  EPI_GATE: out = skip (1 - g) + r g with g = sigmoid(W r + b) (model.py:164-170).
-template <int EPI, int M, int C, int KS>
-__device__ __forceinline__ void epi_pair(const Acc& a, Panel<KS>& out, const Panel<KS>& skip, const Panel<KS>& rr) {
-    float y0, y1;
-    acc_pair<C>(a, y0, y1);
-    if constexpr (EPI == EPI_RELU) {
-        y0 = fmaxf(y0, 0.0f);
-        y1 = fmaxf(y1, 0.0f);
-    }
+// Piece E (= 4 vt + r) of tile M's epilogue; the even piece of a pair parks its value in `carry`, the odd one
+// splits and stores the pair.  EPI_GATE: out = skip (1 - g) + r g with g = sigmoid(W r + b) (model.py:164-170).
+template <int EPI, int M, int E, int KS>
+__device__ __forceinline__ void epi_elem(const Acc& a, float inv_scale, Panel<KS>& out, const Panel<KS>& skip,
+                                         const Panel<KS>& rr, float& carry) {
+    float y = acc_elem<E>(a, inv_scale);
+    if constexpr (EPI == EPI_RELU) y = fmaxf(y, 0.0f);
     if constexpr (EPI == EPI_GATE) {
-        float s0, s1, r0, r1;
-        get_pair<M, C>(skip, s0, s1);
-        get_pair<M, C>(rr, r0, r1);
-        const float g0 = qb::sigmoidf_(y0), g1 = qb::sigmoidf_(y1);  // model.py:169
-        y0 = s0 * (1.0f - g0) + r0 * g0;                               // model.py:170
-        y1 = s1 * (1.0f - g1) + r1 * g1;
+        const float sk = get_elem<M, E>(skip), r = get_elem<M, E>(rr);
+        const float gate = qb::sigmoidf_(y);  // model.py:169
+        y = fmaf(gate, r - sk, sk);           // skip (1 - g) + r g, model.py:170
     }
-    put_pair<M, C>(out, y0, y1);
+    if constexpr (E % 2 == 0) carry = y;
+    else put_pair<M, E / 2>(out, carry, y);
+}
+
+// the dense op's 2^-e (LDS aux image, float index IDX): wave-uniform
+template <int IDX>
+__device__ __forceinline__ float op_inv_scale(uint32_t aux_lds) {
+    uint32_t r;
+    asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(aux_lds), "n"(IDX * 4));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(r));
 }
 
 // A dense op: tiles M .. MT-1 of out = epi(W in + b).  Tile M-1's epilogue runs inside tile M's MFMA stream
 // (two accumulator sets in rotation); the last tile's runs after the op.
 template <int KS, int KSIN, int MT, int F0, int FP, int BOFF, int EPI, int M = 0>
-__device__ __forceinline__ void dense_op(Stream& S, uint32_t bias_lds, Frag& w, const Panel<KSIN>& in,
-                                         Panel<KS>& out, const Panel<KS>& skip, const Panel<KS>& rr, Acc (&acc)[2]) {
+__device__ __forceinline__ void dense_op(Stream& S, uint32_t bias_lds, float inv_scale, Frag& wa, Frag& wb,
+                                         const Panel<KSIN>& in, Panel<KS>& out, const Panel<KS>& skip,
+                                         const Panel<KS>& rr, Acc (&acc)[2]) {
     if constexpr (M < MT) {
+        float carry = 0.0f;
         auto prev = [&](auto c) {
-            if constexpr (M > 0) epi_pair<EPI, (M > 0 ? M - 1 : 0), decltype(c)::value>(acc[(M + 1) & 1], out, skip, rr);
+            if constexpr (M > 0)
+                epi_elem<EPI, (M > 0 ? M - 1 : 0), decltype(c)::value>(acc[(M + 1) & 1], inv_scale, out, skip, rr, carry);
         };
-        tile_mma<KSIN, F0 + M * 2 * KSIN, FP, BOFF + 16 * M>(S, bias_lds, w, in, acc[M & 1], prev);
-        dense_op<KS, KSIN, MT, F0, FP, BOFF, EPI, M + 1>(S, bias_lds, w, in, out, skip, rr, acc);
+        tile_mma<KSIN, F0 + M * 2 * KSIN, FP, BOFF + 16 * M>(S, bias_lds, wa, wb, in, acc[M & 1], prev);
+        dense_op<KS, KSIN, MT, F0, FP, BOFF, EPI, M + 1>(S, bias_lds, inv_scale, wa, wb, in, out, skip, rr, acc);
     } else {
         __builtin_amdgcn_sched_barrier(0);
-        epi_pair<EPI, MT - 1, 0>(acc[(MT - 1) & 1], out, skip, rr);
-        epi_pair<EPI, MT - 1, 1>(acc[(MT - 1) & 1], out, skip, rr);
-        epi_pair<EPI, MT - 1, 2>(acc[(MT - 1) & 1], out, skip, rr);
-        epi_pair<EPI, MT - 1, 3>(acc[(MT - 1) & 1], out, skip, rr);
+        float carry = 0.0f;
+        epi_elem<EPI, MT - 1, 0>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
+        epi_elem<EPI, MT - 1, 1>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
+        epi_elem<EPI, MT - 1, 2>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
+        epi_elem<EPI, MT - 1, 3>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
+        epi_elem<EPI, MT - 1, 4>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
+        epi_elem<EPI, MT - 1, 5>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
+        epi_elem<EPI, MT - 1, 6>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
+        epi_elem<EPI, MT - 1, 7>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
     }
 }
 
@@ -380,12 +455,18 @@ struct FusedArgs {
     int T, se_idx, multi_norm;
 };
 
-// Piece C of head tile M: tiles 0 .. TT-1 are log-sigma rows 16 M + 4 g + r, tile TT holds the five q rows.
-template <int TT, int M, int C>
-__device__ __forceinline__ void head_pair(const Acc& acc, const FusedArgs& a, const int64_t (&v)[2], int g) {
-    constexpr int vt = C / 2, d = C % 2;
-    float y0, y1;
-    acc_pair<C>(acc, y0, y1);
+// Piece E (= 4 vt + r) of head tile M: tiles 0 .. TT-1 are log-sigma rows 16 M + 4 g + r, tile TT holds the
+// five q rows.  Even pieces park their value, odd ones store the pair.
+template <int TT, int M, int E>
+__device__ __forceinline__ void head_elem(const Acc& acc, float inv_scale, const FusedArgs& a, const int64_t (&v)[2],
+                                          int g, float& carry) {
+    constexpr int vt = E / 4, d = (E % 4) / 2;
+    const float y = acc_elem<E>(acc, inv_scale);
+    if constexpr (E % 2 == 0) {
+        carry = y;
+        return;
+    }
+    const float y0 = carry, y1 = y;
     if (v[vt] >= a.N) return;
     if constexpr (M < TT) {
         const int row = 16 * M + 4 * g + 2 * d;
@@ -403,41 +484,54 @@ __device__ __forceinline__ void head_pair(const Acc& acc, const FusedArgs& a, co
     }
 }
 template <int KS, int TT, int F0, int FP, int BOFF, int M = 0>
-__device__ __forceinline__ void head_op(Stream& S, uint32_t bias_lds, Frag& w, const Panel<KS>& b, const FusedArgs& a,
-                                        const int64_t (&v)[2], int g, Acc (&acc)[2]) {
+__device__ __forceinline__ void head_op(Stream& S, uint32_t bias_lds, float inv_scale, Frag& wa, Frag& wb,
+                                        const Panel<KS>& b, const FusedArgs& a, const int64_t (&v)[2], int g,
+                                        Acc (&acc)[2]) {
     if constexpr (M <= TT) {
+        float carry = 0.0f;
         auto prev = [&](auto c) {
-            if constexpr (M > 0) head_pair<TT, (M > 0 ? M - 1 : 0), decltype(c)::value>(acc[(M + 1) & 1], a, v, g);
+            if constexpr (M > 0)
+                head_elem<TT, (M > 0 ? M - 1 : 0), decltype(c)::value>(acc[(M + 1) & 1], inv_scale, a, v, g, carry);
         };
-        tile_mma<KS, F0 + M * 2 * KS, FP, BOFF + 16 * M>(S, bias_lds, w, b, acc[M & 1], prev);
-        head_op<KS, TT, F0, FP, BOFF, M + 1>(S, bias_lds, w, b, a, v, g, acc);
+        tile_mma<KS, F0 + M * 2 * KS, FP, BOFF + 16 * M>(S, bias_lds, wa, wb, b, acc[M & 1], prev);
+        head_op<KS, TT, F0, FP, BOFF, M + 1>(S, bias_lds, inv_scale, wa, wb, b, a, v, g, acc);
     } else {
         __builtin_amdgcn_sched_barrier(0);
-        head_pair<TT, TT, 0>(acc[TT & 1], a, v, g);
-        head_pair<TT, TT, 1>(acc[TT & 1], a, v, g);
-        head_pair<TT, TT, 2>(acc[TT & 1], a, v, g);
-        head_pair<TT, TT, 3>(acc[TT & 1], a, v, g);
+        float carry = 0.0f;
+        head_elem<TT, TT, 0>(acc[TT & 1], inv_scale, a, v, g, carry);
+        head_elem<TT, TT, 1>(acc[TT & 1], inv_scale, a, v, g, carry);
+        head_elem<TT, TT, 2>(acc[TT & 1], inv_scale, a, v, g, carry);
+        head_elem<TT, TT, 3>(acc[TT & 1], inv_scale, a, v, g, carry);
+        head_elem<TT, TT, 4>(acc[TT & 1], inv_scale, a, v, g, carry);
+        head_elem<TT, TT, 5>(acc[TT & 1], inv_scale, a, v, g, carry);
+        head_elem<TT, TT, 6>(acc[TT & 1], inv_scale, a, v, g, carry);
+        head_elem<TT, TT, 7>(acc[TT & 1], inv_scale, a, v, g, carry);
     }
 }
 
 // Gated residual blocks LB .. L-1 (model.py:147-172): b comes in P0 and leaves in P1; the panels rotate by
-// name from block to block, nothing is copied.
-template <int KS, int MT, int L, int TT, int FB0, int FP, int LB>
-__device__ __forceinline__ void blocks_and_head(Stream& S, uint32_t bias_lds, Frag& w, Panel<KS>& P0, Panel<KS>& P1,
-                                                Panel<KS>& P2, const FusedArgs& a, const int64_t (&v)[2], int g,
-                                                Acc (&acc)[2]) {
+// name from block to block, nothing is copied.  SC0: float index of the first block op's 2^-e in the aux image.
+template <int KS, int MT, int L, int TT, int FB0, int FP, int SC0, int LB>
+__device__ __forceinline__ void blocks_and_head(Stream& S, uint32_t bias_lds, uint32_t aux_lds, Frag& wa, Frag& wb,
+                                                Panel<KS>& P0, Panel<KS>& P1, Panel<KS>& P2, const FusedArgs& a,
+                                                const int64_t (&v)[2], int g, Acc (&acc)[2]) {
     constexpr int FOP = MT * KS * 2;  // fragments per dense op
     constexpr int U = 16 * MT;
     if constexpr (LB < L) {
-        constexpr int F = FB0 + LB * 4 * FOP, B = U + LB * 4 * U;
-        dense_op<KS, KS, MT, F, FP, B, EPI_RELU>(S, bias_lds, w, P0, P2, P2, P2, acc);                 // skip, :148
-        if constexpr (LB > 0) relu_panel(P0);  // block 0's input is a relu output already                :151
-        dense_op<KS, KS, MT, F + FOP, FP, B + U, EPI_RELU>(S, bias_lds, w, P0, P1, P1, P1, acc);        // t, :152-155
-        dense_op<KS, KS, MT, F + 2 * FOP, FP, B + 2 * U, EPI_LINEAR>(S, bias_lds, w, P1, P0, P0, P0, acc);  // r, :156
-        dense_op<KS, KS, MT, F + 3 * FOP, FP, B + 3 * U, EPI_GATE>(S, bias_lds, w, P0, P1, P2, P0, acc);    // :164-170
-        blocks_and_head<KS, MT, L, TT, FB0, FP, LB + 1>(S, bias_lds, w, P1, P0, P2, a, v, g, acc);
+        constexpr int F = FB0 + LB * 4 * FOP, B = U + LB * 4 * U, SC = SC0 + 8 * LB;
+        dense_op<KS, KS, MT, F, FP, B, EPI_RELU>(S, bias_lds, op_inv_scale<SC>(aux_lds), wa, wb, P0, P2, P2, P2,
+                                                 acc);                                             // skip, :148
+        if constexpr (LB > 0) relu_panel(P0);  // block 0's input is a relu output already            :151
+        dense_op<KS, KS, MT, F + FOP, FP, B + U, EPI_RELU>(S, bias_lds, op_inv_scale<SC + 2>(aux_lds), wa, wb, P0, P1,
+                                                           P1, P1, acc);                            // t, :152-155
+        dense_op<KS, KS, MT, F + 2 * FOP, FP, B + 2 * U, EPI_LINEAR>(S, bias_lds, op_inv_scale<SC + 4>(aux_lds), wa, wb,
+                                                                     P1, P0, P0, P0, acc);          // r, :156
+        dense_op<KS, KS, MT, F + 3 * FOP, FP, B + 3 * U, EPI_GATE>(S, bias_lds, op_inv_scale<SC + 6>(aux_lds), wa, wb,
+                                                                   P0, P1, P2, P0, acc);            // :164-170
+        blocks_and_head<KS, MT, L, TT, FB0, FP, SC0, LB + 1>(S, bias_lds, aux_lds, wa, wb, P1, P0, P2, a, v, g, acc);
     } else {
-        head_op<KS, TT, FB0 + L * 4 * FOP, FP, U + L * 4 * U>(S, bias_lds, w, P0, a, v, g, acc);
+        head_op<KS, TT, FB0 + L * 4 * FOP, FP, U + L * 4 * U>(S, bias_lds, op_inv_scale<SC0 + 8 * L>(aux_lds), wa, wb,
+                                                              P0, a, v, g, acc);
     }
 }
 
@@ -452,7 +546,7 @@ __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
     float* lbias = reinterpret_cast<float*>(smem + kRing * kStageFrags * 64);  // [bias_total]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
-    for (int k = threadIdx.x; k < fl.bias_total; k += kFB) lbias[k] = a.bias[k];
+    for (int k = threadIdx.x; k < fl.aux_floats; k += kFB) lbias[k] = a.bias[k];  // biases, then per-op scales
 
     Stream S;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -466,14 +560,18 @@ __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
     S.read_slot = 0;
     S.pass_bytes = (uint32_t)fl.stages_pass * kStageFrags * 1024;
     const uint32_t bias_lds = lds_addr(lbias) + 16u * g;
+    const uint32_t aux_lds = lds_addr(lbias);
+    constexpr int SC0 = fl.scale_off + 1;  // float index of the first layer's 2^-e; op k's is SC0 + 2 k
 #pragma unroll
     for (int k = 0; k < kAhead; ++k) stream_issue(S);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kAhead - 1)) : "memory");  // stage 0 has landed (my quarter)
     __syncthreads();                                                          // ... everyone's; the biases too
-    Frag w;
-    w.hi = lds_read16<0>(S.cur);
-    w.lo = lds_read16<1024>(S.cur);
-    lds_wait(w.hi, w.lo);
+    Frag wa, wb;  // the next two fragment pairs of the stream
+    wa.hi = lds_read16<0>(S.cur);
+    wa.lo = lds_read16<1024>(S.cur);
+    wb.hi = lds_read16<2048>(S.cur);
+    wb.lo = lds_read16<3072>(S.cur);
+    lds_wait(wa.hi, wa.lo, wb.hi, wb.lo);
 
     const int64_t nblk = (a.N + kVoxPerPass - 1) / kVoxPerPass;
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -509,17 +607,16 @@ __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
                     f[j] = t0 + j < a.T ? logf(qb::clampf_(f[j], 1e-2f, 1e8f) / den) : 0.0f;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const _Float16 ha = (_Float16)f[2 * d], hb = (_Float16)f[2 * d + 1];
-                    X.hi[s][vt][d] = pack2(ha, hb);
-                    X.lo[s][vt][d] = pack2((_Float16)((f[2 * d] - (float)ha) * QB_LO_SCALE),
-                                           (_Float16)((f[2 * d + 1] - (float)hb) * QB_LO_SCALE));
+                    split_pair(f[2 * d], f[2 * d + 1], X.hi[s][vt][d], X.lo[s][vt][d]);
                 }
             }
         }
         Panel<KS> P0, P1, P2;
         Acc acc[2];
-        dense_op<KS, KS1, MT, 0, FP, 0, EPI_RELU>(S, bias_lds, w, X, P0, P0, P0, acc);  // first layer, model.py:181
-        blocks_and_head<KS, MT, L, TT, MT * KS1 * 2, FP, 0>(S, bias_lds, w, P0, P1, P2, a, v, g, acc);
+        dense_op<KS, KS1, MT, 0, FP, 0, EPI_RELU>(S, bias_lds, op_inv_scale<SC0>(aux_lds), wa, wb, X, P0, P0, P0,
+                                                  acc);  // first layer, model.py:181
+        blocks_and_head<KS, MT, L, TT, MT * KS1 * 2, FP, SC0 + 2, 0>(S, bias_lds, aux_lds, wa, wb, P0, P1, P2, a, v, g,
+                                                                     acc);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-direct load may land after the block has gone
 }
@@ -542,7 +639,7 @@ int wide_fused_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const
     a.T = shape->T;
     a.se_idx = ctx->dev.se_idx;
     a.multi_norm = ctx->dev.multi_norm;
-    const size_t smem = sizeof(uint4) * kRing * kStageFrags * 64 + sizeof(float) * ((fl.bias_total + 3) & ~3);
+    const size_t smem = sizeof(uint4) * kRing * kStageFrags * 64 + sizeof(float) * fl.aux_floats;
     const int64_t nblk = (N + kVoxPerPass - 1) / kVoxPerPass;
     const int grid = (int)(nblk < ctx->num_cus ? nblk : ctx->num_cus);
 #define QB_LAUNCH_FUSED(TT, LL)                                                                              \
@@ -589,13 +686,17 @@ extern "C" int qbold_encoder_fused_pack(const qbold_ctx* ctx, const qbold_encode
     const FusedLayout fl = make_fused_layout(T, U, L);
     const qb::CanonLayout c = qb::make_canon(T, U, L, shape->channelwise_gating, shape->spatial_taps);
     hipStream_t s = (hipStream_t)stream;
-    int frag = 0;
+    int frag = 0, op = 0;
     auto pack = [&](int KS, int MT, int korder, const float* W, const float* b, int nin, int nout, const float* W2,
                     const float* b2, int nout2, int split_row, float add, int bias_off) {
+        float* scale = packed + fl.img_floats + fl.scale_off + 2 * op;
+        hipLaunchKernelGGL(fused_scale_kernel, dim3(1), dim3(256), 0, s, W, (int64_t)nin * nout, W2,
+                           W2 ? (int64_t)nin * nout2 : 0, scale);
         const int64_t n = (int64_t)MT * KS * 2 * 512 + 16 * MT;
         hipLaunchKernelGGL(fused_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, frag, KS, MT, korder,
-                           W, b, nin, nout, W2, b2, nout2, split_row, add, bias_off, fl.img_floats, packed);
+                           W, b, nin, nout, W2, b2, nout2, split_row, add, bias_off, scale, fl.img_floats, packed);
         frag += MT * KS * 2;
+        ++op;
     };
     pack(fl.KS1, fl.MT, 0, weights + c.W0, weights + c.b0, T, U, nullptr, nullptr, 0, 0, 0.0f, fl.bias_first);
     const int ctr = c.taps == 9 ? 4 * U * U : 0;  // voxel batches see the centre tap of the 3x3x1 kernels
