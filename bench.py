@@ -239,6 +239,7 @@ def main():
     ap.add_argument("--cpu_budget_s", type=float, default=15.0)
     args = ap.parse_args()
     if os.environ.get("QBOLD_DEBUG_SKIP", "0") not in ("", "0"):
+        os.environ["QBOLD_ALLOW_ABLATION"] = "1"   # the library ignores QBOLD_DEBUG_SKIP without it
         # the ablation hooks of the kernels (phases switched off for timing experiments)
         # must never reach a reported number
         print("bench.py: QBOLD_DEBUG_SKIP is set -- kernels would skip work; this run is an ablation, not a "

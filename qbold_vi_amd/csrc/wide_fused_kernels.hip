@@ -12,31 +12,40 @@
 // registers from the first layer to the heads; HBM sees the signals once and the heads once.
 //
 // Mapping.  256-thread workgroups, one per CU, ONE wave per SIMD, so a wave may use the whole 512-entry
-// register file.  A wave owns 32 voxels (two 16-voxel MFMA column tiles); every dense layer is computed
-// transposed (weights = A operand, activations = B operand) so that the 16x16 accumulator layout (voxel on
-// lane & 15, units 4 (lane >> 4) + reg) IS the next layer's B operand if the weight image is stored in that k
-// order (encoder_core.h).  A 256-unit activation panel of 32 voxels is kept as ready-made B operands -- split
-// f16 halves hi / lo of every value, 8 k-steps x 2 voxel tiles x (4 + 4) VGPRs = 128 VGPRs -- and a gated
-// block needs three panels (b / relu b, skip, t -> r), 384 VGPRs, plus one output tile's accumulators.
-// The loop nest is output tile outermost: the B operands of all k-steps are register-resident, so a tile's
-// accumulators live for 48 MFMAs only and its result goes straight into the next panel (bias, activation,
-// split).  Arithmetic: x = hi + lo with hi = f16(x), lo = f16(x - hi) UNSCALED, so that all three products
-// (hi.hi, hi.lo, lo.hi) add into ONE accumulator per voxel tile and the epilogue has nothing to combine;
-// weights are pre-multiplied per dense op by a power of two that puts max |w| in [2^12, 2^13) (their lo halves
-// stay normal f16 numbers down to |w| = 2^-15 max |w|), undone for free in the epilogue's y = acc 2^-e + bias.
-// An activation's lo half is a normal number for |x| >= 2^-3 and carries an absolute error <= 2^-25 below.
+// register file.  A wave owns 32 voxels = the N side of v_mfma_f32_32x32x16_f16; every dense layer is computed
+// transposed (weights = A operand, activations = B operand) so that the 32x32 accumulator layout (voxel on
+// lane & 31; register r of lane half h = lane >> 5 holds unit 8 (r >> 2) + 4 h + (r & 3) of the tile) IS the next
+// layer's B operand (k-slot j of lane half h) if the weight image is stored in that k order: registers
+// 8 t .. 8 t + 7 of output tile M are the eight k-slots of k-step 2 M + t.  A 256-unit activation panel of 32
+// voxels is kept as ready-made B operands -- split f16 halves hi / lo of every value, 16 k-steps x (4 + 4)
+// VGPRs = 128 VGPRs -- and a gated block needs three panels (b / relu b, skip, t -> r), 384 VGPRs, plus two
+// output tiles' accumulators (16 each).  The loop nest is output tile outermost: the B operands of all k-steps
+// are register-resident, so a tile's accumulator lives for 48 MFMAs only and its result goes straight into
+// the next panel (bias, activation, split).
+//
+// Why 32x32x16.  With one wave per SIMD the epilogue's vector instructions have to issue in the shadow of this
+// wave's own MFMAs.  A 16x16x32 MFMA (16 cycles) leaves 8 cycles of vector issue -- two instructions, and a
+// dependent pair already overruns it; measured, that form of this kernel ran at 2.2x its matrix-pipe time with
+// the vector pipe and the matrix pipe taking turns.  A 32x32x16 MFMA does the same work per cycle in 32-cycle
+// pieces and leaves 24 cycles: the ~3.4 vector instructions per MFMA of this kernel fit.
+//
+// Arithmetic: x = hi + lo with hi = f16(x), lo = f16(x - hi) UNSCALED, so that all three products (hi.hi, hi.lo,
+// lo.hi) add into ONE accumulator and the epilogue has nothing to combine; weights are pre-multiplied per dense
+// op by a power of two that puts max |w| in [2^12, 2^13) (their lo halves stay normal f16 numbers down to
+// |w| = 2^-15 max |w|), undone for free in the epilogue's y = acc 2^-e + bias.  An activation's lo half is a
+// normal number for |x| >= 2^-3 and carries an absolute error <= 2^-25 below that; |x| beyond 65504 overflows hi.
 //
 // Weights.  All dense ops of one pass over 128 voxels form one flat stream of 1 KiB MFMA fragments in
 // consumption order ([op][out tile][k-step][hi, lo]; 2.2 MB for config 3, L2-resident).  Stages of 16
 // fragments travel L2 -> LDS by LDS-direct loads (global_load_lds_dwordx4, each wave issues a quarter) into a
-// ring of four 16 KiB slots, three stages ahead; the handshake sits in the MIDDLE of a stage -- counted
+// ring of eight 16 KiB slots, seven stages ahead; the handshake sits in the MIDDLE of a stage -- counted
 // s_waitcnt vmcnt, raw s_barrier, issue of the stage that reuses the slot everyone has just left -- so the
-// first fragments of the next stage are known to have landed before the current stage ends and the fragment
-// reads run one pair ahead of the MFMAs without a bubble at stage boundaries.  The stream wraps from one
-// pass to the next (same weights), so the ring never drains.  Biases live in LDS for the whole launch.
+// next stage is known to have landed before the current one ends and the fragment reads run two pairs ahead of
+// the MFMAs without a bubble at tile, stage or pass boundaries.  The stream wraps from one pass to the next
+// (same weights), so the ring never drains.  Biases and per-op scales live in LDS for the whole launch.
 //
-// Per pass and wave: 6,576 MFMAs (16 cycles each) = 105 k cycles of matrix pipe for 32 voxels; at N = 1 M that
-// is 32 passes per CU = 1.40 ms at 2.4 GHz -- the floor this kernel is measured against.
+// Per pass and wave: 3,312 MFMAs (32 cycles each) = 106 k cycles of matrix pipe for 32 voxels; at N = 1 M that
+// is 32 passes per CU = 1.41 ms at 2.4 GHz -- the floor this kernel is measured against.
 #include "canon_layout.h"
 #include "encoder_core.h"
 #include "qbold_ctx.h"
@@ -47,7 +56,7 @@ namespace {
 using namespace qbw;
 
 #ifndef QB_FUSED_VALU_PER_MFMA
-#define QB_FUSED_VALU_PER_MFMA 3
+#define QB_FUSED_VALU_PER_MFMA 5
 #endif
 constexpr int kFB = 256;          // threads per block: one wave per SIMD
 constexpr int kRing = 8;          // LDS ring slots of 16 fragments (128 KiB)
@@ -55,10 +64,13 @@ constexpr int kAhead = 7;         // stages requested beyond the one being read
 constexpr int kStageFrags = 16;   // 1 KiB fragments per stage
 constexpr int kVoxPerPass = 128;  // 4 waves x 32 voxels
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define QB_MFMA32_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
 // ---- fused image layout (host + device) ------------------------------------------------------------
 struct FusedLayout {
     int T, U, L;
-    int KS1, KS, MT, TT, HT;  // first-layer k-steps, body k-steps, body tiles, log-sigma tiles, head tiles
+    int KS1, KS, MT, LT, HT;  // first-layer k-steps (16 deep), body k-steps, body tiles (32 rows), log-sigma tiles, head tiles
     int frags_first, frags_op, frags_head, frags_pass, stages_pass;
     int bias_first, bias_blk0, bias_head, bias_total;  // float offsets inside the bias image
     int scale_off, n_ops, aux_floats;                   // per-op (2^e, 2^-e) pairs behind the biases
@@ -67,11 +79,11 @@ struct FusedLayout {
 __host__ __device__ constexpr inline FusedLayout make_fused_layout(int T, int U, int L) {
     FusedLayout f{};
     f.T = T; f.U = U; f.L = L;
-    f.KS1 = (T + 31) / 32;
-    f.KS = U / 32;
-    f.MT = U / 16;
-    f.TT = (T + 15) / 16;
-    f.HT = f.TT + 1;
+    f.KS1 = (T + 15) / 16;
+    f.KS = U / 16;
+    f.MT = U / 32;
+    f.LT = (T + 31) / 32;
+    f.HT = f.LT + 1;
     f.frags_first = f.MT * f.KS1 * 2;
     f.frags_op = f.MT * f.KS * 2;
     f.frags_head = f.HT * f.KS * 2;
@@ -80,7 +92,7 @@ __host__ __device__ constexpr inline FusedLayout make_fused_layout(int T, int U,
     f.bias_first = 0;
     f.bias_blk0 = U;
     f.bias_head = U + 4 * L * U;
-    f.bias_total = f.bias_head + 16 * f.HT;
+    f.bias_total = f.bias_head + 32 * f.HT;
     f.scale_off = (f.bias_total + 3) & ~3;
     f.n_ops = 2 + 4 * L;  // first layer, four per block, heads
     f.aux_floats = (f.scale_off + 2 * f.n_ops + 3) & ~3;
@@ -90,7 +102,7 @@ __host__ __device__ constexpr inline FusedLayout make_fused_layout(int T, int U,
 }
 inline bool fused_supported(const qbold_encoder_shape* s) {
     // the unrolled kernels below are instantiated for these shapes (T <= 16 or 49 .. 64 taus: one or four
-    // log-sigma tiles); anything else keeps the layer-wise path
+    // first-layer k-steps); anything else keeps the layer-wise path
     return s && s->U == 256 && (s->L == 1 || s->L == 2) && ((s->T >= 1 && s->T <= 16) || (s->T >= 49 && s->T <= 64)) &&
            s->channelwise_gating && s->precision == QBOLD_ENC_F32;
 }
@@ -118,10 +130,11 @@ __global__ void fused_scale_kernel(const float* __restrict__ W, int64_t n, const
     }
 }
 
-// One dense op into the fused image.  korder 0: in = 32 s + 8 g + j (first layer: rows of x); 1: the
-// accumulator order unit(s, g, j) = 16 (2 s + (j >> 2)) + 4 g + (j & 3) of encoder_core.h.  Head (W2 != null):
-// output row < 16 TT -> log-sigma row of W (Ws), else q row (row - 16 TT) of W2 (Wf).  Weights are stored
-// times scale[0] as hi = f16(w'), lo = f16(w' - hi); biases unscaled.
+// One dense op into the fused image: fragment (tile m, k-step s, part) holds, for lane (h = lane >> 5,
+// i = lane & 31) and k-slot j, W[in][out = 32 m + i] with in = 16 s + 8 h + j (korder 0: the first layer, rows of
+// x) or in = 16 s + 8 (j >> 2) + 4 h + (j & 3) (korder 1: the accumulator order, see the header).  Head
+// (W2 != null): output row < split_row -> log-sigma row of W (Ws), else q row (row - split_row) of W2 (Wf).
+// Weights are stored times scale[0] as hi = f16(w'), lo = f16(w' - hi); biases unscaled.
 __global__ void fused_pack_kernel(int frag0, int KS, int MT, int korder, const float* __restrict__ W,
                                   const float* __restrict__ b, int nin, int nout, const float* __restrict__ W2,
                                   const float* __restrict__ b2, int nout2, int split_row, float bias_add,
@@ -130,7 +143,7 @@ __global__ void fused_pack_kernel(int frag0, int KS, int MT, int korder, const f
     _Float16* ph = reinterpret_cast<_Float16*>(packed) + (int64_t)frag0 * 512;
     const int64_t halves = (int64_t)MT * KS * 2 * 512;
     const float sc = scale[0];
-    for (int64_t h = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; h < halves + 16 * MT;
+    for (int64_t h = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; h < halves + 32 * MT;
          h += (int64_t)gridDim.x * blockDim.x) {
         if (h >= halves) {  // bias rows in the same (possibly remapped) order
             const int row = (int)(h - halves);
@@ -147,9 +160,9 @@ __global__ void fused_pack_kernel(int frag0, int KS, int MT, int korder, const f
         const int j = (int)(h & 7), lane = (int)((h >> 3) & 63), part = (int)((h >> 9) & 1);
         const int64_t pair = h >> 10;  // m * KS + s
         const int s = (int)(pair % KS), m = (int)(pair / KS);
-        const int g = lane >> 4, i = lane & 15;
-        const int in = korder ? 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3) : 32 * s + 8 * g + j;
-        const int out = 16 * m + i;
+        const int hh = lane >> 5, i = lane & 31;
+        const int in = korder ? 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3) : 16 * s + 8 * hh + j;
+        const int out = 32 * m + i;
         float w = 0.0f;
         if (in < nin) {
             if (W2) {
@@ -166,27 +179,31 @@ __global__ void fused_pack_kernel(int frag0, int KS, int MT, int korder, const f
 }
 
 // ---- device side ---------------------------------------------------------------------------------------
-// B operands of every k-step of one activation tensor, for this wave's two voxel tiles, as packed f16 pairs:
-// dword d of fragment [k-step][voxel tile] holds k-slots 2 d, 2 d + 1.  (Kept as opaque 32-bit values: left as
-// f16x8 vectors filled element by element, the compiler carries every half in a register of its own until the
-// MFMA -- 256 registers per panel.)
+// B operands of every k-step of one activation tensor, for this wave's 32 voxels, as packed f16 pairs:
+// dword d of k-step s holds k-slots 2 d, 2 d + 1.  (Kept as opaque 32-bit values: left as f16x8 vectors filled
+// element by element, the compiler carries every half in a register of its own until the MFMA.)
 template <int KS>
 struct Panel {
-    uint32_t hi[KS][2][4], lo[KS][2][4];
+    uint32_t hi[KS][4], lo[KS][4];
 };
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 template <int KS>
-__device__ __forceinline__ f16x8 frag_hi(const Panel<KS>& P, int s, int vt) {
-    return __builtin_bit_cast(f16x8, u32x4v{P.hi[s][vt][0], P.hi[s][vt][1], P.hi[s][vt][2], P.hi[s][vt][3]});
+__device__ __forceinline__ f16x8 frag_hi(const Panel<KS>& P, int s) {
+    return __builtin_bit_cast(f16x8, u32x4v{P.hi[s][0], P.hi[s][1], P.hi[s][2], P.hi[s][3]});
 }
 template <int KS>
-__device__ __forceinline__ f16x8 frag_lo(const Panel<KS>& P, int s, int vt) {
-    return __builtin_bit_cast(f16x8, u32x4v{P.lo[s][vt][0], P.lo[s][vt][1], P.lo[s][vt][2], P.lo[s][vt][3]});
+__device__ __forceinline__ f16x8 frag_lo(const Panel<KS>& P, int s) {
+    return __builtin_bit_cast(f16x8, u32x4v{P.lo[s][0], P.lo[s][1], P.lo[s][2], P.lo[s][3]});
 }
-__device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
-    uint32_t d = __builtin_bit_cast(uint32_t, qb::f16x2{a, b});
-    asm volatile("" : "+v"(d));  // one packed register from here on
-    return d;
+// x = hi + lo, hi = f16(x), lo = f16(x - hi), for a pair of values: one packed conversion for the hi halves,
+// and each lo half straight from a mixed-precision FMA (x - hi is exact in float32; the FMA rounds it to f16)
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    uint32_t h = __builtin_bit_cast(uint32_t, qb::f16x2{(_Float16)a, (_Float16)b}), l;
+    asm volatile("" : "+v"(h));  // one packed register from here on
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
+    hi = h;
+    lo = l;
 }
 
 // The weight-fragment stream of this wave.
@@ -225,13 +242,11 @@ __device__ __forceinline__ void stream_issue(Stream& S) {
     S.src_off = nxt;
     S.issue_slot = (S.issue_slot + 1) & (kRing - 1);
 }
-// Mid-stage handshake: my quarter of the NEXT stage has landed (all but the youngest stage's four loads
+// Mid-stage handshake: my quarter of the NEXT stage has landed (all but the youngest kAhead - 2 stages' loads
 // are done), everyone has left the previous stage, whose slot the new issue overwrites.
 __device__ __forceinline__ void stream_sync(Stream& S) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kAhead - 2)) : "memory");
-#ifndef QB_FUSED_X_NOBARRIER  // timing experiments only (scripts/dev/fused_variants.sh): results are invalid
     __builtin_amdgcn_s_barrier();
-#endif
     stream_issue(S);
 }
 __device__ __forceinline__ void stream_next_stage(Stream& S) {
@@ -242,25 +257,29 @@ __device__ __forceinline__ void stream_next_stage(Stream& S) {
 struct Frag {   // one (hi, lo) fragment pair of the weight stream
     u32x4 hi, lo;
 };
-struct Acc {    // a finished (or running) output tile: one accumulator per voxel tile and the tile's bias rows
-    f32x4 o[2];
-    u32x4 bias;
-};
 template <int V>
 struct IC {
     static constexpr int value = V;
 };
-// all LDS reads but the two youngest (the pair requested last) have returned
-#ifdef QB_FUSED_X_NOLDSWAIT  // timing experiments only: results are invalid
-#define QB_FUSED_WAIT_BUT2 ""
-#else
-#define QB_FUSED_WAIT_BUT2 "s_waitcnt lgkmcnt(2)"
-#endif
+// every LDS read but the two youngest (the pair requested last) has returned
 __device__ __forceinline__ void lds_wait_but2(u32x4& a, u32x4& b) {
-    asm volatile(QB_FUSED_WAIT_BUT2 : "+v"(a), "+v"(b));
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ void lds_wait_but2(u32x4& a, u32x4& b, u32x4& c) {
-    asm volatile(QB_FUSED_WAIT_BUT2 : "+v"(a), "+v"(b), "+v"(c));
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b), "+v"(c));
+}
+template <int OFF>
+__device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read_b32 immediate offset is 16 bits");
+    uint32_t r;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int OFF>
+__device__ __forceinline__ float lds_read4_now(uint32_t addr) {
+    uint32_t r;
+    asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr), "n"(OFF));
+    return __builtin_bit_cast(float, r);
 }
 
 // Request the fragment pair that starts at fragment F of the pass; F >= FP: a pair of the NEXT pass (same
@@ -274,131 +293,125 @@ __device__ __forceinline__ void frag_fetch(Stream& S, Frag& w) {
     w.lo = lds_read16<(FO + 1) * 1024>(S.cur);
 }
 
-// k-steps S_ .. KSOP-1 of one 16-row output tile, both voxel tiles.  wa holds the pair of step S_ (returned),
-// wb the pair of step S_+1 (requested); the pair of step S_+2 is requested before the six MFMAs of step S_,
-// and after them the wait leaves only that youngest pair outstanding.  The previous tile's epilogue (prev:
-// eight pieces, one per output value of a lane) is spread over the k-steps so that its vector instructions
-// issue between this tile's MFMAs, two or three per MFMA.
-// oa / ob: the two pairs that follow the tile.  (Recursive template: every LDS offset is an immediate.)
-template <int KSOP, int F0, int FP, int BOFF, int S_, class Prev>
+// unit 32 M + 8 (E >> 2) + 4 h + (E & 3) of the tile: float offset of its bias relative to the lane half's base
+__host__ __device__ constexpr inline int bias_row(int E) { return 8 * (E >> 2) + (E & 3); }
+
+// k-steps S_ .. KSOP-1 of one 32-row output tile.  wa holds the pair of step S_ (returned), wb the pair of step
+// S_+1 (requested); the pair of step S_+2 is requested before the three MFMAs of step S_, and after them the
+// wait leaves only that youngest pair outstanding.  The PREVIOUS tile's epilogue (prev: sixteen pieces, one
+// per output value of a lane) is spread over the k-steps so that its vector instructions issue between this
+// tile's MFMAs.  The biases of the pieces of step S_+1 are requested in step S_ (one ds_read_b32 with sixteen
+// k-steps, one ds_read_b128 with four) -- PBOFF: bias offset of the previous tile, BOFF of this one, whose
+// first pieces are requested in the last step -- and travel in `bias`.  oa / ob: the two pairs that follow the
+// tile.  (Recursive template: every LDS offset is an instruction immediate.)
+template <int KSOP, int F0, int FP, int BOFF, int PBOFF, bool HAVE_PREV, int S_, class Prev>
 __device__ __forceinline__ void tile_steps(Stream& S, uint32_t bias_lds, Frag wa, Frag wb, Frag& oa, Frag& ob,
-                                           const Panel<KSOP>& in, Acc& acc, const Prev& prev) {
+                                           const Panel<KSOP>& in, f32x16& acc, u32x4& bias, const Prev& prev) {
+    constexpr int PPS = 16 / KSOP;  // epilogue pieces per k-step
+    constexpr bool AHEAD = PPS <= 4;
     if constexpr (S_ < KSOP) {
         if constexpr ((F0 + 2 * S_) % kStageFrags == kStageFrags / 2) stream_sync(S);
-        if constexpr (S_ == 0) acc.bias = lds_read16<BOFF * 4>(bias_lds);
+        u32x4 nbias = bias;
+        if constexpr (AHEAD) {
+            constexpr bool last = S_ + 1 == KSOP;
+            constexpr int E0 = last ? 0 : PPS * (S_ + 1);           // first piece of the step the bias is for
+            constexpr int off = ((last ? BOFF : PBOFF) + bias_row(E0)) * 4;
+            if constexpr (last || HAVE_PREV) {
+                if constexpr (PPS == 1) nbias[0] = lds_read4<off>(bias_lds);
+                else nbias = lds_read16<off>(bias_lds);  // pieces E0 .. E0 + 3 are four consecutive rows
+            }
+        }
         Frag n;
         frag_fetch<F0 + 2 * S_ + 4, FP>(S, n);
         // the reads are in flight BEFORE this step's MFMAs and waited for AFTER them: nothing crosses either fence
         __builtin_amdgcn_sched_barrier(0);
         const f16x8 h = __builtin_bit_cast(f16x8, wa.hi), l = __builtin_bit_cast(f16x8, wa.lo);
-        const f16x8 h0 = frag_hi(in, S_, 0), h1 = frag_hi(in, S_, 1), l0 = frag_lo(in, S_, 0), l1 = frag_lo(in, S_, 1);
-        acc.o[0] = QB_MFMA_F16(h, h0, acc.o[0]);
-        acc.o[1] = QB_MFMA_F16(h, h1, acc.o[1]);
-        acc.o[0] = QB_MFMA_F16(h, l0, acc.o[0]);
-        acc.o[1] = QB_MFMA_F16(h, l1, acc.o[1]);
-        acc.o[0] = QB_MFMA_F16(l, h0, acc.o[0]);
-        acc.o[1] = QB_MFMA_F16(l, h1, acc.o[1]);
-#ifndef QB_FUSED_X_NOEPI
-        if constexpr ((0 * KSOP) / 8 == S_) prev(IC<0>{});
-        if constexpr ((1 * KSOP) / 8 == S_) prev(IC<1>{});
-        if constexpr ((2 * KSOP) / 8 == S_) prev(IC<2>{});
-        if constexpr ((3 * KSOP) / 8 == S_) prev(IC<3>{});
-        if constexpr ((4 * KSOP) / 8 == S_) prev(IC<4>{});
-        if constexpr ((5 * KSOP) / 8 == S_) prev(IC<5>{});
-        if constexpr ((6 * KSOP) / 8 == S_) prev(IC<6>{});
-        if constexpr ((7 * KSOP) / 8 == S_) prev(IC<7>{});
-#endif
+        const f16x8 bh = frag_hi(in, S_), bl = frag_lo(in, S_);
+        acc = QB_MFMA32_F16(h, bh, acc);
+        acc = QB_MFMA32_F16(h, bl, acc);
+        acc = QB_MFMA32_F16(l, bh, acc);
+        if constexpr (HAVE_PREV) {
+            if constexpr (PPS == 1) {
+                prev(IC<S_>{}, __builtin_bit_cast(float, bias[0]));
+            } else if constexpr (PPS == 4) {
+                const float4 b4 = __builtin_bit_cast(float4, bias);
+                prev(IC<4 * S_ + 0>{}, b4.x);
+                prev(IC<4 * S_ + 1>{}, b4.y);
+                prev(IC<4 * S_ + 2>{}, b4.z);
+                prev(IC<4 * S_ + 3>{}, b4.w);
+            } else {  // a single k-step (T <= 16): biases read where they are used
+                prev(IC<0>{}, 0.0f); prev(IC<1>{}, 0.0f); prev(IC<2>{}, 0.0f); prev(IC<3>{}, 0.0f);
+                prev(IC<4>{}, 0.0f); prev(IC<5>{}, 0.0f); prev(IC<6>{}, 0.0f); prev(IC<7>{}, 0.0f);
+                prev(IC<8>{}, 0.0f); prev(IC<9>{}, 0.0f); prev(IC<10>{}, 0.0f); prev(IC<11>{}, 0.0f);
+                prev(IC<12>{}, 0.0f); prev(IC<13>{}, 0.0f); prev(IC<14>{}, 0.0f); prev(IC<15>{}, 0.0f);
+            }
+        }
         // issue order inside the step: one MFMA, then a share of the epilogue's vector instructions (which
-        // issue while the matrix pipe works on it), six times over
+        // issue while the matrix pipe works on it), three times over
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < 3; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, QB_FUSED_VALU_PER_MFMA, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (S_ == 0) lds_wait_but2(wb.hi, wb.lo, acc.bias);
-        else lds_wait_but2(wb.hi, wb.lo);
-        tile_steps<KSOP, F0, FP, BOFF, S_ + 1>(S, bias_lds, wb, n, oa, ob, in, acc, prev);
+        lds_wait_but2(wb.hi, wb.lo, nbias);
+        bias = nbias;
+        tile_steps<KSOP, F0, FP, BOFF, PBOFF, HAVE_PREV, S_ + 1>(S, bias_lds, wb, n, oa, ob, in, acc, bias, prev);
     } else {
         oa = wa;
         ob = wb;
     }
 }
 
-// One output tile into acc.  F0: fragment index within the pass of the tile's first fragment (a tile never
-// straddles a stage); BOFF: float offset of the tile's bias rows in the LDS bias image.  wa / wb: in, the
-// tile's first two pairs; out, the two pairs that follow it.
-template <int KSOP, int F0, int FP, int BOFF, class Prev>
+// One output tile into acc.  F0: fragment index within the pass of the tile's first fragment; BOFF / PBOFF:
+// float offsets of this / the previous tile's bias rows in the LDS bias image.  wa / wb: in, the tile's first
+// two pairs; out, the two pairs that follow it.
+template <int KSOP, int F0, int FP, int BOFF, int PBOFF, bool HAVE_PREV, class Prev>
 __device__ __forceinline__ void tile_mma(Stream& S, uint32_t bias_lds, Frag& wa, Frag& wb, const Panel<KSOP>& in,
-                                         Acc& acc, const Prev& prev) {
-    static_assert(F0 % kStageFrags + 2 * KSOP <= kStageFrags, "a tile's fragments stay inside one stage");
-    static_assert(BOFF * 4 + 64 < 65536, "bias offset is a ds_read immediate");
+                                         f32x16& acc, u32x4& bias, const Prev& prev) {
+    static_assert((BOFF + 32) * 4 < 65536, "bias offset is a ds_read immediate");
     __builtin_amdgcn_sched_barrier(0);  // tiles are scheduled one at a time: three panels leave no slack
-    acc.o[0] = acc.o[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    tile_steps<KSOP, F0, FP, BOFF, 0>(S, bias_lds, wa, wb, wa, wb, in, acc, prev);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    tile_steps<KSOP, F0, FP, BOFF, PBOFF, HAVE_PREV, 0>(S, bias_lds, wa, wb, wa, wb, in, acc, bias, prev);
 }
 
-// (W in + b)[16 M + 4 g + r] of voxel tile vt: piece E = 4 vt + r of a finished tile.  inv_scale undoes the
-// dense op's power-of-two weight scale.
-template <int E>
-__device__ __forceinline__ float acc_elem(const Acc& a, float inv_scale) {
-    constexpr int vt = E / 4, r = E % 4;
-    const float4 b4 = __builtin_bit_cast(float4, a.bias);
-    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-    return fmaf(a.o[vt][r], inv_scale, bb[r]);
-}
-// x = hi + lo, hi = f16(x), lo = f16(x - hi): the packed hi pair is converted once and its halves are read
-// back for the residual (x - hi is exact in float32)
-__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
-    hi = pack2((_Float16)a, (_Float16)b);
-    const qb::f16x2 h = __builtin_bit_cast(qb::f16x2, hi);
-    lo = pack2((_Float16)__builtin_fmaf((float)h[0], -1.0f, a), (_Float16)__builtin_fmaf((float)h[1], -1.0f, b));
-}
-// k-slots 4 (M & 1) + 2 d, + 1 of k-step M / 2 hold units 16 M + 4 g + 2 d, + 1 (C = 2 vt + d)
-template <int M, int C, int KS>
-__device__ __forceinline__ void put_pair(Panel<KS>& P, float a, float b) {
-    constexpr int vt = C / 2, d = C % 2;
-    split_pair(a, b, P.hi[M / 2][vt][2 * (M & 1) + d], P.lo[M / 2][vt][2 * (M & 1) + d]);
-}
-// value E = 4 vt + r of tile M, read back from a panel
+// value E (register E of the accumulator = unit 32 M + 8 (E >> 2) + 4 h + (E & 3)) read back from a panel
 template <int M, int E, int KS>
 __device__ __forceinline__ float get_elem(const Panel<KS>& P) {
-    constexpr int vt = E / 4, d = (E % 4) / 2, e = E % 2;
-    // laundered: otherwise the float32 values of the hi halves computed when the panel was written (split_pair)
-    // are kept alive from that op to this one -- a second, spilled copy of the panel
-    uint32_t dh = P.hi[M / 2][vt][2 * (M & 1) + d], dl = P.lo[M / 2][vt][2 * (M & 1) + d];
+    // laundered: otherwise the float32 values of the hi halves computed when the panel was written are kept
+    // alive from that op to this one -- a second, spilled copy of the panel
+    uint32_t dh = P.hi[2 * M + E / 8][(E % 8) / 2], dl = P.lo[2 * M + E / 8][(E % 8) / 2];
     asm volatile("" : "+v"(dh), "+v"(dl));
     const qb::f16x2 h = __builtin_bit_cast(qb::f16x2, dh);
     const qb::f16x2 l = __builtin_bit_cast(qb::f16x2, dl);
-    return __builtin_fmaf((float)l[e], 1.0f, (float)h[e]);
+    return __builtin_fmaf((float)l[E % 2], 1.0f, (float)h[E % 2]);
 }
 
 // relu on a split panel, in place (the Activation in front of the first 3x3x1 convolution, model.py:151):
-// the sign of hi + 2^-11 lo is the sign bit of hi (lo is below half an ulp of hi; x tiny negative gives hi = -0)
+// the sign of hi + lo is the sign bit of hi (|lo| is at most half an ulp of hi; x tiny negative gives hi = -0)
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 template <int KS>
 __device__ __forceinline__ void relu_panel(Panel<KS>& P) {
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int vt = 0; vt < 2; ++vt)
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const s16x2 neg = __builtin_bit_cast(s16x2, P.hi[s][vt][d]) >> (short)15;  // 0xffff where negative
-                const uint32_t keep = ~__builtin_bit_cast(uint32_t, neg);
-                P.hi[s][vt][d] &= keep;
-                P.lo[s][vt][d] &= keep;
-            }
+        for (int d = 0; d < 4; ++d) {
+            const s16x2 neg = __builtin_bit_cast(s16x2, P.hi[s][d]) >> (short)15;  // 0xffff where negative
+            const uint32_t keep = ~__builtin_bit_cast(uint32_t, neg);
+            P.hi[s][d] &= keep;
+            P.lo[s][d] &= keep;
+        }
 }
 
 enum { EPI_RELU = 0, EPI_LINEAR = 1, EPI_GATE = 2 };
 
-// Piece E (= 4 vt + r) of tile M's epilogue; the even piece of a pair parks its value in `carry`, the odd one
-// splits and stores the pair.  EPI_GATE: out = skip (1 - g) + r g with g = sigmoid(W r + b) (model.py:164-170).
+// Piece E of tile M's epilogue: y = acc[E] 2^-e + bias; the even piece of a pair parks its value in `carry`, the
+// odd one splits and stores the pair.  EPI_GATE: out = skip (1 - g) + r g, g = sigmoid(W r + b) (model.py:164-170).
 template <int EPI, int M, int E, int KS>
-__device__ __forceinline__ void epi_elem(const Acc& a, float inv_scale, Panel<KS>& out, const Panel<KS>& skip,
-                                         const Panel<KS>& rr, float& carry) {
-    float y = acc_elem<E>(a, inv_scale);
+__device__ __forceinline__ void epi_elem(const f32x16& acc, float inv_scale, float bias, Panel<KS>& out,
+                                         const Panel<KS>& skip, const Panel<KS>& rr, float& carry) {
+    float y = fmaf(acc[E], inv_scale, bias);
     if constexpr (EPI == EPI_RELU) y = fmaxf(y, 0.0f);
     if constexpr (EPI == EPI_GATE) {
         const float sk = get_elem<M, E>(skip), r = get_elem<M, E>(rr);
@@ -406,147 +419,250 @@ __device__ __forceinline__ void epi_elem(const Acc& a, float inv_scale, Panel<KS
         y = fmaf(gate, r - sk, sk);           // skip (1 - g) + r g, model.py:170
     }
     if constexpr (E % 2 == 0) carry = y;
-    else put_pair<M, E / 2>(out, carry, y);
+    else split_pair(carry, y, out.hi[2 * M + E / 8][(E % 8) / 2], out.lo[2 * M + E / 8][(E % 8) / 2]);
 }
 
 // the dense op's 2^-e (LDS aux image, float index IDX): wave-uniform
 template <int IDX>
 __device__ __forceinline__ float op_inv_scale(uint32_t aux_lds) {
-    uint32_t r;
-    asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(aux_lds), "n"(IDX * 4));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(r));
+    const float r = lds_read4_now<IDX * 4>(aux_lds);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, r)));
+}
+
+// the sixteen biases of a lane for one tile (rows 8 q + 4 h + 0..3, q = 0..3), read and waited for at once
+template <int BOFF>
+__device__ __forceinline__ void last_tile_bias(uint32_t bias_lds, float (&b)[16]) {
+    u32x4 r0 = lds_read16<(BOFF + 0) * 4>(bias_lds), r1 = lds_read16<(BOFF + 8) * 4>(bias_lds);
+    u32x4 r2 = lds_read16<(BOFF + 16) * 4>(bias_lds), r3 = lds_read16<(BOFF + 24) * 4>(bias_lds);
+    lds_wait(r0, r1, r2, r3);
+    const u32x4 r[4] = {r0, r1, r2, r3};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[4 * q + k] = __builtin_bit_cast(float, r[q][k]);
 }
 
 // A dense op: tiles M .. MT-1 of out = epi(W in + b).  Tile M-1's epilogue runs inside tile M's MFMA stream
-// (two accumulator sets in rotation); the last tile's runs after the op.
+// (two accumulators in rotation); the last tile's runs after the op.
 template <int KS, int KSIN, int MT, int F0, int FP, int BOFF, int EPI, int M = 0>
 __device__ __forceinline__ void dense_op(Stream& S, uint32_t bias_lds, float inv_scale, Frag& wa, Frag& wb,
                                          const Panel<KSIN>& in, Panel<KS>& out, const Panel<KS>& skip,
-                                         const Panel<KS>& rr, Acc (&acc)[2]) {
+                                         const Panel<KS>& rr, f32x16 (&acc)[2], u32x4& bias) {
+    constexpr bool AHEAD = KSIN >= 4;  // as tile_steps: biases requested a k-step ahead
     if constexpr (M < MT) {
+        constexpr int PM = M > 0 ? M - 1 : 0;
         float carry = 0.0f;
-        auto prev = [&](auto c) {
-            if constexpr (M > 0)
-                epi_elem<EPI, (M > 0 ? M - 1 : 0), decltype(c)::value>(acc[(M + 1) & 1], inv_scale, out, skip, rr, carry);
+        auto prev = [&](auto c, float b) {
+            constexpr int E = decltype(c)::value;
+            if constexpr (!AHEAD) b = lds_read4_now<(BOFF + 32 * PM + bias_row(E)) * 4>(bias_lds);
+            epi_elem<EPI, PM, E>(acc[(M + 1) & 1], inv_scale, b, out, skip, rr, carry);
         };
-        tile_mma<KSIN, F0 + M * 2 * KSIN, FP, BOFF + 16 * M>(S, bias_lds, wa, wb, in, acc[M & 1], prev);
-        dense_op<KS, KSIN, MT, F0, FP, BOFF, EPI, M + 1>(S, bias_lds, inv_scale, wa, wb, in, out, skip, rr, acc);
+        tile_mma<KSIN, F0 + M * 2 * KSIN, FP, BOFF + 32 * M, BOFF + 32 * PM, (M > 0)>(S, bias_lds, wa, wb, in,
+                                                                                       acc[M & 1], bias, prev);
+        dense_op<KS, KSIN, MT, F0, FP, BOFF, EPI, M + 1>(S, bias_lds, inv_scale, wa, wb, in, out, skip, rr, acc, bias);
     } else {
         __builtin_amdgcn_sched_barrier(0);
         float carry = 0.0f;
-        epi_elem<EPI, MT - 1, 0>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
-        epi_elem<EPI, MT - 1, 1>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
-        epi_elem<EPI, MT - 1, 2>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
-        epi_elem<EPI, MT - 1, 3>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
-        epi_elem<EPI, MT - 1, 4>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
-        epi_elem<EPI, MT - 1, 5>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
-        epi_elem<EPI, MT - 1, 6>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
-        epi_elem<EPI, MT - 1, 7>(acc[(MT - 1) & 1], inv_scale, out, skip, rr, carry);
+        float bl[16];
+        last_tile_bias<BOFF + 32 * (MT - 1)>(bias_lds, bl);
+        auto last = [&](auto c) {
+            constexpr int E = decltype(c)::value;
+            epi_elem<EPI, MT - 1, E>(acc[(MT - 1) & 1], inv_scale, bl[E], out, skip, rr, carry);
+        };
+        last(IC<0>{}); last(IC<1>{}); last(IC<2>{}); last(IC<3>{}); last(IC<4>{}); last(IC<5>{}); last(IC<6>{});
+        last(IC<7>{}); last(IC<8>{}); last(IC<9>{}); last(IC<10>{}); last(IC<11>{}); last(IC<12>{}); last(IC<13>{});
+        last(IC<14>{}); last(IC<15>{});
     }
 }
 
 struct FusedArgs {
     const float* x;     // [N][T]
     const uint4* img;   // fused weight image
-    const float* bias;  // bias image (floats)
+    const float* bias;  // bias image, then per-op scales (floats)
     float* q;           // [N][5]
     float* ls;          // [N][T] log sigma
     int64_t N;
     int T, se_idx, multi_norm;
+    unsigned long long* stamps;  // diagnostic builds only (QB_FUSED_STAMP): s_memtime at op boundaries
+    int* stamp_idx;
 };
+#ifdef QB_FUSED_STAMP
+#define QB_STAMP(a, k)                                                                              \
+    do {                                                                                            \
+        if ((a).stamps && blockIdx.x == 0 && threadIdx.x == 0) {                                    \
+            (a).stamps[(*(a).stamp_idx)++] = __builtin_amdgcn_s_memtime();                                 \
+        }                                                                                           \
+    } while (0)
+#else
+#define QB_STAMP(a, k) do {} while (0)
+#endif
 
-// Piece E (= 4 vt + r) of head tile M: tiles 0 .. TT-1 are log-sigma rows 16 M + 4 g + r, tile TT holds the
-// five q rows.  Even pieces park their value, odd ones store the pair.
-template <int TT, int M, int E>
-__device__ __forceinline__ void head_elem(const Acc& acc, float inv_scale, const FusedArgs& a, const int64_t (&v)[2],
-                                          int g, float& carry) {
-    constexpr int vt = E / 4, d = (E % 4) / 2;
-    const float y = acc_elem<E>(acc, inv_scale);
-    if constexpr (E % 2 == 0) {
-        carry = y;
-        return;
-    }
-    const float y0 = carry, y1 = y;
-    if (v[vt] >= a.N) return;
-    if constexpr (M < TT) {
-        const int row = 16 * M + 4 * g + 2 * d;
-        float* dst = a.ls + v[vt] * a.T + row;
-        if ((a.T & 1) == 0 && row + 1 < a.T) {
-            *reinterpret_cast<float2*>(dst) = make_float2(y0, y1);
+// Raw signals of this lane's voxel for the first layer's B operand: k-step s, lane half h holds taus
+// 16 s + 8 h .. + 7; plus the images the normaliser needs (model.py:102-106).
+template <int KS1>
+struct XRaw {
+    float f[KS1][8];
+    float d[3];
+};
+template <int KS1>
+__device__ __forceinline__ void load_x(const FusedArgs& a, int64_t v, int h, XRaw<KS1>& xr) {
+    // opaque: keeps the address arithmetic here, at the loads -- hoisted out of the pass loop its pieces sit in
+    // registers through the whole pass, where three panels leave none to spare
+    asm volatile("" : "+v"(v), "+v"(h));
+    const int64_t vc = v < a.N ? v : a.N - 1;  // clamp: every lane takes part in the MFMAs (a.N >= 1)
+    const float* xv = a.x + vc * a.T;
+    const int se = a.se_idx;
+    xr.d[1] = xv[se];
+    xr.d[0] = xv[se > 0 ? se - 1 : 0];
+    xr.d[2] = xv[se + 1 < a.T ? se + 1 : se];
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) {
+        const int t0 = 16 * s + 8 * h;
+        if ((a.T & 3) == 0 && a.T >= 8) {  // wave-uniform
+            const int tc = t0 + 8 <= a.T ? t0 : a.T - 8;  // clamped: values past the row are masked in convert_x
+            const float4 lo4 = *reinterpret_cast<const float4*>(xv + tc);
+            const float4 hi4 = *reinterpret_cast<const float4*>(xv + tc + 4);
+            xr.f[s][0] = lo4.x; xr.f[s][1] = lo4.y; xr.f[s][2] = lo4.z; xr.f[s][3] = lo4.w;
+            xr.f[s][4] = hi4.x; xr.f[s][5] = hi4.y; xr.f[s][6] = hi4.z; xr.f[s][7] = hi4.w;
         } else {
-            if (row < a.T) dst[0] = y0;
-            if (row + 1 < a.T) dst[1] = y1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xr.f[s][j] = xv[t0 + j < a.T ? t0 + j : a.T - 1];
         }
-    } else {
-        const int row = 4 * g + 2 * d;
-        if (row < 5) a.q[v[vt] * 5 + row] = y0;
-        if (row + 1 < 5) a.q[v[vt] * 5 + row + 1] = y1;
     }
 }
-template <int KS, int TT, int F0, int FP, int BOFF, int M = 0>
+// normalise_data (model.py:97-113) and the split into B operands
+template <int KS1>
+__device__ __forceinline__ void convert_x(const FusedArgs& a, int h, const XRaw<KS1>& xr, Panel<KS1>& X) {
+    float den = qb::clampf_(xr.d[1], 1e-2f, 1e8f);
+    if (a.multi_norm) den = (qb::clampf_(xr.d[0], 1e-2f, 1e8f) + den + qb::clampf_(xr.d[2], 1e-2f, 1e8f)) / 3.0f;
+    const bool wide_rows = (a.T & 3) == 0 && a.T >= 8;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) {
+        const int t0 = 16 * s + 8 * h;
+        const bool whole = !wide_rows || t0 + 8 <= a.T;  // else the clamped load fetched other taus
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            f[j] = (whole && t0 + j < a.T) ? logf(qb::clampf_(xr.f[s][j], 1e-2f, 1e8f) / den) : 0.0f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) split_pair(f[2 * d], f[2 * d + 1], X.hi[s][d], X.lo[s][d]);
+    }
+}
+
+// Where a pass's head outputs go: raw buffer resources over this pass's voxels only, so that the hardware drops
+// the stores of lanes beyond the batch (their offsets lie outside the resource) -- no branch in the epilogue
+// pieces, which therefore stay inside the MFMA stream's scheduling regions.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct HeadOut {
+    __amdgpu_buffer_rsrc_t ls, q;
+    uint32_t ls_off, q_off;  // byte offsets of this lane's voxel inside the pass
+    int T;
+};
+#define QB_OOB 0x7ffffff0u  // beyond any resource: a dropped store
+// Piece E of head tile M: tiles 0 .. LT-1 are log-sigma rows 32 M + 8 (E >> 2) + 4 h + (E & 3), tile LT holds the
+// five q rows.
+template <int LT, int M, int E>
+__device__ __forceinline__ void head_elem(const f32x16& acc, float inv_scale, float bias, const HeadOut& o, int h) {
+    const float y = fmaf(acc[E], inv_scale, bias);
+    const int row_in_tile = 8 * (E >> 2) + 4 * h + (E & 3);
+    if constexpr (M < LT) {
+        const int row = 32 * M + row_in_tile;
+        const uint32_t off = row < o.T ? o.ls_off + 4u * row : QB_OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), o.ls, off, 0, 0);
+    } else if constexpr (E < 4) {  // rows 0-3 (h = 0) and 4 (h = 1, E = 0); registers 4 .. 15 hold padding rows
+        const uint32_t off = row_in_tile < 5 ? o.q_off + 4u * row_in_tile : QB_OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), o.q, off, 0, 0);
+    }
+}
+template <int KS, int LT, int F0, int FP, int BOFF, int M = 0>
 __device__ __forceinline__ void head_op(Stream& S, uint32_t bias_lds, float inv_scale, Frag& wa, Frag& wb,
-                                        const Panel<KS>& b, const FusedArgs& a, const int64_t (&v)[2], int g,
-                                        Acc (&acc)[2]) {
-    if constexpr (M <= TT) {
-        float carry = 0.0f;
-        auto prev = [&](auto c) {
-            if constexpr (M > 0)
-                head_elem<TT, (M > 0 ? M - 1 : 0), decltype(c)::value>(acc[(M + 1) & 1], inv_scale, a, v, g, carry);
+                                        const Panel<KS>& b, const HeadOut& o, int h, f32x16 (&acc)[2], u32x4& bias) {
+    if constexpr (M <= LT) {
+        constexpr int PM = M > 0 ? M - 1 : 0;
+        auto prev = [&](auto c, float bb) {
+            head_elem<LT, PM, decltype(c)::value>(acc[(M + 1) & 1], inv_scale, bb, o, h);
         };
-        tile_mma<KS, F0 + M * 2 * KS, FP, BOFF + 16 * M>(S, bias_lds, wa, wb, b, acc[M & 1], prev);
-        head_op<KS, TT, F0, FP, BOFF, M + 1>(S, bias_lds, inv_scale, wa, wb, b, a, v, g, acc);
+        tile_mma<KS, F0 + M * 2 * KS, FP, BOFF + 32 * M, BOFF + 32 * PM, (M > 0)>(S, bias_lds, wa, wb, b, acc[M & 1],
+                                                                                   bias, prev);
+        head_op<KS, LT, F0, FP, BOFF, M + 1>(S, bias_lds, inv_scale, wa, wb, b, o, h, acc, bias);
     } else {
         __builtin_amdgcn_sched_barrier(0);
-        float carry = 0.0f;
-        head_elem<TT, TT, 0>(acc[TT & 1], inv_scale, a, v, g, carry);
-        head_elem<TT, TT, 1>(acc[TT & 1], inv_scale, a, v, g, carry);
-        head_elem<TT, TT, 2>(acc[TT & 1], inv_scale, a, v, g, carry);
-        head_elem<TT, TT, 3>(acc[TT & 1], inv_scale, a, v, g, carry);
-        head_elem<TT, TT, 4>(acc[TT & 1], inv_scale, a, v, g, carry);
-        head_elem<TT, TT, 5>(acc[TT & 1], inv_scale, a, v, g, carry);
-        head_elem<TT, TT, 6>(acc[TT & 1], inv_scale, a, v, g, carry);
-        head_elem<TT, TT, 7>(acc[TT & 1], inv_scale, a, v, g, carry);
+        float bl[16];
+        last_tile_bias<BOFF + 32 * LT>(bias_lds, bl);
+        auto last = [&](auto c) {
+            constexpr int E = decltype(c)::value;
+            head_elem<LT, LT, E>(acc[LT & 1], inv_scale, bl[E], o, h);
+        };
+        last(IC<0>{}); last(IC<1>{}); last(IC<2>{}); last(IC<3>{}); last(IC<4>{}); last(IC<5>{}); last(IC<6>{});
+        last(IC<7>{}); last(IC<8>{}); last(IC<9>{}); last(IC<10>{}); last(IC<11>{}); last(IC<12>{}); last(IC<13>{});
+        last(IC<14>{}); last(IC<15>{});
     }
 }
 
 // Gated residual blocks LB .. L-1 (model.py:147-172): b comes in P0 and leaves in P1; the panels rotate by
 // name from block to block, nothing is copied.  SC0: float index of the first block op's 2^-e in the aux image.
-template <int KS, int MT, int L, int TT, int FB0, int FP, int SC0, int LB>
+template <int KS, int KS1, int MT, int L, int LT, int FB0, int FP, int SC0, int LB>
 __device__ __forceinline__ void blocks_and_head(Stream& S, uint32_t bias_lds, uint32_t aux_lds, Frag& wa, Frag& wb,
                                                 Panel<KS>& P0, Panel<KS>& P1, Panel<KS>& P2, const FusedArgs& a,
-                                                const int64_t (&v)[2], int g, Acc (&acc)[2]) {
+                                                int64_t v, int64_t v_next, int h, f32x16 (&acc)[2], u32x4& bias,
+                                                XRaw<KS1>& xr) {
     constexpr int FOP = MT * KS * 2;  // fragments per dense op
-    constexpr int U = 16 * MT;
+    constexpr int U = 32 * MT;
     if constexpr (LB < L) {
         constexpr int F = FB0 + LB * 4 * FOP, B = U + LB * 4 * U, SC = SC0 + 8 * LB;
-        dense_op<KS, KS, MT, F, FP, B, EPI_RELU>(S, bias_lds, op_inv_scale<SC>(aux_lds), wa, wb, P0, P2, P2, P2,
-                                                 acc);                                             // skip, :148
+        dense_op<KS, KS, MT, F, FP, B, EPI_RELU>(S, bias_lds, op_inv_scale<SC>(aux_lds), wa, wb, P0, P2, P2, P2, acc,
+                                                 bias);                                            // skip, :148
+        QB_STAMP(a, 0);
         if constexpr (LB > 0) relu_panel(P0);  // block 0's input is a relu output already            :151
         dense_op<KS, KS, MT, F + FOP, FP, B + U, EPI_RELU>(S, bias_lds, op_inv_scale<SC + 2>(aux_lds), wa, wb, P0, P1,
-                                                           P1, P1, acc);                            // t, :152-155
+                                                           P1, P1, acc, bias);                      // t, :152-155
+        QB_STAMP(a, 1);
         dense_op<KS, KS, MT, F + 2 * FOP, FP, B + 2 * U, EPI_LINEAR>(S, bias_lds, op_inv_scale<SC + 4>(aux_lds), wa, wb,
-                                                                     P1, P0, P0, P0, acc);          // r, :156
+                                                                     P1, P0, P0, P0, acc, bias);    // r, :156
+        QB_STAMP(a, 2);
         dense_op<KS, KS, MT, F + 3 * FOP, FP, B + 3 * U, EPI_GATE>(S, bias_lds, op_inv_scale<SC + 6>(aux_lds), wa, wb,
-                                                                   P0, P1, P2, P0, acc);            // :164-170
-        blocks_and_head<KS, MT, L, TT, FB0, FP, SC0, LB + 1>(S, bias_lds, aux_lds, wa, wb, P1, P0, P2, a, v, g, acc);
+                                                                   P0, P1, P2, P0, acc, bias);      // :164-170
+        QB_STAMP(a, 3);
+        blocks_and_head<KS, KS1, MT, L, LT, FB0, FP, SC0, LB + 1>(S, bias_lds, aux_lds, wa, wb, P1, P0, P2, a, v, v_next,
+                                                                  h, acc, bias, xr);
     } else {
-        head_op<KS, TT, FB0 + L * 4 * FOP, FP, U + L * 4 * U>(S, bias_lds, op_inv_scale<SC0 + 8 * L>(aux_lds), wa, wb,
-                                                              P0, a, v, g, acc);
+        load_x<KS1>(a, v_next, h, xr);  // the next pass's signals (clamped beyond the batch: then unused)
+        HeadOut o;
+        {
+            const int64_t v0 = __builtin_amdgcn_readfirstlane((int)(v >> 7)) * (int64_t)kVoxPerPass;  // pass's first voxel
+            const int64_t left = a.N - v0;
+            const uint32_t nv = (uint32_t)(left < kVoxPerPass ? left : kVoxPerPass);
+            o.ls = __builtin_amdgcn_make_buffer_rsrc(a.ls + v0 * a.T, 0, nv * (uint32_t)a.T * 4u, 0x00020000);
+            o.q = __builtin_amdgcn_make_buffer_rsrc(a.q + v0 * 5, 0, nv * 20u, 0x00020000);
+            const uint32_t local = (uint32_t)(v - v0);
+            o.ls_off = local * (uint32_t)a.T * 4u;
+            o.q_off = local * 20u;
+            o.T = a.T;
+        }
+        head_op<KS, LT, FB0 + L * 4 * FOP, FP, U + L * 4 * U>(S, bias_lds, op_inv_scale<SC0 + 8 * L>(aux_lds), wa, wb,
+                                                              P0, o, h, acc, bias);
+        QB_STAMP(a, 4);
     }
 }
 
+// TT: first-layer k-steps (ceil(T / 16): 1 or 4)
 template <int TT, int L>
 __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
-    constexpr int U = 256, KS = U / 32, MT = U / 16, KS1 = (TT + 1) / 2;
-    constexpr FusedLayout fl = make_fused_layout(16 * TT, U, L);  // T only pads inside its 16-row tile
+#ifdef QB_FUSED_STAMP
+    int stamp_counter = 0;
+    a.stamp_idx = &stamp_counter;
+#endif
+    constexpr int U = 256, KS = U / 16, MT = U / 32, KS1 = TT, LT = (TT + 1) / 2;
+    constexpr FusedLayout fl = make_fused_layout(16 * TT, U, L);  // T only pads inside its tile
     constexpr int FP = fl.frags_pass;
     static_assert(FP % kStageFrags == 0, "a pass is a whole number of stages");
+    static_assert(fl.KS1 == KS1 && fl.LT == LT, "layout and kernel agree on the tile counts");
     extern __shared__ __align__(16) uint4 smem[];
     uint4* ring = smem;                                                      // [kRing][16][64]
-    float* lbias = reinterpret_cast<float*>(smem + kRing * kStageFrags * 64);  // [bias_total]
+    float* lbias = reinterpret_cast<float*>(smem + kRing * kStageFrags * 64);  // biases, then per-op scales
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, i = lane & 15;
-    for (int k = threadIdx.x; k < fl.aux_floats; k += kFB) lbias[k] = a.bias[k];  // biases, then per-op scales
+    const int h = lane >> 5, i = lane & 31;
+    for (int k = threadIdx.x; k < fl.aux_floats; k += kFB) lbias[k] = a.bias[k];
 
     Stream S;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -559,7 +675,7 @@ __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
     S.issue_slot = 0;
     S.read_slot = 0;
     S.pass_bytes = (uint32_t)fl.stages_pass * kStageFrags * 1024;
-    const uint32_t bias_lds = lds_addr(lbias) + 16u * g;
+    const uint32_t bias_lds = lds_addr(lbias) + 16u * h;  // rows 4 h .. 4 h + 3 of every group of eight
     const uint32_t aux_lds = lds_addr(lbias);
     constexpr int SC0 = fl.scale_off + 1;  // float index of the first layer's 2^-e; op k's is SC0 + 2 k
 #pragma unroll
@@ -572,51 +688,29 @@ __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
     wb.hi = lds_read16<2048>(S.cur);
     wb.lo = lds_read16<3072>(S.cur);
     lds_wait(wa.hi, wa.lo, wb.hi, wb.lo);
+    u32x4 bias = {0u, 0u, 0u, 0u};  // biases of the next step's epilogue pieces (requested one step ahead)
 
+    // The signals of a pass are requested one pass ahead, at the start of the previous pass's head op (one panel
+    // live, registers to spare, ~2 us of matrix work to cover the HBM latency): branch-free loads with clamped
+    // addresses, so that the compiler can count them (a load behind a branch made it wait for vmcnt(0), i.e.
+    // for every LDS-direct load in flight as well -- ten times per pass).
     const int64_t nblk = (a.N + kVoxPerPass - 1) / kVoxPerPass;
+    XRaw<KS1> xr;
+    load_x<KS1>(a, (int64_t)blockIdx.x * kVoxPerPass + wave * 32 + i, h, xr);
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        int64_t v[2];
+        const int64_t v = blk * kVoxPerPass + wave * 32 + i;
         Panel<KS1> X;
-#pragma unroll
-        for (int vt = 0; vt < 2; ++vt) {
-            v[vt] = blk * kVoxPerPass + wave * 32 + vt * 16 + i;
-            const int64_t vc = v[vt] < a.N ? v[vt] : a.N - 1;  // clamp: every lane takes part in the MFMAs
-            const float* xv = a.x + vc * a.T;
-            float den;                                          // normalise_data, model.py:97-113
-            if (a.multi_norm)
-                den = (qb::clampf_(xv[a.se_idx - 1], 1e-2f, 1e8f) + qb::clampf_(xv[a.se_idx], 1e-2f, 1e8f) +
-                       qb::clampf_(xv[a.se_idx + 1], 1e-2f, 1e8f)) / 3.0f;
-            else
-                den = qb::clampf_(xv[a.se_idx], 1e-2f, 1e8f);
-#pragma unroll
-            for (int s = 0; s < KS1; ++s) {
-                float f[8];
-                const int t0 = 32 * s + 8 * g;
-                if ((a.T & 3) == 0) {
-                    const float4 lo4 = t0 + 3 < a.T ? *reinterpret_cast<const float4*>(xv + t0) : make_float4(0, 0, 0, 0);
-                    const float4 hi4 =
-                        t0 + 7 < a.T ? *reinterpret_cast<const float4*>(xv + t0 + 4) : make_float4(0, 0, 0, 0);
-                    f[0] = lo4.x; f[1] = lo4.y; f[2] = lo4.z; f[3] = lo4.w;
-                    f[4] = hi4.x; f[5] = hi4.y; f[6] = hi4.z; f[7] = hi4.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) f[j] = t0 + j < a.T ? xv[t0 + j] : 0.0f;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    f[j] = t0 + j < a.T ? logf(qb::clampf_(f[j], 1e-2f, 1e8f) / den) : 0.0f;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    split_pair(f[2 * d], f[2 * d + 1], X.hi[s][vt][d], X.lo[s][vt][d]);
-                }
-            }
-        }
+        QB_STAMP(a, 5);
+        convert_x<KS1>(a, h, xr, X);
+        QB_STAMP(a, 6);
         Panel<KS> P0, P1, P2;
-        Acc acc[2];
-        dense_op<KS, KS1, MT, 0, FP, 0, EPI_RELU>(S, bias_lds, op_inv_scale<SC0>(aux_lds), wa, wb, X, P0, P0, P0,
-                                                  acc);  // first layer, model.py:181
-        blocks_and_head<KS, MT, L, TT, MT * KS1 * 2, FP, SC0 + 2, 0>(S, bias_lds, aux_lds, wa, wb, P0, P1, P2, a, v, g,
-                                                                     acc);
+        f32x16 acc[2];
+        dense_op<KS, KS1, MT, 0, FP, 0, EPI_RELU>(S, bias_lds, op_inv_scale<SC0>(aux_lds), wa, wb, X, P0, P0, P0, acc,
+                                                  bias);  // first layer, model.py:181
+        QB_STAMP(a, 7);
+        blocks_and_head<KS, KS1, MT, L, LT, MT * KS1 * 2, FP, SC0 + 2, 0>(S, bias_lds, aux_lds, wa, wb, P0, P1, P2, a, v,
+                                                                          v + (int64_t)gridDim.x * kVoxPerPass, h, acc,
+                                                                          bias, xr);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-direct load may land after the block has gone
 }
@@ -639,6 +733,11 @@ int wide_fused_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const
     a.T = shape->T;
     a.se_idx = ctx->dev.se_idx;
     a.multi_norm = ctx->dev.multi_norm;
+    a.stamps = nullptr;
+    a.stamp_idx = nullptr;
+#ifdef QB_FUSED_STAMP
+    if (const char* p = getenv("QBOLD_FUSED_STAMPS")) a.stamps = reinterpret_cast<unsigned long long*>(strtoull(p, nullptr, 0));
+#endif
     const size_t smem = sizeof(uint4) * kRing * kStageFrags * 64 + sizeof(float) * fl.aux_floats;
     const int64_t nblk = (N + kVoxPerPass - 1) / kVoxPerPass;
     const int grid = (int)(nblk < ctx->num_cus ? nblk : ctx->num_cus);
@@ -650,12 +749,12 @@ int wide_fused_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const
         hipLaunchKernelGGL(k, dim3(grid), dim3(kFB), smem, s, a);                                            \
     } while (0)
 #ifndef QB_FUSED_DEV
-    if (fl.TT == 1 && shape->L == 1) QB_LAUNCH_FUSED(1, 1);
-    else if (fl.TT == 1 && shape->L == 2) QB_LAUNCH_FUSED(1, 2);
-    else if (fl.TT == 4 && shape->L == 1) QB_LAUNCH_FUSED(4, 1);
+    if (fl.KS1 == 1 && shape->L == 1) QB_LAUNCH_FUSED(1, 1);
+    else if (fl.KS1 == 1 && shape->L == 2) QB_LAUNCH_FUSED(1, 2);
+    else if (fl.KS1 == 4 && shape->L == 1) QB_LAUNCH_FUSED(4, 1);
     else
 #endif
-    if (fl.TT == 4 && shape->L == 2) QB_LAUNCH_FUSED(4, 2);
+    if (fl.KS1 == 4 && shape->L == 2) QB_LAUNCH_FUSED(4, 2);
     else {
         qb::set_error("wide_fused_fwd: shape not instantiated");
         return QBOLD_ERR_UNSUPPORTED;
@@ -692,7 +791,7 @@ extern "C" int qbold_encoder_fused_pack(const qbold_ctx* ctx, const qbold_encode
         float* scale = packed + fl.img_floats + fl.scale_off + 2 * op;
         hipLaunchKernelGGL(fused_scale_kernel, dim3(1), dim3(256), 0, s, W, (int64_t)nin * nout, W2,
                            W2 ? (int64_t)nin * nout2 : 0, scale);
-        const int64_t n = (int64_t)MT * KS * 2 * 512 + 16 * MT;
+        const int64_t n = (int64_t)MT * KS * 2 * 512 + 32 * MT;
         hipLaunchKernelGGL(fused_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, frag, KS, MT, korder,
                            W, b, nin, nout, W2, b2, nout2, split_row, add, bias_off, scale, fl.img_floats, packed);
         frag += MT * KS * 2;
@@ -708,7 +807,7 @@ extern "C" int qbold_encoder_fused_pack(const qbold_ctx* ctx, const qbold_encode
         pack(fl.KS, fl.MT, 1, wb + c.Wr2 + ctr, wb + c.br2, U, U, nullptr, nullptr, 0, 0, 0.0f, b0 + 2 * U);
         pack(fl.KS, fl.MT, 1, wb + c.Wg, wb + c.bg, U, U, nullptr, nullptr, 0, 0, shape->gate_offset, b0 + 3 * U);
     }
-    pack(fl.KS, fl.HT, 1, weights + c.Ws, weights + c.bs, U, T, weights + c.Wf, weights + c.bf, 5, 16 * fl.TT, 0.0f,
+    pack(fl.KS, fl.HT, 1, weights + c.Ws, weights + c.bs, U, T, weights + c.Wf, weights + c.bf, 5, 32 * fl.LT, 0.0f,
          fl.bias_head);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;

@@ -3,9 +3,14 @@ canonical tensor names of this package.
 
 h5py is NOT a dependency of this package (it is absent from the build image), so this module
 imports it lazily and says so when it is missing; `.npz` with the canonical names stays the native
-format.  The mapping follows the layout Keras 2.x writes for the reference's model and goes by ORDER
-AND SHAPE, not by layer names (Keras numbers `conv3d_<n>` by creation order in the process, so the
-names shift when several models were built):
+format.  The reference creates its Conv3D layers in one fixed order (model.py:122-223: first 1x1x1 conv; per
+create_block call the shared 1x1x1 conv, two 3x3x1 convs, the gating conv; then the final layer and the sigma
+head) and Keras numbers them `conv3d`, `conv3d_1`, ... in CREATION order, whereas the order in which a
+Functional model's variables are WRITTEN follows graph depth (a block's 3x3x1 kernels come before its 1x1x1
+ones).  So variables are first paired (kernel, bias) per layer and sorted by the layer's creation number (the
+numbers shift by a constant when several models were built in one process: only their order is used); files
+whose names carry no number fall back to roles by shape inside each block (3x3x1 kernels are Wr1 then Wr2, of
+the 1x1x1 kernels the first is the shared conv, the other the gate).  What Keras 2.x writes:
 
   root.attrs['layer_names']  -> the outer model's layers in order: input, lambda (normalise_data),
       the first 1x1x1 conv, the inner functional model, the sigma-head conv (model.py:176-222)
@@ -37,14 +42,80 @@ def _names(attr):
     return [n.decode("utf8") if isinstance(n, (bytes, np.bytes_)) else str(n) for n in attr]
 
 
-def flatten_variables(f):
-    """All variables of a Keras weights file (an open h5py.File or anything with the same mapping /
-    .attrs interface) in layer order, as float32 arrays."""
+def _named_variables(f):
     out = []
     for layer in _names(f.attrs["layer_names"]):
         g = f[layer]
         for w in _names(g.attrs.get("weight_names", [])):
-            out.append(np.asarray(g[w], dtype=np.float32))
+            out.append((w, np.asarray(g[w], dtype=np.float32)))
+    return out
+
+
+def _creation_number(weight_name):
+    """'model/conv3d_7/kernel:0' -> 7, 'conv3d/bias:0' -> 0; None when the layer name carries no number."""
+    import re
+    parts = weight_name.split("/")
+    layer = parts[-2] if len(parts) >= 2 else ""
+    m = re.fullmatch(r"(?:.*?)conv3d(?:_(\d+))?", layer)
+    if not m:
+        return None
+    return int(m.group(1)) if m.group(1) else 0
+
+
+def _pair_layers(named):
+    """[(weight name, array)] in file order -> [(kernel, bias)] per layer, in file order."""
+    layers, index = [], {}
+    for name, a in named:
+        key = name.rsplit("/", 1)[0]
+        if key not in index:
+            index[key] = len(layers)
+            layers.append([key, None, None])
+        slot = 1 if a.ndim == 5 else 2
+        if layers[index[key]][slot] is not None:
+            raise ValueError(f"layer {key!r} has two variables of the same rank")
+        layers[index[key]][slot] = a
+    for key, k, b in layers:
+        if k is None or b is None:
+            raise ValueError(f"layer {key!r} does not hold one Conv3D kernel and one bias")
+    return layers
+
+
+def _by_roles(layers):
+    """File order (graph depth) -> creation order, by kernel shape inside each block: the outer model's first
+    conv and sigma head are the first and last layers; the inner model holds 4 L block layers + the final one."""
+    first, last, inner = layers[0], layers[-1], layers[1:-1]
+    final = [l for l in inner if l[1].shape[:2] == (1, 1) and l[1].shape[-1] in (4, 5) and l[1].shape[-1] != l[1].shape[-2]]
+    if len(final) != 1:
+        raise ValueError("cannot tell the final layer from the block layers by shape")
+    body = [l for l in inner if l is not final[0]]
+    if len(body) % 4:
+        raise ValueError(f"{len(body)} block layers are not four per block")
+    L = len(body) // 4
+    k3 = [l for l in body if l[1].shape[:2] == (3, 3)]
+    k1 = [l for l in body if l[1].shape[:2] == (1, 1)]
+    if len(k3) != 2 * L or len(k1) != 2 * L:
+        raise ValueError("a block needs two 3x3x1 and two 1x1x1 kernels")
+    out = [first]
+    for l in range(L):
+        shared, gate = k1[2 * l], k1[2 * l + 1]
+        if shared[1].shape[-1] != shared[1].shape[-2] and gate[1].shape[-1] == gate[1].shape[-2]:
+            shared, gate = gate, shared   # shared gating has one output: it cannot be the U -> U conv
+        out += [shared, k3[2 * l], k3[2 * l + 1], gate]
+    return out + [final[0], last]
+
+
+def flatten_variables(f):
+    """All variables of a Keras weights file (an open h5py.File or anything with the same mapping /
+    .attrs interface) as float32 arrays in the reference's layer CREATION order, kernel before bias."""
+    layers = _pair_layers(_named_variables(f))
+    numbers = [_creation_number(key + "/kernel:0") for key, _, _ in layers]
+    if all(n is not None for n in numbers) and len(set(numbers)) == len(numbers):
+        layers = [l for _, l in sorted(zip(numbers, layers), key=lambda t: t[0])]
+    else:
+        layers = _by_roles(layers)
+    out = []
+    for _, k, b in layers:
+        out += [k, b]
     return out
 
 

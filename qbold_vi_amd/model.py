@@ -439,9 +439,11 @@ class EncoderTrainer:
         return (tv[0] / mask.sum()).float()
 
     def estimate_population_param_distribution(self, model, data):
-        """model.py:756-770: masked population mean / std of the predicted OEF and DBV logits
-        (first head), printed and returned as (mean_oef, log_std_oef, mean_dbv, log_std_dbv)."""
-        predictions = model.predict(data[..., :-1] * data[..., -1:], want=("out1",))[0]
+        """model.py:756-770: masked population mean / std of the predicted OEF and DBV logits of the SECOND
+        output (`_, predictions, _ = model.predict(...)`, model.py:757: the stream-2 / fine-tuned head, which
+        sees the 3x3x1 context on volumes), printed and returned as (mean_oef, log_std_oef, mean_dbv,
+        log_std_dbv)."""
+        predictions = model.predict(data[..., :-1] * data[..., -1:], want=("out2",))[0]
         mask = data[..., -1:]
         oef, dbv = predictions[..., 0:1] * mask, predictions[..., 2:3] * mask
         mask_pix = mask.sum()

@@ -35,6 +35,15 @@ def make_header(shape, dtype, template=None):
         if len(template) < HEADER_BYTES or struct.unpack_from("<i", template, 0)[0] != HEADER_BYTES:
             raise ValueError("template is not a little-endian NIfTI-1 header")
         h = bytearray(template[:HEADER_BYTES])
+        # only the geometry is inherited (pixdim, qform / sform, xyzt_units): the template's intensity scaling
+        # and display window describe ITS voxel values (e.g. a scaled int16 scan) and would rescale the float
+        # maps written under it in every reader -- nibabel's Nifti1Image(arr, None, header=hdr) resets them too
+        struct.pack_into("<f", h, 112, 1.0)                               # scl_slope
+        struct.pack_into("<f", h, 116, 0.0)                               # scl_inter
+        struct.pack_into("<ff", h, 124, 0.0, 0.0)                         # cal_max, cal_min
+        struct.pack_into("<h", h, 68, 0)                                  # intent_code
+        struct.pack_into("<3f", h, 56, 0.0, 0.0, 0.0)                     # intent_p1..p3
+        h[148:228] = b"\0" * 80                                           # descrip
     else:
         h = bytearray(HEADER_BYTES)
         struct.pack_into("<i", h, 0, HEADER_BYTES)                       # sizeof_hdr

@@ -37,6 +37,17 @@ def _f32(t, name, shape_last=None):
     return t
 
 
+def merge_ranges(pieces):
+    """Sorted [offset, length] pieces with touching neighbours merged."""
+    out = []
+    for off, n in sorted(pieces):
+        if out and out[-1][0] + out[-1][1] == off:
+            out[-1][1] += n
+        else:
+            out.append([off, n])
+    return [tuple(r) for r in out]
+
+
 class EncoderWeights:
     """The canonical (Keras-orientation) weight blob of the voxel-wise encoder plus its
     MFMA-ordered device copy.  Layout: include/qbold_hip.h, qbold_encoder_num_params."""
@@ -117,6 +128,15 @@ class EncoderWeights:
 
     def mark_dirty(self):
         self._dirty = {"packed", "wide", "fused"}
+
+    # the tensors stream 1 (the pre-training output, model.py:199) depends on; every other variable gets a None
+    # gradient from Keras' loss=[synthetic_data_loss, None, None] (train.py:388-392) and is left alone by
+    # apply_gradients -- no Adam update AND no decoupled weight decay
+    STREAM1_TENSORS = ("W0", "b0", "Wc", "bc", "Wf", "bf")
+
+    def param_ranges(self, names):
+        """Merged, sorted [offset, length] ranges of the named tensors inside the canonical blob."""
+        return merge_ranges([(off, int(np.prod(shape))) for n in names for off, shape in self._slices()[n]])
 
     def set_precision(self, precision):
         """'f32' (split-f16 MFMA, float32-grade) or 'bf16' (single bf16 MFMA pass) for the fused
@@ -684,13 +704,18 @@ class TrainState:
                    "qbold_synth_loss_bwd")
         return lv, gq
 
-    def adamw(self, lr, weight_decay, beta1=0.9, beta2=0.999, eps=1e-7):
+    def adamw(self, lr, weight_decay, beta1=0.9, beta2=0.999, eps=1e-7, ranges=None):
+        """One AdamW step.  ranges: [(offset, length)] of the canonical blob that received a gradient in this
+        phase (EncoderWeights.param_ranges); parameters outside them are not touched -- neither the Adam update
+        nor the weight decay -- as Keras / tfa leave variables whose gradient is None."""
         self.step += 1
-        _lib.check(self.ctx.lib.qbold_adamw_step(self.ctx.handle, _ptr(self.weights.flat), _ptr(self.grad),
-                                                 _ptr(self.m), _ptr(self.v), self.weights.num_params,
-                                                 float(lr), float(beta1), float(beta2), float(eps),
-                                                 float(weight_decay), self.step, _stream()),
-                   "qbold_adamw_step")
+        w = self.weights.flat
+        for off, n in (ranges if ranges is not None else [(0, self.weights.num_params)]):
+            _lib.check(self.ctx.lib.qbold_adamw_step(self.ctx.handle, _ptr(w[off:off + n]), _ptr(self.grad[off:off + n]),
+                                                     _ptr(self.m[off:off + n]), _ptr(self.v[off:off + n]), int(n),
+                                                     float(lr), float(beta1), float(beta2), float(eps),
+                                                     float(weight_decay), self.step, _stream()),
+                       "qbold_adamw_step")
         self.weights.mark_dirty()
 
 

@@ -60,10 +60,13 @@ def get_params(path="config"):
 
 
 def _existing_weights(save_dir, stem):
-    """<save_dir>/<stem>.npz (native), or the reference's Keras <stem>.h5 when only that exists
-    (qbold_build_model.py:29-33; read through keras_h5.py, which needs h5py).  New files are .npz."""
+    """<save_dir>/<stem>.npz (native).  The reference's Keras <stem>.h5 (qbold_build_model.py:29-33) is read
+    through keras_h5.py only on request -- QBOLD_KERAS_H5=1 -- because that mapping has never met a real Keras
+    file (no h5py, no TensorFlow, no shipped weights here): experimental until it has."""
     npz, h5 = os.path.join(save_dir, stem + ".npz"), os.path.join(save_dir, stem + ".h5")
-    return h5 if (os.path.isfile(h5) and not os.path.isfile(npz)) else npz
+    if os.environ.get("QBOLD_KERAS_H5") == "1" and os.path.isfile(h5) and not os.path.isfile(npz):
+        return h5
+    return npz
 
 
 def create_encoder_model(config_dict, params, device=None):
@@ -147,6 +150,9 @@ def create_and_train_on_synthetic_data(config_dict, params, log=None, sample_siz
                                     sample_size=sample_size, device=device)
     (tx, ty), (vx, vy), batch = prepare_synthetic_dataset(x, y)
     state = TrainState(trainer.context, model.weights)
+    # only the tensors stream 1 runs through receive a gradient here; the stream-2-only ones (residual and
+    # gating convolutions, sigma head) are neither updated nor decayed (their Keras gradient is None)
+    pt_ranges = model.weights.param_ranges(model.weights.STREAM1_TENSORS)
     lr = float(_get(config_dict, "pt_lr"))
     # AdamW(weight_decay=pt_adamw_decay) wrapped in SWA whose averages are never swapped in
     # (train.py:382-385); plain Adam without decay when use_swa is off.
@@ -175,7 +181,7 @@ def create_and_train_on_synthetic_data(config_dict, params, log=None, sample_siz
                 lv = lv - 1.8378770664093453
             state.backward(1, gq)
             qd.allreduce_mean_(state.grad)
-            state.adamw(lr, wd, 0.9, 0.999, 1e-7)
+            state.adamw(lr, wd, 0.9, 0.999, 1e-7, ranges=pt_ranges)
             losses.append(lv.mean())
             steps += 1
             if max_steps and steps >= max_steps:

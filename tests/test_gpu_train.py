@@ -66,6 +66,26 @@ def test_two_phase_training_and_phase_skipping(tmp_path, monkeypatch):
     assert mb.weight_status == training.WeightStatus.PRE_TRAINED
 
 
+def test_pretraining_leaves_the_stream2_only_tensors_untouched(tmp_path, monkeypatch):
+    """Keras' loss=[synthetic_data_loss, None, None] (train.py:388-392) gives the residual / gating convolutions
+    and the sigma head a None gradient: apply_gradients skips them, so tfa's AdamW neither updates nor DECAYS
+    them.  After pre-training with pt_adamw_decay > 0 they are bit-identical to their initial values, while
+    every stream-1 tensor has moved."""
+    from qbold_vi_amd import training
+    monkeypatch.chdir(ROOT)
+    cfg = small_config(tmp_path, no_pt_epochs=3, no_ft_epochs=0, pt_adamw_decay=2e-2, use_swa=True)
+    params = training.get_params()
+    model0, _, _ = training.create_encoder_model(cfg, params)   # the initialisers are seeded: same start below
+    w0 = {k: v.copy() for k, v in model0.get_weights().items()}
+    model, _, _ = training.create_and_train_on_synthetic_data(cfg, params, log=training.MetricsLog(echo=False),
+                                                              sample_size=200)
+    w1 = model.get_weights()
+    for k in ("Wr1", "br1", "Wr2", "br2", "Wg", "bg", "Ws", "bs"):
+        np.testing.assert_array_equal(w1[k], w0[k], err_msg=k)
+    for k in ("W0", "Wc", "Wf"):
+        assert np.abs(w1[k] - w0[k]).max() > 1e-4, k
+
+
 def test_sweep_style_configuration_trains(tmp_path, monkeypatch):
     """The hyper-parameters the reference's sweep file fixes (configurations/sweep_prior.yaml):
     Student-t likelihood with df = 2, three-image normalisation, an inverse-gamma prior on the

@@ -191,10 +191,18 @@ def test_nifti_writer_follows_the_nifti1_layout(tmp_path):
     tmpl = bytearray(hdr)
     struct.pack_into("<hh", tmpl, 252, 1, 1)
     struct.pack_into("<8f", tmpl, 76, 1.0, 2.0, 2.0, 3.0, 1.0, 1.0, 1.0, 1.0)
+    # ... but not its intensity scaling: an example image that is a scaled int16 scan (scl_slope 0.25, offset 7,
+    # a display window) must not rescale the float maps exported under its header
+    struct.pack_into("<ff", tmpl, 112, 0.25, 7.0)
+    struct.pack_into("<ff", tmpl, 124, 900.0, 100.0)
+    struct.pack_into("<h", tmpl, 68, 1005)
     nifti.save(arr[..., 0].astype(np.float64), str(tmp_path / "b.nii"), bytes(tmpl))
     b, hb = nifti.load(str(tmp_path / "b.nii"))
     assert b.dtype == np.float64 and b.shape == (5, 4, 3)
+    np.testing.assert_array_equal(b, arr[..., 0].astype(np.float64))
     assert struct.unpack_from("<hh", hb, 252) == (1, 1) and struct.unpack_from("<8f", hb, 76)[1:4] == (2.0, 2.0, 3.0)
+    assert struct.unpack_from("<ff", hb, 112) == (1.0, 0.0) and struct.unpack_from("<ff", hb, 124) == (0.0, 0.0)
+    assert struct.unpack_from("<h", hb, 68)[0] == 0
     with pytest.raises(ValueError):
         nifti.save(arr.astype(np.complex64), str(tmp_path / "c.nii"))
 
@@ -244,6 +252,33 @@ def test_keras_h5_mapping_by_order_and_shape():
     for k in w:
         if k != "meta":
             np.testing.assert_array_equal(back[k], w[k])
+    # Keras writes a Functional model's variables by graph depth, not by creation: inside a block the 3x3x1
+    # kernels come before the shared 1x1x1 conv and the gate.  With numbered layer names the creation numbers
+    # restore the order; with unnumbered names the kernel shapes do.
+    inner = var[2:-2]
+    depth_order = []
+    for l in range(2):
+        b = inner[8 * l: 8 * l + 8]                      # Wc bc Wr1 br1 Wr2 br2 Wg bg
+        depth_order += b[2:6] + b[0:2] + b[6:8]
+    depth_order += inner[16:]
+    for rename in (shift, lambda n: "layer_%s/%s" % (n.split("/")[0].replace("conv3d", "x"), n.split("/")[1])):
+        f2 = _FakeH5Node()
+        groups2 = [("conv3d", var[:2]), ("model", depth_order), ("sigma", var[-2:])]
+        f2.attrs["layer_names"] = [g.encode() for g, _ in groups2]
+        for gname, items in groups2:
+            g = _FakeH5Node()
+            g.attrs["weight_names"] = [rename(n).encode() for n, _ in items]
+            for n, a in items:
+                node = g
+                parts = rename(n).split("/")
+                for part in parts[:-1]:
+                    node = node.setdefault(part, _FakeH5Node()) if part not in node else dict.__getitem__(node, part)
+                dict.__setitem__(node, parts[-1], a)
+            dict.__setitem__(f2, gname, g)
+        back2 = keras_h5.variables_to_canonical(keras_h5.flatten_variables(f2))
+        for k in w:
+            if k != "meta":
+                np.testing.assert_array_equal(back2[k], w[k], err_msg=k)
     # diagonal family: 4-column final layer
     w4 = dict(w, Wf=w["Wf"][:, :4], bf=w["bf"][:4])
     assert keras_h5.variables_to_canonical([a for _, a in keras_h5.canonical_to_variables(w4)])["Wf"].shape == (12, 4)
