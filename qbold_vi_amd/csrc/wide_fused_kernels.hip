@@ -268,6 +268,13 @@ __device__ __forceinline__ void lds_wait_but2(u32x4& a, u32x4& b) {
 __device__ __forceinline__ void lds_wait_but2(u32x4& a, u32x4& b, u32x4& c) {
     asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b), "+v"(c));
 }
+__device__ __forceinline__ void lds_wait_but2(u32x4& a, u32x4& b, uint32_t& c) {
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b), "+v"(c));
+}
+// biases requested one k-step ahead travel as a pair of plain variables: one value (sixteen-step tiles) or four
+// (four-step tiles)
+#define QB_BIAS_REFS uint32_t &bias, u32x4 &bias4
+#define QB_BIAS_ARGS bias, bias4
 template <int OFF>
 __device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
     static_assert(OFF >= 0 && OFF < 65536, "ds_read_b32 immediate offset is 16 bits");
@@ -306,19 +313,22 @@ __host__ __device__ constexpr inline int bias_row(int E) { return 8 * (E >> 2) +
 // tile.  (Recursive template: every LDS offset is an instruction immediate.)
 template <int KSOP, int F0, int FP, int BOFF, int PBOFF, bool HAVE_PREV, int S_, class Prev>
 __device__ __forceinline__ void tile_steps(Stream& S, uint32_t bias_lds, Frag wa, Frag wb, Frag& oa, Frag& ob,
-                                           const Panel<KSOP>& in, f32x16& acc, u32x4& bias, const Prev& prev) {
+                                           const Panel<KSOP>& in, f32x16& acc, QB_BIAS_REFS, const Prev& prev) {
     constexpr int PPS = 16 / KSOP;  // epilogue pieces per k-step
     constexpr bool AHEAD = PPS <= 4;
     if constexpr (S_ < KSOP) {
         if constexpr ((F0 + 2 * S_) % kStageFrags == kStageFrags / 2) stream_sync(S);
-        u32x4 nbias = bias;
+        // NB a register an asm LDS read is still writing must reach its wait untouched: whole variables only
+        // (a read into one component of a vector makes the compiler copy the pending register into the tuple)
+        uint32_t nbias = bias;
+        u32x4 nbias4 = bias4;
         if constexpr (AHEAD) {
             constexpr bool last = S_ + 1 == KSOP;
             constexpr int E0 = last ? 0 : PPS * (S_ + 1);           // first piece of the step the bias is for
             constexpr int off = ((last ? BOFF : PBOFF) + bias_row(E0)) * 4;
             if constexpr (last || HAVE_PREV) {
-                if constexpr (PPS == 1) nbias[0] = lds_read4<off>(bias_lds);
-                else nbias = lds_read16<off>(bias_lds);  // pieces E0 .. E0 + 3 are four consecutive rows
+                if constexpr (PPS == 1) nbias = lds_read4<off>(bias_lds);
+                else nbias4 = lds_read16<off>(bias_lds);  // pieces E0 .. E0 + 3 are four consecutive rows
             }
         }
         Frag n;
@@ -332,9 +342,9 @@ __device__ __forceinline__ void tile_steps(Stream& S, uint32_t bias_lds, Frag wa
         acc = QB_MFMA32_F16(l, bh, acc);
         if constexpr (HAVE_PREV) {
             if constexpr (PPS == 1) {
-                prev(IC<S_>{}, __builtin_bit_cast(float, bias[0]));
+                prev(IC<S_>{}, __builtin_bit_cast(float, bias));
             } else if constexpr (PPS == 4) {
-                const float4 b4 = __builtin_bit_cast(float4, bias);
+                const float4 b4 = __builtin_bit_cast(float4, bias4);
                 prev(IC<4 * S_ + 0>{}, b4.x);
                 prev(IC<4 * S_ + 1>{}, b4.y);
                 prev(IC<4 * S_ + 2>{}, b4.z);
@@ -354,9 +364,12 @@ __device__ __forceinline__ void tile_steps(Stream& S, uint32_t bias_lds, Frag wa
             __builtin_amdgcn_sched_group_barrier(0x002, QB_FUSED_VALU_PER_MFMA, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        lds_wait_but2(wb.hi, wb.lo, nbias);
+        if constexpr (PPS == 1) lds_wait_but2(wb.hi, wb.lo, nbias);
+        else if constexpr (PPS == 4) lds_wait_but2(wb.hi, wb.lo, nbias4);
+        else lds_wait_but2(wb.hi, wb.lo);
         bias = nbias;
-        tile_steps<KSOP, F0, FP, BOFF, PBOFF, HAVE_PREV, S_ + 1>(S, bias_lds, wb, n, oa, ob, in, acc, bias, prev);
+        bias4 = nbias4;
+        tile_steps<KSOP, F0, FP, BOFF, PBOFF, HAVE_PREV, S_ + 1>(S, bias_lds, wb, n, oa, ob, in, acc, QB_BIAS_ARGS, prev);
     } else {
         oa = wa;
         ob = wb;
@@ -368,12 +381,12 @@ __device__ __forceinline__ void tile_steps(Stream& S, uint32_t bias_lds, Frag wa
 // two pairs; out, the two pairs that follow it.
 template <int KSOP, int F0, int FP, int BOFF, int PBOFF, bool HAVE_PREV, class Prev>
 __device__ __forceinline__ void tile_mma(Stream& S, uint32_t bias_lds, Frag& wa, Frag& wb, const Panel<KSOP>& in,
-                                         f32x16& acc, u32x4& bias, const Prev& prev) {
+                                         f32x16& acc, QB_BIAS_REFS, const Prev& prev) {
     static_assert((BOFF + 32) * 4 < 65536, "bias offset is a ds_read immediate");
     __builtin_amdgcn_sched_barrier(0);  // tiles are scheduled one at a time: three panels leave no slack
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    tile_steps<KSOP, F0, FP, BOFF, PBOFF, HAVE_PREV, 0>(S, bias_lds, wa, wb, wa, wb, in, acc, bias, prev);
+    tile_steps<KSOP, F0, FP, BOFF, PBOFF, HAVE_PREV, 0>(S, bias_lds, wa, wb, wa, wb, in, acc, QB_BIAS_ARGS, prev);
 }
 
 // value E (register E of the accumulator = unit 32 M + 8 (E >> 2) + 4 h + (E & 3)) read back from a panel
@@ -435,11 +448,16 @@ __device__ __forceinline__ void last_tile_bias(uint32_t bias_lds, float (&b)[16]
     u32x4 r0 = lds_read16<(BOFF + 0) * 4>(bias_lds), r1 = lds_read16<(BOFF + 8) * 4>(bias_lds);
     u32x4 r2 = lds_read16<(BOFF + 16) * 4>(bias_lds), r3 = lds_read16<(BOFF + 24) * 4>(bias_lds);
     lds_wait(r0, r1, r2, r3);
-    const u32x4 r[4] = {r0, r1, r2, r3};
+    // whole-vector casts: __builtin_bit_cast(float, r[k]) of a vector element yields element 0 for every k here
+    const float4 f[4] = {__builtin_bit_cast(float4, r0), __builtin_bit_cast(float4, r1), __builtin_bit_cast(float4, r2),
+                         __builtin_bit_cast(float4, r3)};
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) b[4 * q + k] = __builtin_bit_cast(float, r[q][k]);
+    for (int q = 0; q < 4; ++q) {
+        b[4 * q + 0] = f[q].x;
+        b[4 * q + 1] = f[q].y;
+        b[4 * q + 2] = f[q].z;
+        b[4 * q + 3] = f[q].w;
+    }
 }
 
 // A dense op: tiles M .. MT-1 of out = epi(W in + b).  Tile M-1's epilogue runs inside tile M's MFMA stream
@@ -447,19 +465,22 @@ __device__ __forceinline__ void last_tile_bias(uint32_t bias_lds, float (&b)[16]
 template <int KS, int KSIN, int MT, int F0, int FP, int BOFF, int EPI, int M = 0>
 __device__ __forceinline__ void dense_op(Stream& S, uint32_t bias_lds, float inv_scale, Frag& wa, Frag& wb,
                                          const Panel<KSIN>& in, Panel<KS>& out, const Panel<KS>& skip,
-                                         const Panel<KS>& rr, f32x16 (&acc)[2], u32x4& bias) {
+                                         const Panel<KS>& rr, f32x16 (&acc)[2], QB_BIAS_REFS) {
     constexpr bool AHEAD = KSIN >= 4;  // as tile_steps: biases requested a k-step ahead
     if constexpr (M < MT) {
         constexpr int PM = M > 0 ? M - 1 : 0;
         float carry = 0.0f;
         auto prev = [&](auto c, float b) {
             constexpr int E = decltype(c)::value;
-            if constexpr (!AHEAD) b = lds_read4_now<(BOFF + 32 * PM + bias_row(E)) * 4>(bias_lds);
+#ifndef QB_X_SYNC_BIAS
+            if constexpr (!AHEAD)
+#endif
+                b = lds_read4_now<(BOFF + 32 * PM + bias_row(E)) * 4>(bias_lds);
             epi_elem<EPI, PM, E>(acc[(M + 1) & 1], inv_scale, b, out, skip, rr, carry);
         };
         tile_mma<KSIN, F0 + M * 2 * KSIN, FP, BOFF + 32 * M, BOFF + 32 * PM, (M > 0)>(S, bias_lds, wa, wb, in,
-                                                                                       acc[M & 1], bias, prev);
-        dense_op<KS, KSIN, MT, F0, FP, BOFF, EPI, M + 1>(S, bias_lds, inv_scale, wa, wb, in, out, skip, rr, acc, bias);
+                                                                                       acc[M & 1], QB_BIAS_ARGS, prev);
+        dense_op<KS, KSIN, MT, F0, FP, BOFF, EPI, M + 1>(S, bias_lds, inv_scale, wa, wb, in, out, skip, rr, acc, QB_BIAS_ARGS);
     } else {
         __builtin_amdgcn_sched_barrier(0);
         float carry = 0.0f;
@@ -557,6 +578,9 @@ struct HeadOut {
     __amdgpu_buffer_rsrc_t ls, q;
     uint32_t ls_off, q_off;  // byte offsets of this lane's voxel inside the pass
     int T;
+#ifdef QB_X_GLOBAL_STORE
+    float* pls; float* pq; int64_t vv, N;
+#endif
 };
 #define QB_OOB 0x7ffffff0u  // beyond any resource: a dropped store
 // Piece E of head tile M: tiles 0 .. LT-1 are log-sigma rows 32 M + 8 (E >> 2) + 4 h + (E & 3), tile LT holds the
@@ -565,6 +589,14 @@ template <int LT, int M, int E>
 __device__ __forceinline__ void head_elem(const f32x16& acc, float inv_scale, float bias, const HeadOut& o, int h) {
     const float y = fmaf(acc[E], inv_scale, bias);
     const int row_in_tile = 8 * (E >> 2) + 4 * h + (E & 3);
+#ifdef QB_X_GLOBAL_STORE
+    if (o.vv < o.N) {
+        if constexpr (M < LT) {
+            if (32 * M + row_in_tile < o.T) o.pls[o.vv * o.T + 32 * M + row_in_tile] = y;
+        } else if (row_in_tile < 5) o.pq[o.vv * 5 + row_in_tile] = y;
+    }
+    return;
+#endif
     if constexpr (M < LT) {
         const int row = 32 * M + row_in_tile;
         const uint32_t off = row < o.T ? o.ls_off + 4u * row : QB_OOB;
@@ -576,15 +608,18 @@ __device__ __forceinline__ void head_elem(const f32x16& acc, float inv_scale, fl
 }
 template <int KS, int LT, int F0, int FP, int BOFF, int M = 0>
 __device__ __forceinline__ void head_op(Stream& S, uint32_t bias_lds, float inv_scale, Frag& wa, Frag& wb,
-                                        const Panel<KS>& b, const HeadOut& o, int h, f32x16 (&acc)[2], u32x4& bias) {
+                                        const Panel<KS>& b, const HeadOut& o, int h, f32x16 (&acc)[2], QB_BIAS_REFS) {
     if constexpr (M <= LT) {
         constexpr int PM = M > 0 ? M - 1 : 0;
         auto prev = [&](auto c, float bb) {
+#ifdef QB_X_SYNC_BIAS
+            bb = lds_read4_now<(BOFF + 32 * PM + bias_row(decltype(c)::value)) * 4>(bias_lds);
+#endif
             head_elem<LT, PM, decltype(c)::value>(acc[(M + 1) & 1], inv_scale, bb, o, h);
         };
         tile_mma<KS, F0 + M * 2 * KS, FP, BOFF + 32 * M, BOFF + 32 * PM, (M > 0)>(S, bias_lds, wa, wb, b, acc[M & 1],
-                                                                                   bias, prev);
-        head_op<KS, LT, F0, FP, BOFF, M + 1>(S, bias_lds, inv_scale, wa, wb, b, o, h, acc, bias);
+                                                                                   QB_BIAS_ARGS, prev);
+        head_op<KS, LT, F0, FP, BOFF, M + 1>(S, bias_lds, inv_scale, wa, wb, b, o, h, acc, QB_BIAS_ARGS);
     } else {
         __builtin_amdgcn_sched_barrier(0);
         float bl[16];
@@ -604,27 +639,27 @@ __device__ __forceinline__ void head_op(Stream& S, uint32_t bias_lds, float inv_
 template <int KS, int KS1, int MT, int L, int LT, int FB0, int FP, int SC0, int LB>
 __device__ __forceinline__ void blocks_and_head(Stream& S, uint32_t bias_lds, uint32_t aux_lds, Frag& wa, Frag& wb,
                                                 Panel<KS>& P0, Panel<KS>& P1, Panel<KS>& P2, const FusedArgs& a,
-                                                int64_t v, int64_t v_next, int h, f32x16 (&acc)[2], u32x4& bias,
+                                                int64_t v, int64_t v_next, int h, f32x16 (&acc)[2], QB_BIAS_REFS,
                                                 XRaw<KS1>& xr) {
     constexpr int FOP = MT * KS * 2;  // fragments per dense op
     constexpr int U = 32 * MT;
     if constexpr (LB < L) {
         constexpr int F = FB0 + LB * 4 * FOP, B = U + LB * 4 * U, SC = SC0 + 8 * LB;
         dense_op<KS, KS, MT, F, FP, B, EPI_RELU>(S, bias_lds, op_inv_scale<SC>(aux_lds), wa, wb, P0, P2, P2, P2, acc,
-                                                 bias);                                            // skip, :148
+                                                 QB_BIAS_ARGS);                                            // skip, :148
         QB_STAMP(a, 0);
         if constexpr (LB > 0) relu_panel(P0);  // block 0's input is a relu output already            :151
         dense_op<KS, KS, MT, F + FOP, FP, B + U, EPI_RELU>(S, bias_lds, op_inv_scale<SC + 2>(aux_lds), wa, wb, P0, P1,
-                                                           P1, P1, acc, bias);                      // t, :152-155
+                                                           P1, P1, acc, QB_BIAS_ARGS);                      // t, :152-155
         QB_STAMP(a, 1);
         dense_op<KS, KS, MT, F + 2 * FOP, FP, B + 2 * U, EPI_LINEAR>(S, bias_lds, op_inv_scale<SC + 4>(aux_lds), wa, wb,
-                                                                     P1, P0, P0, P0, acc, bias);    // r, :156
+                                                                     P1, P0, P0, P0, acc, QB_BIAS_ARGS);    // r, :156
         QB_STAMP(a, 2);
         dense_op<KS, KS, MT, F + 3 * FOP, FP, B + 3 * U, EPI_GATE>(S, bias_lds, op_inv_scale<SC + 6>(aux_lds), wa, wb,
-                                                                   P0, P1, P2, P0, acc, bias);      // :164-170
+                                                                   P0, P1, P2, P0, acc, QB_BIAS_ARGS);      // :164-170
         QB_STAMP(a, 3);
         blocks_and_head<KS, KS1, MT, L, LT, FB0, FP, SC0, LB + 1>(S, bias_lds, aux_lds, wa, wb, P1, P0, P2, a, v, v_next,
-                                                                  h, acc, bias, xr);
+                                                                  h, acc, QB_BIAS_ARGS, xr);
     } else {
         load_x<KS1>(a, v_next, h, xr);  // the next pass's signals (clamped beyond the batch: then unused)
         HeadOut o;
@@ -638,9 +673,12 @@ __device__ __forceinline__ void blocks_and_head(Stream& S, uint32_t bias_lds, ui
             o.ls_off = local * (uint32_t)a.T * 4u;
             o.q_off = local * 20u;
             o.T = a.T;
+#ifdef QB_X_GLOBAL_STORE
+            o.pls = a.ls; o.pq = a.q; o.vv = v; o.N = a.N;
+#endif
         }
         head_op<KS, LT, FB0 + L * 4 * FOP, FP, U + L * 4 * U>(S, bias_lds, op_inv_scale<SC0 + 8 * L>(aux_lds), wa, wb,
-                                                              P0, o, h, acc, bias);
+                                                              P0, o, h, acc, QB_BIAS_ARGS);
         QB_STAMP(a, 4);
     }
 }
@@ -688,7 +726,8 @@ __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
     wb.hi = lds_read16<2048>(S.cur);
     wb.lo = lds_read16<3072>(S.cur);
     lds_wait(wa.hi, wa.lo, wb.hi, wb.lo);
-    u32x4 bias = {0u, 0u, 0u, 0u};  // biases of the next step's epilogue pieces (requested one step ahead)
+    uint32_t bias = 0u;                    // bias of the next step's epilogue piece (requested one step ahead)
+    u32x4 bias4 = u32x4{0u, 0u, 0u, 0u};   // ... of the next step's four pieces (the first layer)
 
     // The signals of a pass are requested one pass ahead, at the start of the previous pass's head op (one panel
     // live, registers to spare, ~2 us of matrix work to cover the HBM latency): branch-free loads with clamped
@@ -706,11 +745,12 @@ __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
         Panel<KS> P0, P1, P2;
         f32x16 acc[2];
         dense_op<KS, KS1, MT, 0, FP, 0, EPI_RELU>(S, bias_lds, op_inv_scale<SC0>(aux_lds), wa, wb, X, P0, P0, P0, acc,
-                                                  bias);  // first layer, model.py:181
+                                                  QB_BIAS_ARGS);  // first layer, model.py:181
+        bias4 = u32x4{0u, 0u, 0u, 0u};  // dead until the next pass's first layer
         QB_STAMP(a, 7);
         blocks_and_head<KS, KS1, MT, L, LT, MT * KS1 * 2, FP, SC0 + 2, 0>(S, bias_lds, aux_lds, wa, wb, P0, P1, P2, a, v,
                                                                           v + (int64_t)gridDim.x * kVoxPerPass, h, acc,
-                                                                          bias, xr);
+                                                                          QB_BIAS_ARGS, xr);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-direct load may land after the block has gone
 }

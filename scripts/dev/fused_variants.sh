@@ -9,6 +9,6 @@ for v in "$@"; do
   hipcc $FL $v -c $C/wide_fused_kernels.hip -o /tmp/wf_var.o || exit 1
   objs=$(ls $O/*.o | grep -v wide_fused_kernels)
   hipcc --offload-arch=gfx950 -shared -fPIC -o qbold_vi_amd/libqbold_hip.so $objs /tmp/wf_var.o || exit 1
-  echo "variant [$v]: $(python scripts/dev/time_fused.py 2>&1 | tail -1)"
+  echo "variant [$v]: $(python ${QB_VARIANT_SCRIPT:-scripts/dev/time_fused.py} 2>&1 | grep -v amdgpu.ids | tail -${QB_VARIANT_LINES:-1} | tr "\n" " ")"
 done
 cp /tmp/lib_orig.so qbold_vi_amd/libqbold_hip.so
