@@ -272,6 +272,14 @@ int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float* mask, cons
                    int K, uint64_t seed, int64_t voxel0, float* nll_kl, double* sums,
                    void* workspace, int64_t N, void* stream);
 
+/* The same with the sigma head handed over BEFORE its exp (log_sigma [N][T], model.py:211-214), as the one-launch
+ * wide encoder (qbold_encoder_fused_fwd) writes it; Philox stream only.  Built for the 64-tau protocol whose
+ * tau = 0 image is index 12 (BASELINE config 3; table mode, Gaussian likelihood, one-image normalisation):
+ * QBOLD_ERR_UNSUPPORTED otherwise. */
+int qbold_elbo_fwd_logsigma(const qbold_ctx* ctx, const float* x, const float* mask, const float* q,
+                            const float* prior, const float* log_sigma, int S, int K, uint64_t seed, int64_t voxel0,
+                            float* nll_kl, double* sums, void* workspace, int64_t N, void* stream);
+
 /* The whole hot path in one launch: encoder stream 2 (model.py:122-223) -> S reparameterised
  * samples -> forward model -> NLL, K-sample KL against `prior`, masked sums.  q_out [N][5]
  * receives the posterior parameters (NULL to skip); other arguments as qbold_elbo_fwd. */

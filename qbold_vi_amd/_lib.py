@@ -79,6 +79,7 @@ SIGNATURES = {
     "qbold_elbo_workspace_bytes": (_I64, [_P]),
     "qbold_elbo_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _U64, _I64,
                                  _P, _P, _P, _I64, _P]),
+    "qbold_elbo_fwd_logsigma": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _U64, _I64, _P, _P, _P, _I64, _P]),
     "qbold_elbo_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _U64, _I64, _P, _P, _P, _P,
                                  _P, _I64, _P]),
     "qbold_train_workspace_floats": (_I64, [C.POINTER(EncoderShape), _I64]),

@@ -664,6 +664,18 @@ extern "C" int qbold_elbo_fwd(const qbold_ctx* ctx, const float* x, const float*
                                workspace, N, (hipStream_t)stream);
 }
 
+extern "C" int qbold_elbo_fwd_logsigma(const qbold_ctx* ctx, const float* x, const float* mask, const float* q,
+                                       const float* prior, const float* log_sigma, int S, int K, uint64_t seed,
+                                       int64_t voxel0, float* nll_kl, double* sums, void* workspace, int64_t N,
+                                       void* stream) {
+    QB_NEED_DEVICE(ctx);
+    QB_REQUIRE(N >= 0 && S >= 1 && K >= 0, "qbold_elbo_fwd_logsigma: need N >= 0, S >= 1, K >= 0");
+    QB_REQUIRE(sums && workspace, "qbold_elbo_fwd_logsigma: null sums/workspace");
+    QB_REQUIRE(N == 0 || (x && q && prior && log_sigma), "qbold_elbo_fwd_logsigma: null input buffer");
+    return qb::elbo_fwd_launch(ctx, x, mask, q, prior, log_sigma, true, nullptr, nullptr, S, K, seed, voxel0, nll_kl,
+                               sums, workspace, N, (hipStream_t)stream);
+}
+
 // kl_loss for the diagonal family (use_mvg = False, per-voxel prior): model.py:686-716 with
 // tfp LogitNormal.kl_divergence = kl_normal_normal of the underlying Gaussians,
 //   0.5 ((mu_q - mu_p) / sigma_p)^2 + 0.5 expm1(2 (s_q - s_p)) - (s_q - s_p)   per dimension,

@@ -38,7 +38,7 @@
 // Weights.  All dense ops of one pass over 128 voxels form one flat stream of 1 KiB MFMA fragments in
 // consumption order ([op][out tile][k-step][hi, lo]; 2.2 MB for config 3, L2-resident).  Stages of 16
 // fragments travel L2 -> LDS by LDS-direct loads (global_load_lds_dwordx4, each wave issues a quarter) into a
-// ring of eight 16 KiB slots, seven stages ahead; the handshake sits in the MIDDLE of a stage -- counted
+// ring of eight 16 KiB slots, four stages ahead; the handshake sits in the MIDDLE of a stage -- counted
 // s_waitcnt vmcnt, raw s_barrier, issue of the stage that reuses the slot everyone has just left -- so the
 // next stage is known to have landed before the current one ends and the fragment reads run two pairs ahead of
 // the MFMAs without a bubble at tile, stage or pass boundaries.  The stream wraps from one pass to the next
@@ -60,7 +60,8 @@ using namespace qbw;
 #endif
 constexpr int kFB = 256;          // threads per block: one wave per SIMD
 constexpr int kRing = 8;          // LDS ring slots of 16 fragments (128 KiB)
-constexpr int kAhead = 7;         // stages requested beyond the one being read
+constexpr int kAhead = 4;         // stages requested beyond the one being read (16 loads in flight per wave: the
+                                  // 6-bit vmcnt also has to hold a pass's signal loads and head stores)
 constexpr int kStageFrags = 16;   // 1 KiB fragments per stage
 constexpr int kVoxPerPass = 128;  // 4 waves x 32 voxels
 
@@ -557,14 +558,15 @@ __device__ __forceinline__ void convert_x(const FusedArgs& a, int h, const XRaw<
     float den = qb::clampf_(xr.d[1], 1e-2f, 1e8f);
     if (a.multi_norm) den = (qb::clampf_(xr.d[0], 1e-2f, 1e8f) + den + qb::clampf_(xr.d[2], 1e-2f, 1e8f)) / 3.0f;
     const bool wide_rows = (a.T & 3) == 0 && a.T >= 8;
+    const float inv_den = 1.0f / den;
 #pragma unroll
     for (int s = 0; s < KS1; ++s) {
         const int t0 = 16 * s + 8 * h;
         const bool whole = !wide_rows || t0 + 8 <= a.T;  // else the clamped load fetched other taus
         float f[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            f[j] = (whole && t0 + j < a.T) ? logf(qb::clampf_(xr.f[s][j], 1e-2f, 1e8f) / den) : 0.0f;
+        for (int j = 0; j < 8; ++j)  // v_log_f32 as the LDS-resident kernels (encoder_core.h normalise)
+            f[j] = (whole && t0 + j < a.T) ? QB_LN2 * qb::log2f_(qb::clampf_(xr.f[s][j], 1e-2f, 1e8f) * inv_den) : 0.0f;
 #pragma unroll
         for (int d = 0; d < 4; ++d) split_pair(f[2 * d], f[2 * d + 1], X.hi[s][d], X.lo[s][d]);
     }

@@ -423,3 +423,41 @@ def test_restatement_goldens_have_not_drifted(oracle32, oracle64):
     np.testing.assert_allclose(wo, g["wls_oef"], rtol=1e-9)
     np.testing.assert_allclose(wd, g["wls_dbv"], rtol=1e-9)
     np.testing.assert_allclose(wr, g["wls_r2p"], rtol=1e-9)
+
+
+def test_two_independent_restatements_agree_on_config_1(oracle32, params):
+    """BASELINE config 1 (optimal.yaml shapes, 4,096 synthetic voxels x 11 tau, CPU): oracle/torch_ref.py -- written
+    separately from qbold_oracle.c, from the same reference lines, as whole-batch torch float32 ops at the
+    reference's granularity ([V, T, 129] Bessel tensor, S-fold tiled batch) -- against the C restatement.  With no
+    reference-held vector to pin either (TensorFlow cannot run here), two restatements agreeing to float32
+    rounding is the tightest check available: signals 1e-6, encoder 2e-6, ELBO 1e-6 relative."""
+    torch = pytest.importorskip("torch")
+    from oracle import torch_ref as tr
+    from oracle.oracle import init_weights, synth_inputs
+    n, S, K = 4096, 2, 70
+    w = init_weights(T=11, U=60, L=2, seed=1)
+    w["gate_offset"] = -3.0
+    rb = np.random.default_rng(0)
+    for nm in ("b0", "bc", "br1", "br2", "bg", "bf"):
+        w[nm] = (rb.standard_normal(w[nm].shape) * 0.1).astype(np.float32)
+    x, y = synth_inputs(n, params, seed=1, oracle=oracle32)
+    np.testing.assert_array_equal(tr.tau_grid(params).numpy(), oracle32.taus)
+    sig_c, sig_t = oracle32.signal_fwd(y), tr.signal_model(y, params).numpy()
+    assert np.max(np.abs(sig_c - sig_t) / np.abs(sig_c)) < 1e-6
+    p1, q2, sg = oracle32.encoder_fwd(w, x)
+    a, b, c = (t.numpy() for t in tr.encoder(w, x, oracle32.se_idx, -3.0))
+    assert np.abs(a - p1).max() < 2e-6 and np.abs(b - q2).max() < 2e-6 and np.max(np.abs(c - sg) / sg) < 2e-6
+    mask = (rb.uniform(size=n) > 0.1).astype(np.float32)
+    zs, zk = oracle32.philox_normals(1, 0, 0, n, S), oracle32.philox_normals(1, 1, 0, n, K)
+    want = oracle32.elbo(x, mask, q2, p1, sg, zs, zk)
+    got = tr.elbo(x, mask, q2, p1, sg, zs, zk, params, oracle32.se_idx)
+    assert abs(want["elbo"] - got["elbo"]) < 1e-6 * abs(want["elbo"])
+    assert abs(want["nll"] - got["nll"]) < 1e-6 * abs(want["nll"]) and abs(want["kl"] - got["kl"]) < 1e-5 * abs(want["kl"])
+    assert np.max(np.abs(want["nll_v"] - got["nll_v"]) / (np.abs(want["nll_v"]) + 1.0)) < 5e-5
+    assert np.max(np.abs(want["kl_v"] - got["kl_v"]) / (np.abs(want["kl_v"]) + 1.0)) < 1e-5
+    # the log-linear and no-blood signal models as well
+    for full, blood in ((False, True), (True, False)):
+        from oracle.oracle import Oracle
+        oc = Oracle("f32", params, full_model=full, include_blood=blood)
+        s_c, s_t = oc.signal_fwd(y[:512]), tr.signal_model(y[:512], params, full, blood).numpy()
+        assert np.max(np.abs(s_c - s_t) / np.abs(s_c)) < 2e-6
