@@ -443,7 +443,7 @@ class EncoderTrainer:
         output (`_, predictions, _ = model.predict(...)`, model.py:757: the stream-2 / fine-tuned head, which
         sees the 3x3x1 context on volumes), printed and returned as (mean_oef, log_std_oef, mean_dbv,
         log_std_dbv)."""
-        predictions = model.predict(data[..., :-1] * data[..., -1:], want=("out2",))[0]
+        predictions = model.predict(data[..., :-1] * data[..., -1:], want=("out2",))[1]
         mask = data[..., -1:]
         oef, dbv = predictions[..., 0:1] * mask, predictions[..., 2:3] * mask
         mask_pix = mask.sum()
