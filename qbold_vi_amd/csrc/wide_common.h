@@ -33,6 +33,9 @@ __device__ __forceinline__ u32x4 lds_read16(uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
     return r;
 }
+__device__ __forceinline__ void lds_wait(u32x4& a) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a));
+}
 __device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
 }

@@ -290,8 +290,8 @@ __global__ __launch_bounds__(kWB) void wide_dense_kernel(WideArgs a) {
 #pragma unroll
                 for (int m = 0; m < MTW; ++m) {
                     const int col = 16 * (osplit * MTW + m) + 4 * g;
-                    u32x4 braw = lds_read16<0>(lds_addr(lbias + col)), bdummy = braw;
-                    lds_wait(braw, bdummy);
+                    u32x4 braw = lds_read16<0>(lds_addr(lbias + col));
+                    lds_wait(braw);   // (no copy of braw before this: its registers are still being written)
                     const float4 bi = __builtin_bit_cast(float4, braw);
                     float y[4] = {fmaf(cross[vt][m][0], QB_LO_UNSCALE, out[vt][m][0]) + bi.x,
                                   fmaf(cross[vt][m][1], QB_LO_UNSCALE, out[vt][m][1]) + bi.y,

@@ -21,9 +21,11 @@ def main():
     inside, pending, bad, nreads = key == "", [], [], 0   # pending: list of register sets, oldest first
     for no, ln in enumerate(lines, 1):
         s = ln.strip()
-        if s.endswith(":") and not s.startswith("."):
-            inside = key in s
+        m = re.match(r"^([A-Za-z_][\w$]*):", s)     # a function label (".LBB" block labels start with a dot)
+        if m:
+            inside = key in m.group(1)
             pending = []
+            continue
         if not inside or not s or s.startswith((";", ".")):
             continue
         op, _, rest = s.partition(" ")

@@ -688,3 +688,120 @@ def test_config3_wide_encoder_64_taus(params):
         assert rel(nk2.cpu().numpy()[:, 0], want2["nll_v"], 1.0) < 5e-4
         # per-voxel KL = mean of log q - log p, two O(10) terms that cancel to O(0.1): float32 noise
         assert np.max(np.abs(nk2.cpu().numpy()[:, 1] - want2["kl_v"]) / (np.abs(want2["kl_v"]) + 1.0)) < 5e-4
+
+
+def _config3_params(params):
+    return dict(params, tau_start="-0.015", tau_end="0.065", tau_step="0.00125")
+
+
+def test_one_launch_wide_encoder_matches_oracle_and_layerwise(params):
+    """wide_fused_kernel (the whole stream-2 encoder of U = 256 in one launch, activations in registers) against
+    the oracle and against the layer-wise weight-streaming kernels, on both instantiated tau counts (one and four
+    first-layer k-steps), one and two blocks, voxel counts around its 128-voxel passes and a multi-pass batch;
+    non-zero biases everywhere, a weight scale spread over four decades (the per-op power-of-two scaling)."""
+    from oracle.oracle import Oracle, init_weights
+    from qbold_vi_amd.ops import Context, EncoderWeights
+    for T, p in ((11, params), (64, _config3_params(params))):
+        orc = Oracle("f32", p)
+        ctx = Context(p, True, True)
+        assert ctx.T == T
+        for L in (1, 2):
+            w = init_weights(T=T, U=256, L=L, seed=10 * T + L)
+            rb = np.random.default_rng(T + L)
+            for nm in ("b0", "bc", "br1", "br2", "bg", "bf", "bs"):
+                w[nm] = (w[nm] + rb.standard_normal(w[nm].shape) * 0.1).astype(np.float32)
+            w["Wr1"] = (w["Wr1"] * 10.0 ** rb.uniform(-3, 0.3, size=(L, 1, 256))).astype(np.float32)
+            w["gate_offset"] = -1.0
+            ew = EncoderWeights(ctx, T, 256, L, True, -1.0).set_from_arrays(w)
+            assert ew.fused_wide
+            for n in (1, 127, 129, 1000, 70001):
+                g = torch.Generator(device="cuda")
+                g.manual_seed(n)
+                x = torch.rand((n, T), generator=g, device="cuda") * 0.6 + 0.15
+                ctx.force_layerwise_wide = True
+                _, q0, s0 = ctx.encoder_fwd(ew, x, want=("out2", "sigma"))
+                ctx.force_layerwise_wide = False
+                _, q1, s1 = ctx.encoder_fwd(ew, x, want=("out2", "sigma"))
+                assert float((q0 - q1).abs().max()) < 5e-6 and float(((s0 - s1).abs() / s0).max()) < 5e-6, (T, L, n)
+                if n <= 1000:
+                    _, q_want, s_want = orc.encoder_fwd(w, x.cpu().numpy())
+                    assert np.max(np.abs(q1.cpu().numpy() - q_want)) < 2e-5, (T, L, n)
+                    assert rel(s1.cpu().numpy(), s_want) < 2e-5, (T, L, n)
+            # re-packing after an update is picked up (per-op scales are recomputed from the new weights)
+            w2 = dict(w, W0=(w["W0"] * 3.0).astype(np.float32))
+            ew.set_from_arrays(w2)
+            x = torch.rand((300, T), device="cuda") * 0.6 + 0.15
+            _, q_want, _ = orc.encoder_fwd(w2, x.cpu().numpy())
+            assert np.max(np.abs(ctx.encoder_fwd(ew, x, want=("out2",))[1].cpu().numpy() - q_want)) < 2e-5
+
+
+def test_config3_full_size_properties(params):
+    """BASELINE config 3 at its full size (1,048,576 voxels x 64 tau, encoder width 256, S = 32, K = 70) through
+    qbold_vi_fwd's two-launch wide path: bitwise determinism, the sums as the checksum of the per-voxel outputs,
+    shard additivity with global-voxel Philox keys, the oracle on a window -- and a 9 M-voxel batch whose signal
+    and log-sigma tensors pass 2^31 bytes (64-bit offsets), checked by the oracle on a window at its tail."""
+    from oracle.oracle import Oracle, init_weights
+    from qbold_vi_amd.ops import Context, EncoderWeights
+    from qbold_vi_amd.signals import SignalGenerationLayer
+    p = _config3_params(params)
+    orc = Oracle("f32", p)
+    ctx = Context(p, True, True)
+    w = init_weights(T=64, U=256, L=2, seed=3)
+    rb = np.random.default_rng(7)
+    for nm in ("b0", "bc", "br1", "br2", "bg", "bf"):
+        w[nm] = (rb.standard_normal(w[nm].shape) * 0.1).astype(np.float32)
+    w["gate_offset"] = -3.0
+    ew = EncoderWeights(ctx, 64, 256, 2, True, -3.0).set_from_arrays(w)
+    S, K, seed = 32, 70, 11
+
+    def batch(N, gseed):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(gseed)
+        y = torch.stack([torch.rand(N, generator=g, device="cuda") * 0.7 + 0.08,
+                         torch.rand(N, generator=g, device="cuda") * 0.1 + 0.005], -1)
+        x = SignalGenerationLayer(p, True, True)(y)
+        x = x * (1 + 0.01 * torch.randn(x.shape, generator=g, device="cuda"))
+        return x.contiguous(), (torch.rand(N, generator=g, device="cuda") > 0.25).float()
+
+    def window(x, mask, prior, nk, q, v0, n):
+        xs, ms, ps = (t[v0:v0 + n].cpu().numpy() for t in (x, mask, prior))
+        _, q_want, sigma = orc.encoder_fwd(w, xs)
+        assert np.max(np.abs(q[v0:v0 + n].cpu().numpy() - q_want)) < 2e-5
+        want = orc.elbo(xs, ms, q_want, ps, sigma, orc.philox_normals(seed, 0, v0, n, S),
+                        orc.philox_normals(seed, 1, v0, n, K))
+        got = nk[v0:v0 + n].cpu().numpy()
+        assert rel(got[:, 0], want["nll_v"], 1.0) < 5e-4
+        assert np.max(np.abs(got[:, 1] - want["kl_v"]) / (np.abs(want["kl_v"]) + 1.0)) < 5e-4
+
+    N = 1 << 20
+    x, mask = batch(N, 5)
+    prior = ctx.encoder_fwd(ew, x, want=("out1",))[0]
+    sums, q, nk = ctx.vi_fwd(ew, x, mask, prior, S, K, seed=seed)
+    sums2, q2, nk2 = ctx.vi_fwd(ew, x, mask, prior, S, K, seed=seed)
+    assert torch.equal(sums, sums2) and torch.equal(nk, nk2) and torch.equal(q, q2)   # bitwise repeatable
+    assert bool(torch.isfinite(nk).all()) and bool(torch.isfinite(sums).all())
+    nkd, md = nk.double(), mask.double()
+    assert abs(float((nkd[:, 0] * md).sum()) / float(sums[0]) - 1) < 1e-9
+    assert abs(float(nkd[:, 1][mask > 0].sum()) / float(sums[1]) - 1) < 1e-9
+    assert float(sums[2]) == float(md.sum())
+    parts, acc = [], torch.zeros_like(sums)
+    for a, b in ((0, 300_001), (300_001, 700_000), (700_000, N)):   # ragged shards: partial passes in the middle
+        s_r, _, nk_r = ctx.vi_fwd(ew, x[a:b].contiguous(), mask[a:b].contiguous(), prior[a:b].contiguous(), S, K,
+                                  seed=seed, voxel0=a)
+        parts.append(nk_r)
+        acc += s_r
+    assert torch.equal(torch.cat(parts), nk)
+    assert torch.allclose(acc, sums, rtol=1e-9, atol=0)
+    window(x, mask, prior, nk, q, 777_000, 256)
+    del x, mask, prior, q, nk, q2, nk2, parts
+    # 9 M voxels: x and log sigma are 2.3 GB each
+    N = 9_000_000
+    x, mask = batch(N, 6)
+    assert x.numel() * 4 > 2 ** 31
+    prior = ctx.encoder_fwd(ew, x[N - 4096:].contiguous(), want=("out1",))[0]
+    prior = torch.cat([torch.zeros((N - 4096, 5), device="cuda"), prior])
+    prior[:, 1] = torch.where(prior[:, 1] == 0, torch.full_like(prior[:, 1], -0.3), prior[:, 1])
+    sums, q, nk = ctx.vi_fwd(ew, x, mask, prior, S, K, seed=seed)
+    assert bool(torch.isfinite(sums).all()) and float(sums[2]) == float(mask.double().sum())
+    window(x, mask, prior, nk, q, N - 300, 300)      # the last, partial pass; byte offsets beyond 2^31
+    window(x, mask, prior, nk, q, 8_500_000, 128)

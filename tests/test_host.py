@@ -5,6 +5,8 @@ import ctypes as C
 import json
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -340,3 +342,27 @@ def test_crop_dataset_windows_match_the_volumes():
     assert dv.crop == [60, 44] and dv.batch == 3
     xa, ma, _ = dv.next_batch(g)
     np.testing.assert_array_equal(ma.numpy(), vol[..., -1])
+
+
+def test_hand_placed_lds_reads_are_not_touched_before_their_wait(tmp_path):
+    """The weight-streaming encoder kernels read their LDS rings through inline-asm ds_read + counted s_waitcnt
+    (the compiler would otherwise drain the LDS-direct loads in flight).  The compiler does not know those reads
+    are asynchronous: scripts/check_lds_hazards.py scans the ISA for any use of a register between the read that
+    writes it and the wait that covers it (a bias read into one vector component once made the compiler copy the
+    pending register: garbage biases, run to run different)."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "qbold_vi_amd", "csrc")
+    # (wide_kernels.hip's wide_dense_kernel passes the same check -- 592 reads, 0 hazards -- but takes minutes to
+    # compile; QB_FUSED_DEV builds the config-3 instantiation of the one-launch kernel only)
+    for src, flags, key in (("wide_fused_kernels.hip", ["-DQB_FUSED_DEV"], "wide_fused_kernel"),):
+        out = tmp_path / (src + ".s")
+        subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-gpu-rdc", "-Wno-unused-function",
+                               "--cuda-device-only", "-S", *flags, os.path.join(csrc, src), "-o", str(out)],
+                              stderr=subprocess.DEVNULL)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_lds_hazards.py"), str(out), key],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        assert "LDS reads checked, 0 hazards" in r.stdout and " 0 LDS reads" not in r.stdout, r.stdout
