@@ -759,7 +759,7 @@ def test_config3_full_size_properties(params):
         g.manual_seed(gseed)
         y = torch.stack([torch.rand(N, generator=g, device="cuda") * 0.7 + 0.08,
                          torch.rand(N, generator=g, device="cuda") * 0.1 + 0.005], -1)
-        x = SignalGenerationLayer(p, True, True)(y)
+        x = SignalGenerationLayer(dict(p, simulate_noise='False'), True, True)(y)   # (noise model: 11 / 24 taus only)
         x = x * (1 + 0.01 * torch.randn(x.shape, generator=g, device="cuda"))
         return x.contiguous(), (torch.rand(N, generator=g, device="cuda") > 0.25).float()
 
@@ -790,8 +790,10 @@ def test_config3_full_size_properties(params):
                                   seed=seed, voxel0=a)
         parts.append(nk_r)
         acc += s_r
-    assert torch.equal(torch.cat(parts), nk)
-    assert torch.allclose(acc, sums, rtol=1e-9, atol=0)
+    assert torch.equal(torch.cat(parts), nk)           # per voxel: bit for bit, whatever the sharding
+    # the three sums: a lane adds its voxels' terms in float32 before the float64 block / grid reduction, and
+    # ragged shards regroup the voxels over lanes -- float32 rounding of sixteen-term partial sums
+    assert torch.allclose(acc, sums, rtol=1e-7, atol=0)
     window(x, mask, prior, nk, q, 777_000, 256)
     del x, mask, prior, q, nk, q2, nk2, parts
     # 9 M voxels: x and log sigma are 2.3 GB each
