@@ -63,7 +63,23 @@ typedef enum {
     QBOLD_TISSUE_LITERAL = 1  /* the 129-node Simpson sum with Cephes j0f, per (voxel, tau) */
 } qbold_tissue_mode;
 
-/* Arithmetic of the fused voxel-wise encoder kernels (qbold_encoder_fwd, qbold_vi_fwd). */
+/* Arithmetic of the fused voxel-wise encoder kernels (qbold_encoder_fwd, qbold_vi_fwd, qbold_encoder_wide_fwd,
+ * qbold_encoder_fused_fwd).
+ *
+ * QBOLD_ENC_F32 operand range.  Every weight and activation x enters the matrix cores as hi = f16(x) plus a lo half
+ * carrying the next 11 bits; products hi.hi + hi.lo + lo.hi accumulate in float32 (the lo.lo term, <= 2^-22
+ * relative, is dropped).  Consequences the float32 reference does not share:
+ *   - |x| > 65504 (the largest f16): hi overflows to inf.  The heads then come out non-finite and, because
+ *     nll * mask is NaN for a NaN nll whatever the mask, so do the three sums: NON-FINITE SUMS ARE THE STATUS
+ *     CHANNEL for this condition (the library never clamps silently).  The exact-float32 layer-wise path
+ *     (qbold_encoder_train_fwd + qbold_elbo_fwd) has no such limit; the Python mirror's
+ *     Context.vi_fwd(range_check=True) / FineTuner.elbo fall back to it.
+ *   - 6.1e-5 <= |x| <= 65504: 22 significant bits (relative error <= ~7e-7 per product).
+ *   - |x| < 6.1e-5: both halves are f16 subnormals, absolute resolution 2^-35 = 2.9e-11 (LDS-resident kernels,
+ *     lo scaled by 2^11) or 2^-25 = 3e-8 for activations in qbold_encoder_fused_fwd (unscaled lo; its weights
+ *     are pre-scaled per dense op by a power of two, so their lo halves stay normal) -- absolute errors far
+ *     below float32 rounding of an O(1) layer output, but the RELATIVE precision of tiny operands degrades.
+ *   tests/test_gpu_parity.py::test_split_operand_range drives all three regimes against the oracle. */
 typedef enum {
     QBOLD_ENC_F32 = 0,  /* float32-grade: operands split into two f16 halves, three MFMAs per tile */
     QBOLD_ENC_BF16 = 1  /* operands rounded to bfloat16, float32 accumulate (BASELINE config 5:

@@ -49,6 +49,7 @@ struct EncLayout {
     int blk0;           // offset of block 0
     int blk_stride;     // floats per block
     int head_A, head_b;
+    int flag;           // one float: max |w| over the weights beyond the f16 range (0: none), see split_part
     int total;
 };
 // inside one block: four dense ops, each 4096 (A) + 64 (bias) floats
@@ -67,8 +68,8 @@ __host__ __device__ constexpr inline EncLayout make_enc_layout(int T, int U, int
     e.blk_stride = BLK_FLOATS;
     e.head_A = e.blk0 + L * BLK_FLOATS;
     e.head_b = e.head_A + 1024 * e.head_tiles;
-    e.total = e.head_b + 16 * e.head_tiles;
-    e.total = (e.total + 3) & ~3;
+    e.flag = e.head_b + 16 * e.head_tiles;
+    e.total = (e.flag + 1 + 3) & ~3;
     return e;
 }
 
@@ -130,13 +131,25 @@ __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo
 struct ActFrag {
     f16x8 hi[2], lo[2];
 };
+// The largest magnitude an f16 hi half can hold; an activation beyond it overflows the operand split to inf,
+// and what follows is NOT reliably non-finite (inf - inf = NaN in the accumulators, and relu's v_max_f32 turns a
+// NaN into 0).  The kernels therefore track max |activation| over everything they split (amax, one v_max3_f32
+// per pair of values) and poison the voxel's outputs with NaN when it passes the limit: non-finite outputs /
+// sums are the status channel of include/qbold_hip.h.
+#define QB_SPLIT_MAX 65504.0f
+__device__ __forceinline__ bool split_overflowed(float amax) { return !(amax <= QB_SPLIT_MAX); }
+
 template <bool BF = false>
-__device__ __forceinline__ ActFrag split_act(const f32x4 (&in)[4]) {
+__device__ __forceinline__ ActFrag split_act(const f32x4 (&in)[4], float* amax = nullptr) {
     ActFrag f;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const float v[8] = {in[2 * s][0], in[2 * s][1], in[2 * s][2], in[2 * s][3],
                             in[2 * s + 1][0], in[2 * s + 1][1], in[2 * s + 1][2], in[2 * s + 1][3]};
+        if (!BF && amax) {
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) *amax = fmaxf(*amax, fmaxf(fabsf(v[j]), fabsf(v[j + 1])));  // v_max3_f32
+        }
         split8<BF>(v, f.hi[s], f.lo[s]);
     }
     return f;
@@ -208,8 +221,8 @@ __device__ __forceinline__ void dense_f16x3(const float* __restrict__ A,
 // 64 -> 64 layer on an activation tensor
 template <bool BF = false>
 __device__ __forceinline__ void dense64(const float* __restrict__ A, const float* __restrict__ bias,
-                                        const f32x4 (&in)[4], f32x4 (&out)[4], int lane) {
-    const ActFrag f = split_act<BF>(in);
+                                        const f32x4 (&in)[4], f32x4 (&out)[4], int lane, float* amax = nullptr) {
+    const ActFrag f = split_act<BF>(in, amax);
     dense_f16x3<4, 2, BF>(A, bias, f.hi, f.lo, out, lane);
 }
 
@@ -217,8 +230,8 @@ __device__ __forceinline__ void dense64(const float* __restrict__ A, const float
 template <int HT, bool BF = false>
 __device__ __forceinline__ void dense_head(const float* __restrict__ A,
                                            const float* __restrict__ bias, const f32x4 (&in)[4],
-                                           f32x4 (&out)[HT], int lane) {
-    const ActFrag f = split_act<BF>(in);
+                                           f32x4 (&out)[HT], int lane, float* amax = nullptr) {
+    const ActFrag f = split_act<BF>(in, amax);
     dense_f16x3<HT, 2, BF>(A, bias, f.hi, f.lo, out, lane);
 }
 
@@ -275,19 +288,19 @@ __device__ __forceinline__ void dense_first(const float* __restrict__ A,
 // One create_block step of stream 2 (gated residual), in place -- model.py:147-172.
 template <bool BF = false>
 __device__ __forceinline__ void block_stream2(const float* __restrict__ W, f32x4 (&b)[4],
-                                              int lane) {
+                                              int lane, float* amax = nullptr) {
     f32x4 skip[4], t[4], r[4];
-    dense64<BF>(W + BLK_WC_A, W + BLK_WC_B, b, skip, lane);  // shared 1x1x1 conv as skip, :148
+    dense64<BF>(W + BLK_WC_A, W + BLK_WC_B, b, skip, lane, amax);  // shared 1x1x1 conv as skip, :148
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         skip[m] = relu4(skip[m]);
         b[m] = relu4(b[m]);  // Activation before the first 3x3x1 conv, :151
     }
-    dense64<BF>(W + BLK_R1_A, W + BLK_R1_B, b, t, lane);  // :152
+    dense64<BF>(W + BLK_R1_A, W + BLK_R1_B, b, t, lane);  // :152  (|relu b| <= |b|: already tracked)
 #pragma unroll
     for (int m = 0; m < 4; ++m) t[m] = relu4(t[m]);   // :155
-    dense64<BF>(W + BLK_R2_A, W + BLK_R2_B, t, r, lane);  // :156
-    dense64<BF>(W + BLK_G_A, W + BLK_G_B, r, t, lane);    // gating logits (+ gate_offset in bias), :164
+    dense64<BF>(W + BLK_R2_A, W + BLK_R2_B, t, r, lane, amax);  // :156
+    dense64<BF>(W + BLK_G_A, W + BLK_G_B, r, t, lane, amax);    // gating logits (+ gate_offset in bias), :164
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -301,9 +314,9 @@ __device__ __forceinline__ void block_stream2(const float* __restrict__ W, f32x4
 // One create_block step of stream 1 -- model.py:144-145.
 template <bool BF = false>
 __device__ __forceinline__ void block_stream1(const float* __restrict__ W, f32x4 (&a)[4],
-                                              int lane) {
+                                              int lane, float* amax = nullptr) {
     f32x4 o[4];
-    dense64<BF>(W + BLK_WC_A, W + BLK_WC_B, a, o, lane);
+    dense64<BF>(W + BLK_WC_A, W + BLK_WC_B, a, o, lane, amax);
 #pragma unroll
     for (int m = 0; m < 4; ++m) a[m] = relu4(o[m]);
 }

@@ -24,7 +24,11 @@ __device__ __forceinline__ float wval(const float* W, int nin, int nout, int in,
 
 // One element of a dense op's f16 image: fragment (s, m_out, part), lane, j.
 // bf16 mode: the hi slot carries the bfloat16 bit pattern of w, the lo slot is unused.
-__device__ __forceinline__ _Float16 split_part(float w, int part, bool bf) {
+__device__ __forceinline__ _Float16 split_part(float w, int part, bool bf, float* flag = nullptr) {
+    // a weight beyond f16's 65504 (or non-finite) cannot be split: recorded in the image's flag slot, which
+    // the kernels fold into their activation range guard (outputs become NaN, encoder_core.h)
+    if (!bf && flag && part == 0 && !(fabsf(w) <= QB_SPLIT_MAX))
+        atomicMax(reinterpret_cast<int*>(flag), __float_as_int(fminf(fabsf(w), 3.0e38f)));
     if (bf) {
         const __bf16 b = (__bf16)w;
         return part == 0 ? __builtin_bit_cast(_Float16, b) : (_Float16)0.0f;
@@ -44,7 +48,7 @@ __global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset, b
         if (pf < e.first_b) {   // first-layer A: [m][part][lane][j], k-slot 8g + j = input 8g + j
             const int j = p & 7, lane = (p >> 3) & 63, part = (p >> 9) & 1, m = p >> 10;
             const int in = 8 * (lane >> 4) + j;
-            ph[p] = split_part(wval(w + c.W0, T, U, in, 16 * m + (lane & 15)), part, bf);
+            ph[p] = split_part(wval(w + c.W0, T, U, in, 16 * m + (lane & 15)), part, bf, packed + e.flag);
         } else if (pf < e.blk0) {  // first-layer bias [m][g][r] (float: written by the even half)
             if (p & 1) continue;
             const int q = pf - e.first_b, r = q & 3, g = (q >> 2) & 3, m = q >> 4;
@@ -65,7 +69,7 @@ __global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset, b
                 const int in = frag_unit(s, lane >> 4, j);
                 int out = 16 * m + (lane & 15);
                 if (piece == 3 && G == 1) out = out < U ? 0 : U;  // shared gate broadcast to all units
-                ph[p] = split_part(wval(wb + Aoff, U, nout, in, out), part, bf);
+                ph[p] = split_part(wval(wb + Aoff, U, nout, in, out), part, bf, packed + e.flag);
             } else {
                 if (p & 1) continue;
                 const int qq = oo - 4096, r = qq & 3, g = (qq >> 2) & 3, m = qq >> 4;
@@ -87,7 +91,7 @@ __global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset, b
             float v = 0.0f;
             if (row < 5) v = wval(w + c.Wf, U, 5, in, row);
             else if (row < 5 + T) v = wval(w + c.Ws, U, T, in, row - 5);
-            ph[p] = split_part(v, part, bf);
+            ph[p] = split_part(v, part, bf, packed + e.flag);
         } else if (pf < e.head_b + 16 * e.head_tiles) {  // head bias [mh][g][r]
             if (p & 1) continue;
             const int q = pf - e.head_b, r = q & 3, g = (q >> 2) & 3, mh = q >> 4;
@@ -96,7 +100,7 @@ __global__ void pack_kernel(EncLayout e, qb::CanonLayout c, float gate_offset, b
             if (row < 5) v = w[c.bf + row];
             else if (row < 5 + T) v = w[c.bs + row - 5];
             packed[pf] = v;
-        } else if (!(p & 1)) {
+        } else if (!(p & 1) && pf != e.flag) {   // (the flag slot is zeroed by the host before this launch)
             packed[pf] = 0.0f;
         }
     }
@@ -128,14 +132,25 @@ __global__ __launch_bounds__(kEncBlock) void encoder_fwd_kernel(
         qb::normalise<T>(c, xv, nv);
         f32x4 a[4];
         qb::dense_first<T, BF>(lds_w + e.first_A, lds_w + e.first_b, nv, a, lane);
+        // operand range guard (encoder_core.h): the largest activation split by any of the voxel's four lanes;
+        // beyond f16's 65504 the voxel's outputs are written as NaN, never a silently clamped number
+        auto voxel_max = [](float m) {
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            return fmaxf(m, __shfl_xor(m, 32, 64));
+        };
         if (out2 || sigma) {
             f32x4 b[4] = {a[0], a[1], a[2], a[3]};  // net2 = net1, model.py:185
+            float amax = lds_w[e.flag];   // 0, or the largest unsplittable weight
 #pragma unroll
-            for (int l = 0; l < NL; ++l) qb::block_stream2<BF>(lds_w + e.blk0 + l * e.blk_stride, b, lane);
+            for (int l = 0; l < NL; ++l) qb::block_stream2<BF>(lds_w + e.blk0 + l * e.blk_stride, b, lane, &amax);
             f32x4 hd[HT];
-            qb::dense_head<HT, BF>(lds_w + e.head_A, lds_w + e.head_b, b, hd, lane);
+            qb::dense_head<HT, BF>(lds_w + e.head_A, lds_w + e.head_b, b, hd, lane, &amax);
             float o[5 + T];
             qb::gather_head<5 + T, HT>(hd, o);
+            if (!BF && qb::split_overflowed(voxel_max(amax))) {
+#pragma unroll
+                for (int k = 0; k < 5 + T; ++k) o[k] = __builtin_nanf("");
+            }
             if (v < N) {
                 if (out2 && g == 0) {
 #pragma unroll
@@ -148,12 +163,17 @@ __global__ __launch_bounds__(kEncBlock) void encoder_fwd_kernel(
             }
         }
         if (out1) {
+            float amax = lds_w[e.flag];
 #pragma unroll
-            for (int l = 0; l < NL; ++l) qb::block_stream1<BF>(lds_w + e.blk0 + l * e.blk_stride, a, lane);
+            for (int l = 0; l < NL; ++l) qb::block_stream1<BF>(lds_w + e.blk0 + l * e.blk_stride, a, lane, &amax);
             f32x4 hd[HT];
-            qb::dense_head<HT, BF>(lds_w + e.head_A, lds_w + e.head_b, a, hd, lane);
+            qb::dense_head<HT, BF>(lds_w + e.head_A, lds_w + e.head_b, a, hd, lane, &amax);
             float o[5];
             qb::gather_head<5, 1>(reinterpret_cast<f32x4(&)[1]>(hd[0]), o);
+            if (!BF && qb::split_overflowed(voxel_max(amax))) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) o[k] = __builtin_nanf("");
+            }
             if (v < N && g == 2) {
 #pragma unroll
                 for (int k = 0; k < 5; ++k) out1[v * 5 + k] = o[k];
@@ -199,6 +219,7 @@ extern "C" int qbold_encoder_pack(const qbold_ctx* ctx, const qbold_encoder_shap
     const EncLayout e = qb::make_enc_layout(shape->T, shape->U, shape->L);
     const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating,
                                              shape->spatial_taps);
+    QB_HIP(hipMemsetAsync(packed + e.flag, 0, sizeof(float), (hipStream_t)stream));
     hipLaunchKernelGGL(pack_kernel, dim3((2 * e.total + 255) / 256), dim3(256), 0, (hipStream_t)stream, e,
                        c, shape->gate_offset, shape->precision == QBOLD_ENC_BF16, weights, packed);
     QB_HIP(hipGetLastError());

@@ -79,6 +79,9 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
         const int64_t v = tile * 16 + i;
         const int64_t vc = v < N ? v : N - 1;
         float o[5 + T];
+        // largest activation this lane split (operand range guard, encoder_core.h); starts from the image's flag
+        // slot: 0, or the largest weight the pack kernel could not split
+        float amax = lds_w[e.flag];
         {
             __builtin_amdgcn_s_setprio(QB_PRIO_TILE_START);
             float xv[T], nv[T];
@@ -90,9 +93,9 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
             qb::dense_first<T, BF>(lds_w + e.first_A, lds_w + e.first_b, nv, b, lane);
             if (!(c.debug_skip & 1))
 #pragma unroll
-                for (int l = 0; l < NL; ++l) qb::block_stream2<BF>(lds_w + e.blk0 + l * e.blk_stride, b, lane);
+                for (int l = 0; l < NL; ++l) qb::block_stream2<BF>(lds_w + e.blk0 + l * e.blk_stride, b, lane, &amax);
             f32x4 hd[HT];
-            qb::dense_head<HT, BF>(lds_w + e.head_A, lds_w + e.head_b, b, hd, lane);
+            qb::dense_head<HT, BF>(lds_w + e.head_A, lds_w + e.head_b, b, hd, lane, &amax);
             qb::gather_head<5 + T, HT>(hd, o);
             __builtin_amdgcn_s_setprio(0);
         }
@@ -115,6 +118,8 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
             float nll_part, kl_part;
             qb::voxel_mc_sums<T, SE, FAST, LITERAL>(L, c, lik, qm, prior + v * 5, S, K, nullptr, nullptr, seed,
                                                     (uint64_t)(voxel0 + v), g, nll_part, kl_part);
+            // an activation beyond the f16 operand range: this voxel's terms become NaN (never a silent clamp)
+            if (!BF && qb::split_overflowed(amax)) nll_part = __builtin_nanf("");
             const float nll = qb::voxel_sum(nll_part) / (float)S;
             const float kl = K > 0 ? qb::voxel_sum(kl_part) / (float)K : 0.0f;
             if (g == 0) {

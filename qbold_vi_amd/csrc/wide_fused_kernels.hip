@@ -64,6 +64,11 @@ constexpr int kAhead = 4;         // stages requested beyond the one being read 
                                   // 6-bit vmcnt also has to hold a pass's signal loads and head stores)
 constexpr int kStageFrags = 16;   // 1 KiB fragments per stage
 constexpr int kVoxPerPass = 128;  // 4 waves x 32 voxels
+#ifndef QB_FUSED_PAIRS_AHEAD
+#define QB_FUSED_PAIRS_AHEAD 1
+#endif
+constexpr int kPairsAhead = QB_FUSED_PAIRS_AHEAD;  // fragment pairs requested ahead of the MFMAs (1 or 2; two cost
+                                                   // eight more VGPRs, which three panels do not leave)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define QB_MFMA32_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
@@ -198,7 +203,10 @@ __device__ __forceinline__ f16x8 frag_lo(const Panel<KS>& P, int s) {
 }
 // x = hi + lo, hi = f16(x), lo = f16(x - hi), for a pair of values: one packed conversion for the hi halves,
 // and each lo half straight from a mixed-precision FMA (x - hi is exact in float32; the FMA rounds it to f16)
-__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo, float& amax) {
+    amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));  // v_max3_f32: operand range guard (encoder_core.h)
+    asm volatile("" : "+v"(amax));  // here and now: left free, the compiler parks every value in scratch and
+                                    // evaluates the whole max tree where amax is read, at the head
     uint32_t h = __builtin_bit_cast(uint32_t, qb::f16x2{(_Float16)a, (_Float16)b}), l;
     asm volatile("" : "+v"(h));  // one packed register from here on
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
@@ -262,6 +270,12 @@ template <int V>
 struct IC {
     static constexpr int value = V;
 };
+__device__ __forceinline__ void lds_wait_all(u32x4& a, u32x4& b, u32x4& c) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
+}
+__device__ __forceinline__ void lds_wait_all(u32x4& a, u32x4& b, uint32_t& c) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
+}
 // every LDS read but the two youngest (the pair requested last) has returned
 __device__ __forceinline__ void lds_wait_but2(u32x4& a, u32x4& b) {
     asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b));
@@ -274,8 +288,9 @@ __device__ __forceinline__ void lds_wait_but2(u32x4& a, u32x4& b, uint32_t& c) {
 }
 // biases requested one k-step ahead travel as a pair of plain variables: one value (sixteen-step tiles) or four
 // (four-step tiles)
-#define QB_BIAS_REFS uint32_t &bias, u32x4 &bias4
-#define QB_BIAS_ARGS bias, bias4
+// ... together with the lane's operand range guard (largest activation split so far, encoder_core.h)
+#define QB_BIAS_REFS uint32_t &bias, u32x4 &bias4, float &amax
+#define QB_BIAS_ARGS bias, bias4, amax
 template <int OFF>
 __device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
     static_assert(OFF >= 0 && OFF < 65536, "ds_read_b32 immediate offset is 16 bits");
@@ -333,7 +348,7 @@ __device__ __forceinline__ void tile_steps(Stream& S, uint32_t bias_lds, Frag wa
             }
         }
         Frag n;
-        frag_fetch<F0 + 2 * S_ + 4, FP>(S, n);
+        frag_fetch<F0 + 2 * S_ + 2 * kPairsAhead, FP>(S, n);
         // the reads are in flight BEFORE this step's MFMAs and waited for AFTER them: nothing crosses either fence
         __builtin_amdgcn_sched_barrier(0);
         const f16x8 h = __builtin_bit_cast(f16x8, wa.hi), l = __builtin_bit_cast(f16x8, wa.lo);
@@ -365,12 +380,21 @@ __device__ __forceinline__ void tile_steps(Stream& S, uint32_t bias_lds, Frag wa
             __builtin_amdgcn_sched_group_barrier(0x002, QB_FUSED_VALU_PER_MFMA, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (PPS == 1) lds_wait_but2(wb.hi, wb.lo, nbias);
-        else if constexpr (PPS == 4) lds_wait_but2(wb.hi, wb.lo, nbias4);
-        else lds_wait_but2(wb.hi, wb.lo);
+        if constexpr (kPairsAhead == 2) {
+            if constexpr (PPS == 1) lds_wait_but2(wb.hi, wb.lo, nbias);
+            else if constexpr (PPS == 4) lds_wait_but2(wb.hi, wb.lo, nbias4);
+            else lds_wait_but2(wb.hi, wb.lo);
+        } else {  // one pair ahead: everything requested has to be back
+            if constexpr (PPS == 1) lds_wait_all(n.hi, n.lo, nbias);
+            else if constexpr (PPS == 4) lds_wait_all(n.hi, n.lo, nbias4);
+            else lds_wait(n.hi, n.lo);
+        }
         bias = nbias;
         bias4 = nbias4;
-        tile_steps<KSOP, F0, FP, BOFF, PBOFF, HAVE_PREV, S_ + 1>(S, bias_lds, wb, n, oa, ob, in, acc, QB_BIAS_ARGS, prev);
+        if constexpr (kPairsAhead == 2)
+            tile_steps<KSOP, F0, FP, BOFF, PBOFF, HAVE_PREV, S_ + 1>(S, bias_lds, wb, n, oa, ob, in, acc, QB_BIAS_ARGS, prev);
+        else
+            tile_steps<KSOP, F0, FP, BOFF, PBOFF, HAVE_PREV, S_ + 1>(S, bias_lds, n, n, oa, ob, in, acc, QB_BIAS_ARGS, prev);
     } else {
         oa = wa;
         ob = wb;
@@ -424,7 +448,7 @@ enum { EPI_RELU = 0, EPI_LINEAR = 1, EPI_GATE = 2 };
 // odd one splits and stores the pair.  EPI_GATE: out = skip (1 - g) + r g, g = sigmoid(W r + b) (model.py:164-170).
 template <int EPI, int M, int E, int KS>
 __device__ __forceinline__ void epi_elem(const f32x16& acc, float inv_scale, float bias, Panel<KS>& out,
-                                         const Panel<KS>& skip, const Panel<KS>& rr, float& carry) {
+                                         const Panel<KS>& skip, const Panel<KS>& rr, float& carry, float& amax) {
     float y = fmaf(acc[E], inv_scale, bias);
     if constexpr (EPI == EPI_RELU) y = fmaxf(y, 0.0f);
     if constexpr (EPI == EPI_GATE) {
@@ -433,7 +457,7 @@ __device__ __forceinline__ void epi_elem(const f32x16& acc, float inv_scale, flo
         y = fmaf(gate, r - sk, sk);           // skip (1 - g) + r g, model.py:170
     }
     if constexpr (E % 2 == 0) carry = y;
-    else split_pair(carry, y, out.hi[2 * M + E / 8][(E % 8) / 2], out.lo[2 * M + E / 8][(E % 8) / 2]);
+    else split_pair(carry, y, out.hi[2 * M + E / 8][(E % 8) / 2], out.lo[2 * M + E / 8][(E % 8) / 2], amax);
 }
 
 // the dense op's 2^-e (LDS aux image, float index IDX): wave-uniform
@@ -477,7 +501,7 @@ __device__ __forceinline__ void dense_op(Stream& S, uint32_t bias_lds, float inv
             if constexpr (!AHEAD)
 #endif
                 b = lds_read4_now<(BOFF + 32 * PM + bias_row(E)) * 4>(bias_lds);
-            epi_elem<EPI, PM, E>(acc[(M + 1) & 1], inv_scale, b, out, skip, rr, carry);
+            epi_elem<EPI, PM, E>(acc[(M + 1) & 1], inv_scale, b, out, skip, rr, carry, amax);
         };
         tile_mma<KSIN, F0 + M * 2 * KSIN, FP, BOFF + 32 * M, BOFF + 32 * PM, (M > 0)>(S, bias_lds, wa, wb, in,
                                                                                        acc[M & 1], QB_BIAS_ARGS, prev);
@@ -489,7 +513,7 @@ __device__ __forceinline__ void dense_op(Stream& S, uint32_t bias_lds, float inv
         last_tile_bias<BOFF + 32 * (MT - 1)>(bias_lds, bl);
         auto last = [&](auto c) {
             constexpr int E = decltype(c)::value;
-            epi_elem<EPI, MT - 1, E>(acc[(MT - 1) & 1], inv_scale, bl[E], out, skip, rr, carry);
+            epi_elem<EPI, MT - 1, E>(acc[(MT - 1) & 1], inv_scale, bl[E], out, skip, rr, carry, amax);
         };
         last(IC<0>{}); last(IC<1>{}); last(IC<2>{}); last(IC<3>{}); last(IC<4>{}); last(IC<5>{}); last(IC<6>{});
         last(IC<7>{}); last(IC<8>{}); last(IC<9>{}); last(IC<10>{}); last(IC<11>{}); last(IC<12>{}); last(IC<13>{});
@@ -554,7 +578,7 @@ __device__ __forceinline__ void load_x(const FusedArgs& a, int64_t v, int h, XRa
 }
 // normalise_data (model.py:97-113) and the split into B operands
 template <int KS1>
-__device__ __forceinline__ void convert_x(const FusedArgs& a, int h, const XRaw<KS1>& xr, Panel<KS1>& X) {
+__device__ __forceinline__ void convert_x(const FusedArgs& a, int h, const XRaw<KS1>& xr, Panel<KS1>& X, float& amax) {
     float den = qb::clampf_(xr.d[1], 1e-2f, 1e8f);
     if (a.multi_norm) den = (qb::clampf_(xr.d[0], 1e-2f, 1e8f) + den + qb::clampf_(xr.d[2], 1e-2f, 1e8f)) / 3.0f;
     const bool wide_rows = (a.T & 3) == 0 && a.T >= 8;
@@ -568,7 +592,7 @@ __device__ __forceinline__ void convert_x(const FusedArgs& a, int h, const XRaw<
         for (int j = 0; j < 8; ++j)  // v_log_f32 as the LDS-resident kernels (encoder_core.h normalise)
             f[j] = (whole && t0 + j < a.T) ? QB_LN2 * qb::log2f_(qb::clampf_(xr.f[s][j], 1e-2f, 1e8f) * inv_den) : 0.0f;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) split_pair(f[2 * d], f[2 * d + 1], X.hi[s][d], X.lo[s][d]);
+        for (int d = 0; d < 4; ++d) split_pair(f[2 * d], f[2 * d + 1], X.hi[s][d], X.lo[s][d], amax);
     }
 }
 
@@ -580,6 +604,7 @@ struct HeadOut {
     __amdgpu_buffer_rsrc_t ls, q;
     uint32_t ls_off, q_off;  // byte offsets of this lane's voxel inside the pass
     int T;
+    bool overflow;           // an activation of this voxel left the f16 operand range: its outputs become NaN
 #ifdef QB_X_GLOBAL_STORE
     float* pls; float* pq; int64_t vv, N;
 #endif
@@ -589,7 +614,7 @@ struct HeadOut {
 // five q rows.
 template <int LT, int M, int E>
 __device__ __forceinline__ void head_elem(const f32x16& acc, float inv_scale, float bias, const HeadOut& o, int h) {
-    const float y = fmaf(acc[E], inv_scale, bias);
+    const float y = o.overflow ? __builtin_nanf("") : fmaf(acc[E], inv_scale, bias);
     const int row_in_tile = 8 * (E >> 2) + 4 * h + (E & 3);
 #ifdef QB_X_GLOBAL_STORE
     if (o.vv < o.N) {
@@ -675,6 +700,8 @@ __device__ __forceinline__ void blocks_and_head(Stream& S, uint32_t bias_lds, ui
             o.ls_off = local * (uint32_t)a.T * 4u;
             o.q_off = local * 20u;
             o.T = a.T;
+            // (the head's own input was split by the last gate op: amax is complete here)
+            o.overflow = qb::split_overflowed(fmaxf(amax, __shfl_xor(amax, 32, 64)));
 #ifdef QB_X_GLOBAL_STORE
             o.pls = a.ls; o.pq = a.q; o.vv = v; o.N = a.N;
 #endif
@@ -722,12 +749,17 @@ __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
     for (int k = 0; k < kAhead; ++k) stream_issue(S);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kAhead - 1)) : "memory");  // stage 0 has landed (my quarter)
     __syncthreads();                                                          // ... everyone's; the biases too
-    Frag wa, wb;  // the next two fragment pairs of the stream
+    Frag wa, wb;  // the next fragment pair(s) of the stream
     wa.hi = lds_read16<0>(S.cur);
     wa.lo = lds_read16<1024>(S.cur);
-    wb.hi = lds_read16<2048>(S.cur);
-    wb.lo = lds_read16<3072>(S.cur);
-    lds_wait(wa.hi, wa.lo, wb.hi, wb.lo);
+    if constexpr (kPairsAhead == 2) {
+        wb.hi = lds_read16<2048>(S.cur);
+        wb.lo = lds_read16<3072>(S.cur);
+        lds_wait(wa.hi, wa.lo, wb.hi, wb.lo);
+    } else {
+        lds_wait(wa.hi, wa.lo);
+        wb = wa;
+    }
     uint32_t bias = 0u;                    // bias of the next step's epilogue piece (requested one step ahead)
     u32x4 bias4 = u32x4{0u, 0u, 0u, 0u};   // ... of the next step's four pieces (the first layer)
 
@@ -742,7 +774,8 @@ __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
         const int64_t v = blk * kVoxPerPass + wave * 32 + i;
         Panel<KS1> X;
         QB_STAMP(a, 5);
-        convert_x<KS1>(a, h, xr, X);
+        float amax = 0.0f;   // this pass's voxel: largest activation split (both lane halves are merged at the head)
+        convert_x<KS1>(a, h, xr, X, amax);
         QB_STAMP(a, 6);
         Panel<KS> P0, P1, P2;
         f32x16 acc[2];

@@ -164,7 +164,10 @@ class FineTuner:
             q = _pad5(_flat(q5, q5.shape[-1])).contiguous()
             sums, nll_kl = tr._ctx.elbo_fwd(x, m, q, p5, _flat(sg5, x.shape[-1]), S, K, seed=seed, voxel0=voxel0)
         else:
-            sums, q, nll_kl = tr._ctx.vi_fwd(self.encoder_model.weights, x, m, p5, S, K, seed=seed, voxel0=voxel0)
+            # range_check: activations beyond the f16 operand split's 65504 show as non-finite sums and are
+            # recomputed on the exact-float32 layer-wise path (ops.Context.vi_fwd)
+            sums, q, nll_kl = tr._ctx.vi_fwd(self.encoder_model.weights, x, m, p5, S, K, seed=seed, voxel0=voxel0,
+                                             range_check=True)
         if not tr._use_mvg:
             ksums, kl_v = tr._ctx.kl_diag(q, p5, m)
             sums[1] = ksums[1]

@@ -418,13 +418,48 @@ class Context:
                                            _ptr(self._workspace()), N, _stream()), "qbold_elbo_fwd")
         return sums, out
 
+    def vi_fwd_exact(self, weights, x, mask, prior, S=1, K=70, seed=1, voxel0=0):
+        """The same evaluation with the encoder on the exact-float32 layer-wise path (f32-input MFMA GEMMs,
+        qbold_encoder_train_fwd) -- no f16 operand split, so no 65504 operand limit.  Slow (one launch per layer,
+        activations through HBM); the fallback of vi_fwd(range_check=True)."""
+        x = _f32(x, "x", self.T)
+        N = x.numel() // self.T
+        st = getattr(weights, "_layerwise_state", None)
+        if st is None:
+            st = weights._layerwise_state = TrainState(self, weights, optimiser_state=False)
+        q2, ls = st.forward(x.reshape(N, self.T), 2)
+        sums, nk = self.elbo_fwd(x, mask, q2, prior, self.transform("exp", ls), S, K, seed=seed, voxel0=voxel0)
+        return sums, q2, nk
+
     def vi_fwd(self, weights, x, mask, prior, S=1, K=70, seed=1, voxel0=0, want_q=True,
-               per_voxel=True, out=None):
-        """Fused encoder + ELBO.  Returns (sums, q [N,5] or None, nll_kl [N,2] or None)."""
+               per_voxel=True, out=None, range_check=False):
+        """Fused encoder + ELBO.  Returns (sums, q [N,5] or None, nll_kl [N,2] or None).
+
+        range_check: the MFMA encoders split every operand into two f16 halves (float32-grade for
+        6.1e-5 <= |x| <= 65504, include/qbold_hip.h); an activation beyond 65504 overflows to inf and surfaces as
+        NON-FINITE SUMS -- the kernels' status channel.  With range_check=True the sums are read back (one
+        device synchronisation) and a non-finite result is recomputed on the exact-float32 layer-wise path,
+        which reproduces the float32 reference wherever that is finite.  Off by default: the benchmark and the
+        training steps do not pay the synchronisation; FineTuner.elbo (the reference-shaped API) turns it on."""
         x = _f32(x, "x", self.T)
         N = x.numel() // self.T
         prior = _f32(prior, "prior", 5)
         mask = _f32(mask, "mask") if mask is not None else None
+        if range_check:
+            sums, qo, nk = self.vi_fwd(weights, x, mask, prior, S, K, seed, voxel0, want_q, per_voxel, out)
+            if N > 0 and not bool(torch.isfinite(sums).all()):
+                sums2, q2, nk2 = self.vi_fwd_exact(weights, x, mask, prior, S, K, seed, voxel0)
+                if bool(torch.isfinite(sums2).all()):   # the split overflowed, float32 did not
+                    self.range_fallbacks = getattr(self, "range_fallbacks", 0) + 1
+                    if out is not None:
+                        out[0].copy_(sums2)
+                        if out[1] is not None:
+                            out[1].copy_(q2)
+                        if out[2] is not None:
+                            out[2].copy_(nk2)
+                        return out[0], out[1], out[2]
+                    return sums2, (q2 if want_q else None), (nk2 if per_voxel else None)
+            return sums, qo, nk
         if weights.fused_wide and not self.force_layerwise_wide:
             nws = int(self.lib.qbold_vi_workspace_bytes(self.handle, C.byref(weights.shape), N))
             if nws > int(self.lib.qbold_elbo_workspace_bytes(self.handle)) + 256:  # the two-launch wide path applies

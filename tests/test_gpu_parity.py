@@ -807,3 +807,70 @@ def test_config3_full_size_properties(params):
     assert bool(torch.isfinite(sums).all()) and float(sums[2]) == float(mask.double().sum())
     window(x, mask, prior, nk, q, N - 300, 300)      # the last, partial pass; byte offsets beyond 2^31
     window(x, mask, prior, nk, q, 8_500_000, 128)
+
+
+def test_split_operand_range(ctx, weights, oracle32):
+    """The f16 operand split of the MFMA encoders against the float32 oracle at the ends of its range
+    (include/qbold_hip.h, QBOLD_ENC_F32): (1) hidden activations of several 1e5 -- beyond f16's 65504 -- poison the
+    voxel's outputs: NaN heads from qbold_encoder_fwd, non-finite sums from qbold_vi_fwd (the status channel; left
+    alone, inf - inf = NaN in the accumulators and relu's v_max_f32 would turn it into a finite, wrong number), and
+    vi_fwd(range_check=True) recomputes on the exact-float32 layer-wise path, which matches the oracle; the same
+    for a WEIGHT beyond 65504; (2) activations just inside the range keep float32-grade parity; (3) hidden
+    activations of 1e-5 (f16 subnormals in both halves) amplified back to O(1) by the heads keep an absolute error
+    of the 2.9e-11 resolution times the amplification."""
+    from oracle.oracle import synth_inputs
+    from qbold_vi_amd.ops import EncoderWeights
+    w, _ = weights
+    n, S, K, seed = 512, 4, 8, 3
+    x, _ = synth_inputs(n, seed=12, oracle=oracle32)
+    mask = np.ones(n, np.float32)
+
+    def scaled(sc_first, sc_block, sc_out):
+        w2 = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in w.items()}
+        w2["W0"], w2["b0"] = w["W0"] * sc_first, w["b0"] * sc_first   # first-layer activations scale with sc_first
+        w2["Wc"], w2["bc"] = w["Wc"].copy(), w["bc"].copy()
+        w2["Wc"][0] *= sc_block                                        # ... block 0's skip path with sc_block on top
+        w2["bc"][0] *= sc_block
+        w2["Wf"], w2["Ws"] = w["Wf"] * sc_out, w["Ws"] * sc_out       # heads bring the scale back
+        return w2
+
+    def run(w2, range_check):
+        ew = EncoderWeights(ctx, 11, 60, 2, True, -3.0).set_from_arrays(w2)
+        prior, q_want, sigma = oracle32.encoder_fwd(w2, x)
+        want = oracle32.elbo(x, mask, q_want, prior, sigma, oracle32.philox_normals(seed, 0, 0, n, S),
+                             oracle32.philox_normals(seed, 1, 0, n, K))
+        sums, q, nk = ctx.vi_fwd(ew, dev(x), dev(mask), dev(prior), S, K, seed=seed, range_check=range_check)
+        return ew, want, q_want, sums.cpu().numpy(), q.cpu().numpy()
+
+    # (1) overflow by ACTIVATIONS: weights of a few hundred, block-0 activations of several 1e5
+    big = scaled(1e3, 1e3, 1e-6)
+    assert max(np.abs(big[k]).max() for k in ("W0", "Wc")) < 6e4
+    assert np.abs(oracle32.encoder_fwd(big, x)[1]).max() < 50        # the float32 reference is perfectly finite
+    ew, want, q_want, sums, q = run(big, range_check=False)
+    assert not np.isfinite(sums).any() or not np.isfinite(sums[:2]).all()   # status: non-finite sums
+    o2 = ctx.encoder_fwd(ew, dev(x), want=("out2",))[1]
+    assert int(torch.isnan(o2).any(1).sum()) > n // 2                # poisoned heads, not clamped numbers
+    before = getattr(ctx, "range_fallbacks", 0)
+    ew, want, q_want, sums, q = run(big, range_check=True)
+    assert ctx.range_fallbacks == before + 1 and np.isfinite(sums).all()
+    assert np.max(np.abs(q - q_want)) < 1e-3 * max(1.0, np.abs(q_want).max())   # float32 GEMMs of 1e5-sized terms
+    assert abs((sums[0] + sums[1]) / sums[2] - want["elbo"]) < 1e-3 * abs(want["elbo"])
+    # ... and by a WEIGHT the pack kernel cannot split
+    hot = scaled(3e5, 1.0, 1.0 / 3e5)
+    assert np.abs(hot["W0"]).max() > 65504
+    ew, want, q_want, sums, q = run(hot, range_check=False)
+    assert not np.isfinite(sums[:2]).all()
+    # (2) just inside: activations of a few 1e4
+    mid = scaled(20.0, 1e3, 5e-5)
+    ew, want, q_want, sums, q = run(mid, range_check=False)
+    assert np.isfinite(sums).all() and np.max(np.abs(q - q_want)) < 5e-5 * max(1.0, np.abs(q_want).max())
+    assert abs((sums[0] + sums[1]) / sums[2] - want["elbo"]) < 1e-4 * abs(want["elbo"])
+    # (3) tiny activations (1e-5 and less: below f16's smallest normal 6.1e-5), amplified by 1e5 in the heads
+    tiny = scaled(1e-5, 1.0, 1e5)      # (head weights of ~2e4: an amplification of 1e6 would leave the WEIGHT range)
+    for k in ("bc", "br1", "br2"):     # every hidden activation scales with 1e-5 (the layers are positively homogeneous)
+        tiny[k] = w[k] * 1e-5
+    assert np.abs(oracle32.encoder_fwd(tiny, x)[1]).max() < 50
+    ew, want, q_want, sums, q = run(tiny, range_check=False)
+    assert np.isfinite(sums).all()
+    # absolute resolution 2^-35 per operand, 60 terms, x 2e4 head weights: a few 1e-5 on an O(1) head output
+    assert np.max(np.abs(q - q_want)) < 2e-4
