@@ -149,12 +149,19 @@ class FineTuner:
         # 'predictions' is the S-fold tiled distribution, as in the reference (model.py:245,285)
         return {'predictions': qs, 'predicted_images': torch.cat([output, sig], -1)}
 
-    def elbo(self, data, mask, prior, no_samples=None, kl_samples=70, seed=1, voxel0=0):
+    def elbo(self, data, mask, prior, no_samples=None, kl_samples=70, seed=1, voxel0=0, kl_tiled=None):
         """The fused path: one launch for encoder + S draws + forward model + NLL + K-draw KL
         (image crops: spatial encoder, then the ELBO kernel).
-        Returns dict(nll, kl, elbo (= nll + kl, train.py:351), sums, q, nll_kl)."""
+        Returns dict(nll, kl, elbo (= nll + kl, train.py:351), sums, q, nll_kl).
+
+        kl_tiled (default: the trainer's setting, True = the reference's behaviour): with no_samples = S > 1 the
+        reference tiles the batch S-fold (model.py:245-246, 656) and kl_loss draws `kl_samples` KL samples per TILED
+        row, i.e. S * kl_samples draws per voxel, averaged (model.py:592-610, 661-663).  The kernels never tile; the
+        same estimator is S * kl_samples in-kernel draws per voxel.  kl_tiled=False draws kl_samples per voxel
+        whatever S (same expectation, S times fewer draws: round 1's behaviour)."""
         tr = self._trainer
         S = tr._no_samples if no_samples is None else no_samples
+        kl_samples = tr.kl_draws(kl_samples, S, kl_tiled)
         x = _flat(data, data.shape[-1])
         m = None if mask is None else mask.reshape(-1)
         p5 = _pad5(_flat(prior, prior.shape[-1])).contiguous()
@@ -216,6 +223,7 @@ class EncoderTrainer:
         self._use_population_prior = use_population_prior
         self._mog_components = mog_components
         self._no_samples = no_samples
+        self._kl_tiled = True   # KL draws per voxel = no_samples x kl_samples, as the reference's tiled batch gives
         self._oef_range = 0.8
         self._min_oef = 0.04
         self._dbv_range = 0.2
@@ -305,6 +313,13 @@ class EncoderTrainer:
                                    else "backwards_transform", signal)
 
     # -- sampling / moments (model.py:318-374) -----------------------------------------------
+    def kl_draws(self, kl_samples, no_samples=None, kl_tiled=None):
+        """KL draws per voxel: kl_samples per copy of the S-fold tiled batch of the reference (model.py:245-246, 656),
+        i.e. S * kl_samples, unless kl_tiled is off."""
+        S = self._no_samples if no_samples is None else no_samples
+        tiled = self._kl_tiled if kl_tiled is None else kl_tiled
+        return int(kl_samples) * (int(S) if tiled else 1)
+
     def create_samples(self, predicted_params, mask, no_samples, seed=None):
         q = _pad5(_flat(predicted_params, predicted_params.shape[-1])[:, :self._nq]).contiguous()
         z = self._ctx.normals(q.shape[0], no_samples, stream_id=2,

@@ -213,6 +213,7 @@ def _elbo_bwd(trainer, x, mask, q, prior5, ls, S, K, seed, voxel0):
     """Head gradients of m nll + [m > 0] kl.  Diagonal family (use_mvg=False): the sampled KL is
     replaced by the closed form (model.py:686-716), whose gradient reaches every q parameter, and the
     unused Cholesky column carries no gradient."""
+    K = trainer.kl_draws(K, S)   # K per copy of the reference's S-fold tiled batch (model.py:245-246, 656)
     ctx = trainer.context
     if trainer._use_mvg:
         sums, gq, gls, _ = ctx.elbo_bwd(x, mask, q, prior5, ls, S, K, seed=seed, voxel0=voxel0)

@@ -173,6 +173,19 @@ def test_encoder_trainer_interface(trainer, params, oracle32):
     zk = oracle32.philox_normals(9, 1, 0, n, 70)
     ref = oracle32.elbo(x, mask[:, 0], w2, w1, ws, zs, zk)
     assert abs(float(fused['elbo']) - ref['elbo']) < 1e-4 * abs(ref['elbo'])
+    # no_samples = S > 1: the reference draws kl_samples KL samples per copy of its S-fold tiled batch, i.e.
+    # S * kl_samples per voxel (default, kl_tiled=True); kl_tiled=False draws kl_samples per voxel -- same KL in
+    # expectation
+    S3 = 3
+    tiled = full_model.elbo(x5, mask5, out1, no_samples=S3, kl_samples=70, seed=9)
+    ref3 = oracle32.elbo(x, mask[:, 0], w2, w1, ws, oracle32.philox_normals(9, 0, 0, n, S3),
+                         oracle32.philox_normals(9, 1, 0, n, S3 * 70))
+    assert abs(float(tiled['kl']) - ref3['kl']) < 1e-4 * abs(ref3['kl']) + 1e-5
+    assert abs(float(tiled['elbo']) - ref3['elbo']) < 1e-4 * abs(ref3['elbo'])
+    flat = full_model.elbo(x5, mask5, out1, no_samples=S3, kl_samples=70, seed=9, kl_tiled=False)
+    d = (flat['nll_kl'][:, 1] - tiled['nll_kl'][:, 1]).cpu().numpy()
+    assert abs(float(flat['kl']) - float(tiled['kl'])) < 6.0 * d.std() / np.sqrt(n) + 1e-6
+    assert trainer.kl_draws(70, 4) == 280 and trainer.kl_draws(70, 4, kl_tiled=False) == 70
     # posterior moments via the trainer
     means, var = trainer.calculate_means(out2, None, include_r2p=True, return_stds=True,
                                          no_samples=200, seed=3)

@@ -461,3 +461,27 @@ def test_two_independent_restatements_agree_on_config_1(oracle32, params):
         oc = Oracle("f32", params, full_model=full, include_blood=blood)
         s_c, s_t = oc.signal_fwd(y[:512]), tr.signal_model(y[:512], params, full, blood).numpy()
         assert np.max(np.abs(s_c - s_t) / np.abs(s_c)) < 2e-6
+
+
+def test_kl_draw_count_under_the_tiled_batch(oracle32, params):
+    """With no_samples = S > 1 the reference concatenates S copies of the batch (model.py:245-246, 656) and draws K
+    KL samples per COPY: S * K draws per voxel, averaged.  The torch restatement does exactly that (tiled rows);
+    the kernels / C oracle never tile and draw S * K per voxel instead -- the same numbers when fed the same
+    normals, which is what EncoderTrainer.kl_draws() asks of them by default."""
+    torch = pytest.importorskip("torch")
+    from oracle import torch_ref as tr
+    from oracle.oracle import init_weights, synth_inputs
+    n, S, K = 256, 3, 10
+    w = init_weights(T=11, U=16, L=1, seed=5)
+    w["gate_offset"] = -3.0
+    x, _ = synth_inputs(n, params, seed=4, oracle=oracle32)
+    p1, q2, sg = oracle32.encoder_fwd(w, x)
+    mask = np.ones(n, np.float32)
+    zs, zk = oracle32.philox_normals(2, 0, 0, n, S), oracle32.philox_normals(2, 1, 0, n, S * K)
+    tiled = tr.elbo(x, mask, q2, p1, sg, zs, zk, params, oracle32.se_idx, kl_tiled=True)
+    flat = oracle32.elbo(x, mask, q2, p1, sg, zs, zk)          # S * K draws per voxel, no tiling
+    assert np.max(np.abs(tiled["kl_v"] - flat["kl_v"]) / (np.abs(flat["kl_v"]) + 1.0)) < 1e-5
+    assert abs(tiled["kl"] - flat["kl"]) < 1e-5 * abs(flat["kl"])
+    # K draws per voxel (kl_tiled=False) estimate the same KL with S times fewer draws
+    few = oracle32.elbo(x, mask, q2, p1, sg, zs, zk[:, :K])
+    assert abs(few["kl"] - flat["kl"]) < 6.0 * np.std(few["kl_v"] - flat["kl_v"]) / np.sqrt(n) + 1e-6
