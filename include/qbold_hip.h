@@ -359,6 +359,15 @@ int qbold_encoder_train_bwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
 int qbold_synth_loss_bwd(const qbold_ctx* ctx, const float* y_true, int ld_y, const float* q, float* g_q,
                          float* loss_v, float scale, double inv_gamma_alpha, double inv_gamma_beta,
                          int64_t N, void* stream);
+/* The learned inverse-gamma hyper-prior of synthetic_data_loss (infer_inv_gamma with the diagonal family,
+ * model.py:201-205, 454-455, 493-507): ig_host = HOST double[4] (alpha_oef, beta_oef, alpha_dbv, beta_dbv), the
+ * exp-activated VariableLayer values.  Per voxel - log IG(exp(2 s_o); a_o, b_o) - log IG(exp(2 s_d); a_d, b_d) is
+ * ADDED to loss_v [N], scale * its gradient to g_q [N][5] (columns 1, 3); stats: DEVICE double[4] = sum log v_o,
+ * sum 1 / v_o, sum log v_d, sum 1 / v_d -- what the gradient with respect to the four hyper-parameters needs
+ * (d / d a = digamma(a) - log b + mean log v, d / d b = - a / b + mean 1 / v).  Any of g_q / loss_v / stats may be
+ * NULL.  Call after qbold_synth_loss_bwd. */
+int qbold_hyper_prior_bwd(const qbold_ctx* ctx, const float* q, const double* ig_host, float scale, float* g_q,
+                          float* loss_v, double* stats, int64_t N, void* stream);
 /* The R2' term of synthetic_data_loss (use_r2p_loss, model.py:475-490): n_samples (reference: 10)
  * reparameterised draws of (OEF, DBV) from q [N][5], r = dw(OEF) DBV (calculate_r2p :524-525), a normal
  * fitted by the draws' mean and biased std, gaussian_nll (:403-404) of the true R2' y_true[:, 2] under it.

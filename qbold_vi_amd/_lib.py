@@ -103,6 +103,7 @@ SIGNATURES = {
     "qbold_wls_fit": (C.c_int, [_P, _P, C.c_double, _P, C.c_int64, _P]),
     "qbold_smoothness": (C.c_int, [_P, _P, _P, C.POINTER(Geometry), C.c_float, _P, _P, _P]),
     "qbold_synth_loss_bwd": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_float, C.c_double, C.c_double, _I64, _P]),
+    "qbold_hyper_prior_bwd": (C.c_int, [_P, _P, _P, C.c_float, _P, _P, _P, _I64, _P]),
     "qbold_r2p_loss_bwd": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _U64, _I64, C.c_float, _P, _P, _I64, _P]),
     "qbold_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _I64, C.c_double, C.c_double, C.c_double,
                                    C.c_double, C.c_double, _I64, _P]),

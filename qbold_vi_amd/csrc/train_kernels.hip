@@ -9,6 +9,8 @@
 // matrix instruction (v_mfma_f32_16x16x4_f32), one layer per launch, activations saved to HBM:
 // training steps are 190-256 k voxels in the reference (train.py:68,103), ~1 GB of activations,
 // and HBM-bound at a few ms per step -- off the voxel-ELBO headline path, correctness first.
+#include <cmath>
+
 #include "canon_layout.h"
 #include "encoder_core.h"
 #include "qbold_ctx.h"
@@ -1354,6 +1356,44 @@ __global__ void nlogp_bwd_kernel(const float* __restrict__ y_true, int ldy, cons
     }
 }
 
+// The learned inverse-gamma hyper-prior of the pre-training loss (infer_inv_gamma with the diagonal family,
+// model.py:201-205, 454-455, 493-507): per voxel
+//   term = - log IG(v_o; a_o, b_o) - log IG(v_d; a_d, b_d),   v = exp(2 s),  s = transform_std(raw)
+//        = sum_dim [ lgamma(a) - a log b + (a + 1) log v + b / v ]
+// ADDED to loss_v; scale * d term / d q ADDED to g_q (columns 1 and 3); and the four sums the gradient with
+// respect to (a_o, b_o, a_d, b_d) needs -- sum log v_o, sum 1 / v_o, sum log v_d, sum 1 / v_d -- into stats.
+__global__ __launch_bounds__(256) void hyper_prior_kernel(const float* __restrict__ q, float a_o, float b_o, float c_o,
+                                                          float a_d, float b_d, float c_d, float scale,
+                                                          float* __restrict__ g_q, float* __restrict__ loss,
+                                                          double* __restrict__ stats, int64_t N) {
+    __shared__ double red[4][4];
+    double s_lo = 0.0, s_io = 0.0, s_ld = 0.0, s_id = 0.0;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < N;
+         v += (int64_t)gridDim.x * blockDim.x) {
+        const float so = qb::transform_std(q[v * 5 + 1]), sd = qb::transform_std(q[v * 5 + 3]);
+        const float lvo = 2.0f * so, lvd = 2.0f * sd;              // log v
+        const float ivo = __expf(-lvo), ivd = __expf(-lvd);        // 1 / v
+        if (loss) loss[v] += (c_o + (a_o + 1.0f) * lvo + b_o * ivo) + (c_d + (a_d + 1.0f) * lvd + b_d * ivd);
+        if (g_q) {
+            const float to = (so + 1.0f) * (1.0f / 3.0f), td = (sd + 1.0f) * (1.0f / 3.0f);   // tanh(raw)
+            g_q[v * 5 + 1] += scale * (2.0f * (a_o + 1.0f) - 2.0f * b_o * ivo) * 3.0f * (1.0f - to * to);
+            g_q[v * 5 + 3] += scale * (2.0f * (a_d + 1.0f) - 2.0f * b_d * ivd) * 3.0f * (1.0f - td * td);
+        }
+        s_lo += lvo; s_io += ivo; s_ld += lvd; s_id += ivd;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double vals[4] = {s_lo, s_io, s_ld, s_id};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double x = vals[k];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        if (lane == 0) red[wave][k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && stats)
+        atomicAdd(stats + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // copy g_q [N][5] and g_ls [N][T] into one [N][ld] delta tensor (cols 0-4, 5..5+T-1), scaled.  Only the
 // first 5 + T columns (rounded up to 4) of a row are written: the GEMMs that read this tensor take ndim /
 // kdim = 5 or T columns of it and zero everything beyond by select, so the rest of the row is never used.
@@ -1860,6 +1900,24 @@ extern "C" int qbold_synth_loss_bwd(const qbold_ctx* ctx, const float* y_true, i
     int64_t cap = (int64_t)ctx->num_cus * 8;
     hipLaunchKernelGGL(nlogp_bwd_kernel, dim3((int)(nb < cap ? nb : cap)), dim3(256), 0,
                        (hipStream_t)stream, y_true, ld_y, q, g_q, 5, loss_v, scale, ig_a, ig_b, ig_c0, N);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
+extern "C" int qbold_hyper_prior_bwd(const qbold_ctx* ctx, const float* q, const double* ig_host, float scale,
+                                     float* g_q, float* loss_v, double* stats, int64_t N, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    QB_REQUIRE(N > 0 && q && ig_host && (g_q || loss_v || stats), "qbold_hyper_prior_bwd: bad argument");
+    for (int k = 0; k < 4; ++k)
+        QB_REQUIRE(ig_host[k] > 0.0 && std::isfinite(ig_host[k]), "qbold_hyper_prior_bwd: inverse-gamma parameters must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    if (stats) QB_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(double), s));
+    const double ao = ig_host[0], bo = ig_host[1], ad = ig_host[2], bd = ig_host[3];
+    int64_t nb = (N + 255) / 256;
+    int64_t cap = (int64_t)ctx->num_cus * 8;
+    hipLaunchKernelGGL(hyper_prior_kernel, dim3((int)(nb < cap ? nb : cap)), dim3(256), 0, s, q, (float)ao, (float)bo,
+                       (float)(lgamma(ao) - ao * log(bo)), (float)ad, (float)bd, (float)(lgamma(ad) - ad * log(bd)),
+                       scale, g_q, loss_v, stats, N);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }

@@ -24,6 +24,8 @@ def _pad5(t):
     (use_mvg=False, model.py:33-37) is the 5-parameter one with a zero Cholesky term."""
     if t.shape[-1] == 5:
         return t
+    if t.shape[-1] == 8:   # infer_inv_gamma: [4 parameters | 4 hyper-parameters] (model.py:205): the parameters
+        t = t[..., :4]
     if t.shape[-1] != 4:
         raise ValueError("distribution parameters must have 4 (use_mvg=False) or 5 channels")
     return torch.cat([t, torch.zeros_like(t[..., :1])], -1)
@@ -42,9 +44,22 @@ class EncoderModel:
     def __init__(self, trainer, weights):
         self._trainer = trainer
         self.weights = weights
+        # infer_inv_gamma (model.py:201-205): a tfp VariableLayer of four exp-activated scalars -- the inverse-gamma
+        # (alpha, beta) of the OEF and DBV variances -- initialised to log([20, 2.5, 20, 2.5]) and appended to the
+        # first output as constant channels.  Host state (four numbers): hyper_raw holds the logs.
+        self.hyper_raw = np.log(np.array([20.0, 2.5, 20.0, 2.5])) if trainer._infer_inv_gamma else None
+
+    def hyper_params(self):
+        return np.exp(self.hyper_raw)
 
     def __call__(self, x):
         return self.predict(x)
+
+    def _with_hyper(self, o1):
+        if o1 is None or self.hyper_raw is None:
+            return o1
+        h = torch.as_tensor(self.hyper_params(), dtype=o1.dtype, device=o1.device)
+        return torch.cat([o1, h.expand(o1.shape[:-1] + (4,))], -1)   # model.py:205
 
     def predict(self, x, want=("out1", "out2", "sigma")):
         """Voxel batches go through the fused kernels; image crops [B, X, Y, Z, T] (X or Y > 1) get
@@ -54,8 +69,8 @@ class EncoderModel:
         cut = (lambda t: t if t is None or nq == 5 else t[..., :nq].contiguous())
         if not self._trainer._is_spatial(x):
             o1, o2, sg = ctx.encoder_fwd(self.weights, x, want=want)
-            return [cut(o1), cut(o2), sg]
-        o1 = cut(ctx.encoder_fwd(self.weights, x, want=("out1",))[0]) if "out1" in want else None
+            return [self._with_hyper(cut(o1)), cut(o2), sg]
+        o1 = self._with_hyper(cut(ctx.encoder_fwd(self.weights, x, want=("out1",))[0])) if "out1" in want else None
         o2 = sg = None
         if "out2" in want or "sigma" in want:
             st = self._trainer._spatial_state(self.weights)
@@ -69,10 +84,16 @@ class EncoderModel:
         w = self.weights.to_arrays()
         if self._trainer._nq == 4:  # the reference's final layer has 4 outputs (model.py:191-196)
             w["Wf"], w["bf"] = w["Wf"][:, :4].copy(), w["bf"][:4].copy()
+        if self.hyper_raw is not None:
+            w["hyper_prior"] = np.asarray(self.hyper_raw, np.float32)
         return w
 
     def set_weights(self, arrays):
         arrays = dict(arrays)
+        if "hyper_prior" in arrays:
+            hp = np.asarray(arrays.pop("hyper_prior"), np.float64)
+            if self.hyper_raw is not None:
+                self.hyper_raw = hp
         if np.asarray(arrays["Wf"]).shape[-1] == 4:
             Wf, bf = np.asarray(arrays["Wf"], np.float32), np.asarray(arrays["bf"], np.float32)
             arrays["Wf"] = np.concatenate([Wf, np.zeros_like(Wf[:, :1])], 1)
@@ -238,8 +259,11 @@ class EncoderTrainer:
             unsupported.append("use_layer_norm / dropout_rate (model.py:133-140)")
         if activation_type != 'relu':
             unsupported.append(f"activation_type={activation_type!r} (kernels implement 'relu')")
-        if infer_inv_gamma:
-            unsupported.append("infer_inv_gamma (model.py:201-205)")
+        if infer_inv_gamma and use_mvg:
+            # the reference itself cannot run this pair: synthetic_data_loss splits the 9-channel first output
+            # (5 + 4) in two (tf.split(y_pred_orig, 2, axis=-1), model.py:455)
+            unsupported.append("infer_inv_gamma with use_mvg=True (a shape error in the reference, model.py:455; "
+                               "the learned hyper-prior runs with the diagonal family, use_mvg=False)")
         if use_population_prior:
             unsupported.append("use_population_prior (model.py:252-271)")
         if not heteroscedastic_noise:
@@ -377,15 +401,23 @@ class EncoderTrainer:
                             inv_gamma_beta=0.0):
         """Pre-training loss (model.py:449-514): mean negative log density of the true (OEF, DBV),
         plus the inverse-gamma prior on the marginal variances when alpha * beta > 0 (:492-507)."""
-        if self._infer_inv_gamma:
-            raise NotImplementedError("infer_inv_gamma (model.py:493-496) is disabled in optimal.yaml")
         y = y_true_orig.reshape(-1, 3).contiguous()
+        hyper = None
+        if self._infer_inv_gamma:   # y_pred = [4 parameters | 4 exp-activated hyper-parameters], model.py:454-455
+            flat = _flat(y_pred_orig, y_pred_orig.shape[-1])
+            if flat.shape[-1] != 8:
+                raise ValueError("infer_inv_gamma: y_pred must carry 4 + 4 channels (model.py:201-205)")
+            hyper = [float(v) for v in flat[0, 4:8].tolist()]   # inv_gamma_params[0,0,0,0,:], model.py:494
+            y_pred_orig = flat[:, :4]
         q = _pad5(_flat(y_pred_orig, y_pred_orig.shape[-1])[:, :self._nq]).contiguous()
         offset = 0.0 if self._use_mvg else 1.8378770664093453   # logit_gaussian_log_prob, model.py:470
         if inv_gamma_alpha * inv_gamma_beta > 0.0:
             lv = self._ctx.synth_loss(y, q, inv_gamma_alpha, inv_gamma_beta)
         else:
             lv = self._ctx.logit_mvn_nlogp(y[:, :2], q)
+        if hyper is not None:   # - log IG(exp(2 s_o); a_o, b_o) - log IG(exp(2 s_d); a_d, b_d), model.py:495-507
+            lv = lv.clone()
+            self._ctx.hyper_prior_bwd(q, hyper, loss_v=lv, want_stats=False)
         if use_r2p_loss:   # model.py:475-490: ten reparameterised draws, a normal fitted to their R2'
             self._r2p_calls = getattr(self, "_r2p_calls", 0) + 1
             lv = lv.clone()

@@ -540,6 +540,21 @@ def synth_loss(self, y_true, q, inv_gamma_alpha=0.0, inv_gamma_beta=0.0):
 
 
 @_ctx_method
+def hyper_prior_bwd(self, q, ig, scale=1.0, g_q=None, loss_v=None, want_stats=True):
+    """The learned inverse-gamma hyper-prior term (infer_inv_gamma, model.py:493-507) through
+    qbold_hyper_prior_bwd: ig = (alpha_oef, beta_oef, alpha_dbv, beta_dbv) host floats.  ADDS the per-voxel term
+    to loss_v and scale * d / d q to g_q; returns the device double[4] sums (sum log v_o, sum 1/v_o, sum log v_d,
+    sum 1/v_d) or None."""
+    q = _f32(q, "q", 5)
+    N = q.shape[0]
+    ig4 = (C.c_double * 4)(*[float(v) for v in ig])
+    stats = torch.zeros(4, dtype=torch.float64, device=q.device) if want_stats else None
+    _lib.check(self.lib.qbold_hyper_prior_bwd(self.handle, _ptr(q), ig4, float(scale), _ptr(g_q), _ptr(loss_v),
+                                              _ptr(stats), N, _stream()), "qbold_hyper_prior_bwd")
+    return stats
+
+
+@_ctx_method
 def kl_diag(self, q, prior, mask=None, g_q=None, per_voxel=True):
     """Closed-form KL of the diagonal family (use_mvg=False): q, prior [N,5] (columns 0-3 used).
     Returns (sums double[3] = (0, sum [m>0] kl, sum m), kl_v [N] or None); d kl / d q is added to g_q."""

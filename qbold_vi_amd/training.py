@@ -127,6 +127,37 @@ def _check_finite(value, what):
 # ----------------------------------------------------------------------------------------------
 # phase 1: pre-training on synthetic data (train.py:379-427)
 # ----------------------------------------------------------------------------------------------
+class HyperPriorState:
+    """The four exp-activated scalars of infer_inv_gamma (model.py:201-205) under the pre-training optimiser
+    (tfa AdamW, Keras Adam moments, eps 1e-7; train.py:382-385).  With theta = log of (a_o, b_o, a_d, b_d) and the
+    batch means L = mean log v, R = mean 1 / v of a dimension, the loss term is
+    lgamma(a) - a log b + (a + 1) L + b R, so d / d a = digamma(a) - log b + L, d / d b = - a / b + R, and the
+    chain rule through exp multiplies by a (resp. b)."""
+
+    def __init__(self, model):
+        self.model = model
+        self.m = np.zeros(4)
+        self.v = np.zeros(4)
+        self.t = 0
+
+    def gradient(self, stats, n):
+        from scipy.special import digamma
+        a_o, b_o, a_d, b_d = self.model.hyper_params()
+        Lo, Ro, Ld, Rd = (float(s) / n for s in stats)
+        return np.array([a_o * (digamma(a_o) - math.log(b_o) + Lo), b_o * (-a_o / b_o + Ro),
+                         a_d * (digamma(a_d) - math.log(b_d) + Ld), b_d * (-a_d / b_d + Rd)])
+
+    def step(self, stats, n, lr, wd, beta1=0.9, beta2=0.999, eps=1e-7):
+        g = self.gradient(stats, n)
+        self.t += 1
+        self.m = beta1 * self.m + (1 - beta1) * g
+        self.v = beta2 * self.v + (1 - beta2) * g * g
+        lr_t = lr * math.sqrt(1 - beta2 ** self.t) / (1 - beta1 ** self.t)
+        th = self.model.hyper_raw
+        th = th - wd * th
+        self.model.hyper_raw = th - lr_t * self.m / (np.sqrt(self.v) + eps)
+
+
 def prepare_synthetic_dataset(x, y):
     """train.prepare_synthetic_dataset (train.py:82-104): last 10 % of the (already shuffled)
     voxels for validation; batches of 512 'images' of 10x10x5 voxels = 256,000 voxels."""
@@ -161,6 +192,9 @@ def create_and_train_on_synthetic_data(config_dict, params, log=None, sample_siz
     g.manual_seed(1)
     n = tx.shape[0]
     steps = 0
+    # infer_inv_gamma (diagonal family): the four hyper-parameters are Keras variables of the pre-training model, so
+    # the same AdamW updates (and decays) them; four scalars, optimised on the host in float64
+    hyper = HyperPriorState(model) if trainer._infer_inv_gamma else None
     ig_a = float(_get(config_dict, "inv_gamma_alpha", 0.0) or 0.0)   # train.py:131-135
     ig_b = float(_get(config_dict, "inv_gamma_beta", 0.0) or 0.0)
     use_r2p = bool(_get(config_dict, "use_r2p_loss", False))       # train.py:125, 388
@@ -172,7 +206,10 @@ def create_and_train_on_synthetic_data(config_dict, params, log=None, sample_siz
             a, b = qd.shard_range(idx.numel(), rank, world)
             xb, yb = tx[idx[a:b]], ty[idx[a:b]]
             q1, _ = state.forward(xb, 1)
-            lv, gq = state.synth_loss_bwd(yb, q1, ig_a, ig_b)
+            lv, gq = state.synth_loss_bwd(yb, q1, 0.0 if hyper else ig_a, 0.0 if hyper else ig_b)
+            if hyper:   # model.py:493-507: the learned prior replaces the fixed one
+                stats = trainer.context.hyper_prior_bwd(q1, model.hyper_params(), scale=1.0 / q1.shape[0], g_q=gq, loss_v=lv)
+                qd.allreduce_sums(stats)
             if use_r2p:   # model.py:475-490; fresh draws every step, keyed by the step and the global voxel
                 trainer.context.r2p_loss_bwd(yb, q1, R2P_LOSS_SAMPLES, seed=steps + 1, voxel0=int(b0 + a),
                                              scale=1.0 / q1.shape[0], g_q=gq, loss_v=lv)
@@ -182,6 +219,8 @@ def create_and_train_on_synthetic_data(config_dict, params, log=None, sample_siz
             state.backward(1, gq)
             qd.allreduce_mean_(state.grad)
             state.adamw(lr, wd, 0.9, 0.999, 1e-7, ranges=pt_ranges)
+            if hyper:
+                hyper.step(stats.cpu().numpy(), idx.numel(), lr, wd)
             losses.append(lv.mean())
             steps += 1
             if max_steps and steps >= max_steps:

@@ -255,3 +255,23 @@ def test_two_rank_training_matches_single_process(tmp_path):
         a, b = runs["one"][k], runs["two"][k]
         assert np.isfinite(b).all()
         np.testing.assert_allclose(b, a, rtol=5e-3, atol=5e-4, err_msg=k)
+
+
+def test_infer_inv_gamma_pretraining(tmp_path, monkeypatch):
+    """A pre-training run with the learned inverse-gamma hyper-prior (diagonal family): the loss falls, the four
+    hyper-parameters move away from their initial (20, 2.5, 20, 2.5) and travel with the checkpoint."""
+    from qbold_vi_amd import training
+    monkeypatch.chdir(ROOT)
+    cfg = small_config(tmp_path, no_pt_epochs=25, no_ft_epochs=0, use_mvg=False, infer_inv_gamma=True)
+    params = training.get_params()
+    model, trainer, _ = training.create_and_train_on_synthetic_data(cfg, params, log=training.MetricsLog(echo=False),
+                                                                    sample_size=200)
+    hp = model.hyper_params()
+    assert np.isfinite(hp).all() and np.abs(np.log(hp) - np.log([20.0, 2.5, 20.0, 2.5])).max() > 1e-3
+    w = model.get_weights()
+    assert "hyper_prior" in w and w["hyper_prior"].shape == (4,)
+    model2, _, _ = training.create_encoder_model(cfg, params)
+    model2.set_weights(w)
+    np.testing.assert_allclose(model2.hyper_params(), hp, rtol=1e-6)
+    out1 = model.predict(torch.rand(16, 1, 1, 1, 11, device="cuda") + 0.3, want=("out1",))[0]
+    assert out1.shape[-1] == 8
