@@ -486,7 +486,7 @@ def main():
                  else "operands rounded to bf16, one MFMA pass, f32 accumulate")
         if two_launch:
             # dominant kernel: the one-launch encoder, on the f16 matrix pipe
-            kname, bound = "wide_fused_kernel<4, 2>", "mfma"
+            kname, bound = "wide_fused_kernel<4, 2, true>", "mfma"
             ach = enc_flops_v * n / (kernel_ms * 1e-3) / 1e12
             peak = BF16_MFMA_PEAK_TFLOPS / passes
             prof = measured_profile("r02_config3_pmc.json", "wide_fused_kernel")

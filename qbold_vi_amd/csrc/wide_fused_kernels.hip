@@ -140,10 +140,11 @@ __global__ void fused_scale_kernel(const float* __restrict__ W, int64_t n, const
 // i = lane & 31) and k-slot j, W[in][out = 32 m + i] with in = 16 s + 8 h + j (korder 0: the first layer, rows of
 // x) or in = 16 s + 8 (j >> 2) + 4 h + (j & 3) (korder 1: the accumulator order, see the header).  Head
 // (W2 != null): output row < split_row -> log-sigma row of W (Ws), else q row (row - split_row) of W2 (Wf).
-// Weights are stored times scale[0] as hi = f16(w'), lo = f16(w' - hi); biases unscaled.
+// Weights are stored times scale[0] as hi = f16(w'), lo = f16(w' - hi); biases unscaled, but for the gate ops:
+// theirs are stored as -log2(e) (b + gate_offset), the form the sigmoid's v_exp_f32 takes (epi_elem).
 __global__ void fused_pack_kernel(int frag0, int KS, int MT, int korder, const float* __restrict__ W,
                                   const float* __restrict__ b, int nin, int nout, const float* __restrict__ W2,
-                                  const float* __restrict__ b2, int nout2, int split_row, float bias_add,
+                                  const float* __restrict__ b2, int nout2, int split_row, float bias_add, float bias_mul,
                                   int bias_off, const float* __restrict__ scale, int64_t img_floats,
                                   float* __restrict__ packed) {
     _Float16* ph = reinterpret_cast<_Float16*>(packed) + (int64_t)frag0 * 512;
@@ -158,7 +159,7 @@ __global__ void fused_pack_kernel(int frag0, int KS, int MT, int korder, const f
                 if (row < split_row) v = row < nout ? b[row] : 0.0f;
                 else v = row - split_row < nout2 ? b2[row - split_row] : 0.0f;
             } else if (row < nout) {
-                v = b[row] + bias_add;
+                v = (b[row] + bias_add) * bias_mul;
             }
             packed[img_floats + bias_off + row] = v;
             continue;
@@ -253,14 +254,45 @@ __device__ __forceinline__ void stream_issue(Stream& S) {
 }
 // Mid-stage handshake: my quarter of the NEXT stage has landed (all but the youngest kAhead - 2 stages' loads
 // are done), everyone has left the previous stage, whose slot the new issue overwrites.
+// EXTRA: vector-memory instructions other than the stream's own that are certain to have been issued after the
+// awaited stage's loads (sync_extras below) -- vmcnt counts loads and stores alike and retires them in order,
+// so without the allowance a sync soon after the signal loads of the next pass (HBM latency) or the head's
+// stores would wait for those as well.
+template <int EXTRA>
 __device__ __forceinline__ void stream_sync(Stream& S) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kAhead - 2)) : "memory");
+    static_assert(4 * (kAhead - 2) + EXTRA < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kAhead - 2) + EXTRA) : "memory");
     __builtin_amdgcn_s_barrier();
     stream_issue(S);
 }
 __device__ __forceinline__ void stream_next_stage(Stream& S) {
     S.read_slot = (S.read_slot + 1) & (kRing - 1);
     S.cur = S.ring_lds + (uint32_t)S.read_slot * (kStageFrags * 1024);
+}
+
+// The sync in the middle of stage n needs stage n + 1, which the sync of stage n - 3 requested (kAhead = 4):
+// whatever else was issued since then may still be in flight.  Counted for the V4 kernels (four first-layer
+// k-steps, T % 4 == 0: two log-sigma tiles, one q tile; NS stages per pass, the head takes the last six), whose
+// head issues, in program order and fenced by the syncs' memory clobbers,
+//   11 signal loads | tile 0: sync NS-6, sync NS-5 | tile 1: store, sync NS-4, 2 stores, sync NS-3, store |
+//   tile 2: store, sync NS-2, 2 stores, sync NS-1, store | 4 q stores | next pass
+// (the 16-byte log-sigma stores of tile M leave in steps 3, 7, 11, 15 of tile M + 1, the syncs sit in front of
+// steps 4 and 12).  The next pass starts by waiting for its signals -- at the loop head the compiler makes that
+// a full drain -- so its first syncs have nothing of the head's behind them and take no allowance.
+// scripts/check_vmcnt_ring.py replays the kernel's ISA against this table (tests/test_host.py: every allowance
+// is tight, one more at any site is caught).
+__host__ __device__ constexpr inline int sync_extras(bool v4, int n, int NS) {
+    static_assert(kAhead == 4, "the table counts three syncs back");
+#if defined(QB_X_NO_LS_STORE) || defined(QB_X_GLOBAL_STORE)
+    return 0;  // timing / debugging variants issue other stores
+#endif
+    if (!v4) return 0;
+    if (n == NS - 6 || n == NS - 5) return 11;
+    if (n == NS - 4) return 12;
+    if (n == NS - 3) return 3;
+    if (n == NS - 2) return 5;
+    if (n == NS - 1) return 6;
+    return 0;
 }
 
 struct Frag {   // one (hi, lo) fragment pair of the weight stream
@@ -327,13 +359,14 @@ __host__ __device__ constexpr inline int bias_row(int E) { return 8 * (E >> 2) +
 // k-steps, one ds_read_b128 with four) -- PBOFF: bias offset of the previous tile, BOFF of this one, whose
 // first pieces are requested in the last step -- and travel in `bias`.  oa / ob: the two pairs that follow the
 // tile.  (Recursive template: every LDS offset is an instruction immediate.)
-template <int KSOP, int F0, int FP, int BOFF, int PBOFF, bool HAVE_PREV, int S_, class Prev>
+template <int KSOP, int F0, int FP, bool V4, int BOFF, int PBOFF, bool HAVE_PREV, int S_, class Prev>
 __device__ __forceinline__ void tile_steps(Stream& S, uint32_t bias_lds, Frag wa, Frag wb, Frag& oa, Frag& ob,
                                            const Panel<KSOP>& in, f32x16& acc, QB_BIAS_REFS, const Prev& prev) {
     constexpr int PPS = 16 / KSOP;  // epilogue pieces per k-step
     constexpr bool AHEAD = PPS <= 4;
     if constexpr (S_ < KSOP) {
-        if constexpr ((F0 + 2 * S_) % kStageFrags == kStageFrags / 2) stream_sync(S);
+        if constexpr ((F0 + 2 * S_) % kStageFrags == kStageFrags / 2)
+            stream_sync<sync_extras(V4, (F0 + 2 * S_) / kStageFrags, FP / kStageFrags)>(S);
         // NB a register an asm LDS read is still writing must reach its wait untouched: whole variables only
         // (a read into one component of a vector makes the compiler copy the pending register into the tuple)
         uint32_t nbias = bias;
@@ -392,9 +425,9 @@ __device__ __forceinline__ void tile_steps(Stream& S, uint32_t bias_lds, Frag wa
         bias = nbias;
         bias4 = nbias4;
         if constexpr (kPairsAhead == 2)
-            tile_steps<KSOP, F0, FP, BOFF, PBOFF, HAVE_PREV, S_ + 1>(S, bias_lds, wb, n, oa, ob, in, acc, QB_BIAS_ARGS, prev);
+            tile_steps<KSOP, F0, FP, V4, BOFF, PBOFF, HAVE_PREV, S_ + 1>(S, bias_lds, wb, n, oa, ob, in, acc, QB_BIAS_ARGS, prev);
         else
-            tile_steps<KSOP, F0, FP, BOFF, PBOFF, HAVE_PREV, S_ + 1>(S, bias_lds, n, n, oa, ob, in, acc, QB_BIAS_ARGS, prev);
+            tile_steps<KSOP, F0, FP, V4, BOFF, PBOFF, HAVE_PREV, S_ + 1>(S, bias_lds, n, n, oa, ob, in, acc, QB_BIAS_ARGS, prev);
     } else {
         oa = wa;
         ob = wb;
@@ -404,26 +437,27 @@ __device__ __forceinline__ void tile_steps(Stream& S, uint32_t bias_lds, Frag wa
 // One output tile into acc.  F0: fragment index within the pass of the tile's first fragment; BOFF / PBOFF:
 // float offsets of this / the previous tile's bias rows in the LDS bias image.  wa / wb: in, the tile's first
 // two pairs; out, the two pairs that follow it.
-template <int KSOP, int F0, int FP, int BOFF, int PBOFF, bool HAVE_PREV, class Prev>
+template <int KSOP, int F0, int FP, bool V4, int BOFF, int PBOFF, bool HAVE_PREV, class Prev>
 __device__ __forceinline__ void tile_mma(Stream& S, uint32_t bias_lds, Frag& wa, Frag& wb, const Panel<KSOP>& in,
                                          f32x16& acc, QB_BIAS_REFS, const Prev& prev) {
     static_assert((BOFF + 32) * 4 < 65536, "bias offset is a ds_read immediate");
     __builtin_amdgcn_sched_barrier(0);  // tiles are scheduled one at a time: three panels leave no slack
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    tile_steps<KSOP, F0, FP, BOFF, PBOFF, HAVE_PREV, 0>(S, bias_lds, wa, wb, wa, wb, in, acc, QB_BIAS_ARGS, prev);
+    tile_steps<KSOP, F0, FP, V4, BOFF, PBOFF, HAVE_PREV, 0>(S, bias_lds, wa, wb, wa, wb, in, acc, QB_BIAS_ARGS, prev);
 }
 
 // value E (register E of the accumulator = unit 32 M + 8 (E >> 2) + 4 h + (E & 3)) read back from a panel
 template <int M, int E, int KS>
 __device__ __forceinline__ float get_elem(const Panel<KS>& P) {
-    // laundered: otherwise the float32 values of the hi halves computed when the panel was written are kept
-    // alive from that op to this one -- a second, spilled copy of the panel
-    uint32_t dh = P.hi[2 * M + E / 8][(E % 8) / 2], dl = P.lo[2 * M + E / 8][(E % 8) / 2];
-    asm volatile("" : "+v"(dh), "+v"(dl));
-    const qb::f16x2 h = __builtin_bit_cast(qb::f16x2, dh);
-    const qb::f16x2 l = __builtin_bit_cast(qb::f16x2, dl);
-    return __builtin_fmaf((float)l[E % 2], 1.0f, (float)h[E % 2]);
+    // hi + lo in one v_fma_mix_f32 reading the f16 halves in place (the compiler's own version: two conversions
+    // and an add; it also kept the float32 values of the hi halves alive from the op that wrote the panel to this
+    // one -- a second, spilled copy of the panel -- which the opaque asm rules out)
+    const uint32_t dh = P.hi[2 * M + E / 8][(E % 8) / 2], dl = P.lo[2 * M + E / 8][(E % 8) / 2];
+    float r;
+    if constexpr (E % 2 == 0) asm volatile("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(dl), "v"(dh));
+    else asm volatile("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(dl), "v"(dh));
+    return r;
 }
 
 // relu on a split panel, in place (the Activation in front of the first 3x3x1 convolution, model.py:151):
@@ -451,10 +485,10 @@ __device__ __forceinline__ void epi_elem(const f32x16& acc, float inv_scale, flo
                                          const Panel<KS>& skip, const Panel<KS>& rr, float& carry, float& amax) {
     float y = fmaf(acc[E], inv_scale, bias);
     if constexpr (EPI == EPI_RELU) y = fmaxf(y, 0.0f);
-    if constexpr (EPI == EPI_GATE) {
+    if constexpr (EPI == EPI_GATE) {  // here inv_scale and bias carry the factor -log2(e): y = -log2(e) (W r + b)
         const float sk = get_elem<M, E>(skip), r = get_elem<M, E>(rr);
-        const float gate = qb::sigmoidf_(y);  // model.py:169
-        y = fmaf(gate, r - sk, sk);           // skip (1 - g) + r g, model.py:170
+        const float gate = qb::rcpf_(1.0f + qb::exp2f_(y));  // sigmoid, model.py:169
+        y = fmaf(gate, r - sk, sk);                           // skip (1 - g) + r g, model.py:170
     }
     if constexpr (E % 2 == 0) carry = y;
     else split_pair(carry, y, out.hi[2 * M + E / 8][(E % 8) / 2], out.lo[2 * M + E / 8][(E % 8) / 2], amax);
@@ -487,7 +521,7 @@ __device__ __forceinline__ void last_tile_bias(uint32_t bias_lds, float (&b)[16]
 
 // A dense op: tiles M .. MT-1 of out = epi(W in + b).  Tile M-1's epilogue runs inside tile M's MFMA stream
 // (two accumulators in rotation); the last tile's runs after the op.
-template <int KS, int KSIN, int MT, int F0, int FP, int BOFF, int EPI, int M = 0>
+template <int KS, int KSIN, int MT, int F0, int FP, bool V4, int BOFF, int EPI, int M = 0>
 __device__ __forceinline__ void dense_op(Stream& S, uint32_t bias_lds, float inv_scale, Frag& wa, Frag& wb,
                                          const Panel<KSIN>& in, Panel<KS>& out, const Panel<KS>& skip,
                                          const Panel<KS>& rr, f32x16 (&acc)[2], QB_BIAS_REFS) {
@@ -503,9 +537,9 @@ __device__ __forceinline__ void dense_op(Stream& S, uint32_t bias_lds, float inv
                 b = lds_read4_now<(BOFF + 32 * PM + bias_row(E)) * 4>(bias_lds);
             epi_elem<EPI, PM, E>(acc[(M + 1) & 1], inv_scale, b, out, skip, rr, carry, amax);
         };
-        tile_mma<KSIN, F0 + M * 2 * KSIN, FP, BOFF + 32 * M, BOFF + 32 * PM, (M > 0)>(S, bias_lds, wa, wb, in,
+        tile_mma<KSIN, F0 + M * 2 * KSIN, FP, V4, BOFF + 32 * M, BOFF + 32 * PM, (M > 0)>(S, bias_lds, wa, wb, in,
                                                                                        acc[M & 1], QB_BIAS_ARGS, prev);
-        dense_op<KS, KSIN, MT, F0, FP, BOFF, EPI, M + 1>(S, bias_lds, inv_scale, wa, wb, in, out, skip, rr, acc, QB_BIAS_ARGS);
+        dense_op<KS, KSIN, MT, F0, FP, V4, BOFF, EPI, M + 1>(S, bias_lds, inv_scale, wa, wb, in, out, skip, rr, acc, QB_BIAS_ARGS);
     } else {
         __builtin_amdgcn_sched_barrier(0);
         float carry = 0.0f;
@@ -550,7 +584,7 @@ struct XRaw {
     float f[KS1][8];
     float d[3];
 };
-template <int KS1>
+template <int KS1, bool V4>
 __device__ __forceinline__ void load_x(const FusedArgs& a, int64_t v, int h, XRaw<KS1>& xr) {
     // opaque: keeps the address arithmetic here, at the loads -- hoisted out of the pass loop its pieces sit in
     // registers through the whole pass, where three panels leave none to spare
@@ -564,10 +598,15 @@ __device__ __forceinline__ void load_x(const FusedArgs& a, int64_t v, int h, XRa
 #pragma unroll
     for (int s = 0; s < KS1; ++s) {
         const int t0 = 16 * s + 8 * h;
-        if ((a.T & 3) == 0 && a.T >= 8) {  // wave-uniform
+        if (V4 || ((a.T & 3) == 0 && a.T >= 8)) {  // wave-uniform; V4 (four k-steps, T % 4 == 0): known here
             const int tc = t0 + 8 <= a.T ? t0 : a.T - 8;  // clamped: values past the row are masked in convert_x
+#ifdef QB_FUSED_X_NT
+            const float4 lo4 = __builtin_nontemporal_load(reinterpret_cast<const float4*>(xv + tc));
+            const float4 hi4 = __builtin_nontemporal_load(reinterpret_cast<const float4*>(xv + tc + 4));
+#else
             const float4 lo4 = *reinterpret_cast<const float4*>(xv + tc);
             const float4 hi4 = *reinterpret_cast<const float4*>(xv + tc + 4);
+#endif
             xr.f[s][0] = lo4.x; xr.f[s][1] = lo4.y; xr.f[s][2] = lo4.z; xr.f[s][3] = lo4.w;
             xr.f[s][4] = hi4.x; xr.f[s][5] = hi4.y; xr.f[s][6] = hi4.z; xr.f[s][7] = hi4.w;
         } else {
@@ -612,8 +651,17 @@ struct HeadOut {
 #define QB_OOB 0x7ffffff0u  // beyond any resource: a dropped store
 // Piece E of head tile M: tiles 0 .. LT-1 are log-sigma rows 32 M + 8 (E >> 2) + 4 h + (E & 3), tile LT holds the
 // five q rows.
-template <int LT, int M, int E>
-__device__ __forceinline__ void head_elem(const f32x16& acc, float inv_scale, float bias, const HeadOut& o, int h) {
+#ifndef QB_FUSED_LS_AUX
+#define QB_FUSED_LS_AUX 0  // cache policy of the log-sigma stores.  nt (2) was worth 8 % while the ring's syncs still
+                           // waited for these stores (sync_extras); since then it gains nothing here and costs the
+                           // ELBO kernel, which reads log sigma next, its hits in the memory-side cache
+#endif
+// V4: T is a multiple of four, so the four registers E & ~3 .. | 3 of a lane (taus 8 (E >> 2) + 4 h + 0..3 of its
+// voxel) are one aligned 16-byte piece of the voxel's row: one store instead of four, whole 32-byte sectors per
+// lane pair.  hc parks the first three values of a group.
+template <int LT, int M, int E, bool V4>
+__device__ __forceinline__ void head_elem(const f32x16& acc, float inv_scale, float bias, const HeadOut& o, int h,
+                                          float (&hc)[3]) {
     const float y = o.overflow ? __builtin_nanf("") : fmaf(acc[E], inv_scale, bias);
     const int row_in_tile = 8 * (E >> 2) + 4 * h + (E & 3);
 #ifdef QB_X_GLOBAL_STORE
@@ -625,35 +673,51 @@ __device__ __forceinline__ void head_elem(const f32x16& acc, float inv_scale, fl
     return;
 #endif
     if constexpr (M < LT) {
-        const int row = 32 * M + row_in_tile;
-        const uint32_t off = row < o.T ? o.ls_off + 4u * row : QB_OOB;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), o.ls, off, 0, 0);
+#ifdef QB_X_NO_LS_STORE
+        return;
+#endif
+        if constexpr (V4) {
+            if constexpr ((E & 3) != 3) hc[E & 3] = y;
+            else {
+                const int row = 32 * M + row_in_tile - 3;
+                const uint32_t off = row < o.T ? o.ls_off + 4u * row : QB_OOB;
+                const u32x4 d = {__builtin_bit_cast(uint32_t, hc[0]), __builtin_bit_cast(uint32_t, hc[1]),
+                                 __builtin_bit_cast(uint32_t, hc[2]), __builtin_bit_cast(uint32_t, y)};
+                __builtin_amdgcn_raw_buffer_store_b128(d, o.ls, off, 0, QB_FUSED_LS_AUX);
+            }
+        } else {
+            const int row = 32 * M + row_in_tile;
+            const uint32_t off = row < o.T ? o.ls_off + 4u * row : QB_OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), o.ls, off, 0, QB_FUSED_LS_AUX);
+        }
     } else if constexpr (E < 4) {  // rows 0-3 (h = 0) and 4 (h = 1, E = 0); registers 4 .. 15 hold padding rows
         const uint32_t off = row_in_tile < 5 ? o.q_off + 4u * row_in_tile : QB_OOB;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), o.q, off, 0, 0);
     }
 }
-template <int KS, int LT, int F0, int FP, int BOFF, int M = 0>
+template <int KS, int LT, int F0, int FP, int BOFF, bool V4, int M = 0>
 __device__ __forceinline__ void head_op(Stream& S, uint32_t bias_lds, float inv_scale, Frag& wa, Frag& wb,
                                         const Panel<KS>& b, const HeadOut& o, int h, f32x16 (&acc)[2], QB_BIAS_REFS) {
     if constexpr (M <= LT) {
         constexpr int PM = M > 0 ? M - 1 : 0;
+        float hc[3] = {0.0f, 0.0f, 0.0f};
         auto prev = [&](auto c, float bb) {
 #ifdef QB_X_SYNC_BIAS
             bb = lds_read4_now<(BOFF + 32 * PM + bias_row(decltype(c)::value)) * 4>(bias_lds);
 #endif
-            head_elem<LT, PM, decltype(c)::value>(acc[(M + 1) & 1], inv_scale, bb, o, h);
+            head_elem<LT, PM, decltype(c)::value, V4>(acc[(M + 1) & 1], inv_scale, bb, o, h, hc);
         };
-        tile_mma<KS, F0 + M * 2 * KS, FP, BOFF + 32 * M, BOFF + 32 * PM, (M > 0)>(S, bias_lds, wa, wb, b, acc[M & 1],
+        tile_mma<KS, F0 + M * 2 * KS, FP, V4, BOFF + 32 * M, BOFF + 32 * PM, (M > 0)>(S, bias_lds, wa, wb, b, acc[M & 1],
                                                                                    QB_BIAS_ARGS, prev);
-        head_op<KS, LT, F0, FP, BOFF, M + 1>(S, bias_lds, inv_scale, wa, wb, b, o, h, acc, QB_BIAS_ARGS);
+        head_op<KS, LT, F0, FP, BOFF, V4, M + 1>(S, bias_lds, inv_scale, wa, wb, b, o, h, acc, QB_BIAS_ARGS);
     } else {
         __builtin_amdgcn_sched_barrier(0);
         float bl[16];
+        float hc[3] = {0.0f, 0.0f, 0.0f};
         last_tile_bias<BOFF + 32 * LT>(bias_lds, bl);
         auto last = [&](auto c) {
             constexpr int E = decltype(c)::value;
-            head_elem<LT, LT, E>(acc[LT & 1], inv_scale, bl[E], o, h);
+            head_elem<LT, LT, E, V4>(acc[LT & 1], inv_scale, bl[E], o, h, hc);
         };
         last(IC<0>{}); last(IC<1>{}); last(IC<2>{}); last(IC<3>{}); last(IC<4>{}); last(IC<5>{}); last(IC<6>{});
         last(IC<7>{}); last(IC<8>{}); last(IC<9>{}); last(IC<10>{}); last(IC<11>{}); last(IC<12>{}); last(IC<13>{});
@@ -663,7 +727,7 @@ __device__ __forceinline__ void head_op(Stream& S, uint32_t bias_lds, float inv_
 
 // Gated residual blocks LB .. L-1 (model.py:147-172): b comes in P0 and leaves in P1; the panels rotate by
 // name from block to block, nothing is copied.  SC0: float index of the first block op's 2^-e in the aux image.
-template <int KS, int KS1, int MT, int L, int LT, int FB0, int FP, int SC0, int LB>
+template <int KS, int KS1, int MT, int L, int LT, int FB0, int FP, int SC0, bool V4, int LB>
 __device__ __forceinline__ void blocks_and_head(Stream& S, uint32_t bias_lds, uint32_t aux_lds, Frag& wa, Frag& wb,
                                                 Panel<KS>& P0, Panel<KS>& P1, Panel<KS>& P2, const FusedArgs& a,
                                                 int64_t v, int64_t v_next, int h, f32x16 (&acc)[2], QB_BIAS_REFS,
@@ -672,23 +736,23 @@ __device__ __forceinline__ void blocks_and_head(Stream& S, uint32_t bias_lds, ui
     constexpr int U = 32 * MT;
     if constexpr (LB < L) {
         constexpr int F = FB0 + LB * 4 * FOP, B = U + LB * 4 * U, SC = SC0 + 8 * LB;
-        dense_op<KS, KS, MT, F, FP, B, EPI_RELU>(S, bias_lds, op_inv_scale<SC>(aux_lds), wa, wb, P0, P2, P2, P2, acc,
+        dense_op<KS, KS, MT, F, FP, V4, B, EPI_RELU>(S, bias_lds, op_inv_scale<SC>(aux_lds), wa, wb, P0, P2, P2, P2, acc,
                                                  QB_BIAS_ARGS);                                            // skip, :148
         QB_STAMP(a, 0);
         if constexpr (LB > 0) relu_panel(P0);  // block 0's input is a relu output already            :151
-        dense_op<KS, KS, MT, F + FOP, FP, B + U, EPI_RELU>(S, bias_lds, op_inv_scale<SC + 2>(aux_lds), wa, wb, P0, P1,
+        dense_op<KS, KS, MT, F + FOP, FP, V4, B + U, EPI_RELU>(S, bias_lds, op_inv_scale<SC + 2>(aux_lds), wa, wb, P0, P1,
                                                            P1, P1, acc, QB_BIAS_ARGS);                      // t, :152-155
         QB_STAMP(a, 1);
-        dense_op<KS, KS, MT, F + 2 * FOP, FP, B + 2 * U, EPI_LINEAR>(S, bias_lds, op_inv_scale<SC + 4>(aux_lds), wa, wb,
+        dense_op<KS, KS, MT, F + 2 * FOP, FP, V4, B + 2 * U, EPI_LINEAR>(S, bias_lds, op_inv_scale<SC + 4>(aux_lds), wa, wb,
                                                                      P1, P0, P0, P0, acc, QB_BIAS_ARGS);    // r, :156
         QB_STAMP(a, 2);
-        dense_op<KS, KS, MT, F + 3 * FOP, FP, B + 3 * U, EPI_GATE>(S, bias_lds, op_inv_scale<SC + 6>(aux_lds), wa, wb,
+        dense_op<KS, KS, MT, F + 3 * FOP, FP, V4, B + 3 * U, EPI_GATE>(S, bias_lds, -QB_LOG2E * op_inv_scale<SC + 6>(aux_lds), wa, wb,
                                                                    P0, P1, P2, P0, acc, QB_BIAS_ARGS);      // :164-170
         QB_STAMP(a, 3);
-        blocks_and_head<KS, KS1, MT, L, LT, FB0, FP, SC0, LB + 1>(S, bias_lds, aux_lds, wa, wb, P1, P0, P2, a, v, v_next,
+        blocks_and_head<KS, KS1, MT, L, LT, FB0, FP, SC0, V4, LB + 1>(S, bias_lds, aux_lds, wa, wb, P1, P0, P2, a, v, v_next,
                                                                   h, acc, QB_BIAS_ARGS, xr);
     } else {
-        load_x<KS1>(a, v_next, h, xr);  // the next pass's signals (clamped beyond the batch: then unused)
+        load_x<KS1, V4>(a, v_next, h, xr);  // the next pass's signals (clamped beyond the batch: then unused)
         HeadOut o;
         {
             const int64_t v0 = __builtin_amdgcn_readfirstlane((int)(v >> 7)) * (int64_t)kVoxPerPass;  // pass's first voxel
@@ -706,14 +770,14 @@ __device__ __forceinline__ void blocks_and_head(Stream& S, uint32_t bias_lds, ui
             o.pls = a.ls; o.pq = a.q; o.vv = v; o.N = a.N;
 #endif
         }
-        head_op<KS, LT, FB0 + L * 4 * FOP, FP, U + L * 4 * U>(S, bias_lds, op_inv_scale<SC0 + 8 * L>(aux_lds), wa, wb,
+        head_op<KS, LT, FB0 + L * 4 * FOP, FP, U + L * 4 * U, V4>(S, bias_lds, op_inv_scale<SC0 + 8 * L>(aux_lds), wa, wb,
                                                               P0, o, h, acc, QB_BIAS_ARGS);
         QB_STAMP(a, 4);
     }
 }
 
-// TT: first-layer k-steps (ceil(T / 16): 1 or 4)
-template <int TT, int L>
+// TT: first-layer k-steps (ceil(T / 16): 1 or 4); V4: T % 4 == 0, log sigma leaves in 16-byte stores
+template <int TT, int L, bool V4>
 __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
 #ifdef QB_FUSED_STAMP
     int stamp_counter = 0;
@@ -769,7 +833,7 @@ __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
     // for every LDS-direct load in flight as well -- ten times per pass).
     const int64_t nblk = (a.N + kVoxPerPass - 1) / kVoxPerPass;
     XRaw<KS1> xr;
-    load_x<KS1>(a, (int64_t)blockIdx.x * kVoxPerPass + wave * 32 + i, h, xr);
+    load_x<KS1, V4>(a, (int64_t)blockIdx.x * kVoxPerPass + wave * 32 + i, h, xr);
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int64_t v = blk * kVoxPerPass + wave * 32 + i;
         Panel<KS1> X;
@@ -779,11 +843,11 @@ __global__ __launch_bounds__(kFB) void wide_fused_kernel(FusedArgs a) {
         QB_STAMP(a, 6);
         Panel<KS> P0, P1, P2;
         f32x16 acc[2];
-        dense_op<KS, KS1, MT, 0, FP, 0, EPI_RELU>(S, bias_lds, op_inv_scale<SC0>(aux_lds), wa, wb, X, P0, P0, P0, acc,
+        dense_op<KS, KS1, MT, 0, FP, V4, 0, EPI_RELU>(S, bias_lds, op_inv_scale<SC0>(aux_lds), wa, wb, X, P0, P0, P0, acc,
                                                   QB_BIAS_ARGS);  // first layer, model.py:181
         bias4 = u32x4{0u, 0u, 0u, 0u};  // dead until the next pass's first layer
         QB_STAMP(a, 7);
-        blocks_and_head<KS, KS1, MT, L, LT, MT * KS1 * 2, FP, SC0 + 2, 0>(S, bias_lds, aux_lds, wa, wb, P0, P1, P2, a, v,
+        blocks_and_head<KS, KS1, MT, L, LT, MT * KS1 * 2, FP, SC0 + 2, V4, 0>(S, bias_lds, aux_lds, wa, wb, P0, P1, P2, a, v,
                                                                           v + (int64_t)gridDim.x * kVoxPerPass, h, acc,
                                                                           QB_BIAS_ARGS, xr);
     }
@@ -816,20 +880,23 @@ int wide_fused_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const
     const size_t smem = sizeof(uint4) * kRing * kStageFrags * 64 + sizeof(float) * fl.aux_floats;
     const int64_t nblk = (N + kVoxPerPass - 1) / kVoxPerPass;
     const int grid = (int)(nblk < ctx->num_cus ? nblk : ctx->num_cus);
-#define QB_LAUNCH_FUSED(TT, LL)                                                                              \
+#define QB_LAUNCH_FUSED(TT, LL, V4)                                                                          \
     do {                                                                                                     \
-        auto k = wide_fused_kernel<TT, LL>;                                                                  \
+        auto k = wide_fused_kernel<TT, LL, V4>;                                                              \
         QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                    (int)smem));                                                              \
         hipLaunchKernelGGL(k, dim3(grid), dim3(kFB), smem, s, a);                                            \
     } while (0)
+    const bool v4 = shape->T % 4 == 0 && reinterpret_cast<uintptr_t>(out_log_sigma) % 16 == 0;
 #ifndef QB_FUSED_DEV
-    if (fl.KS1 == 1 && shape->L == 1) QB_LAUNCH_FUSED(1, 1);
-    else if (fl.KS1 == 1 && shape->L == 2) QB_LAUNCH_FUSED(1, 2);
-    else if (fl.KS1 == 4 && shape->L == 1) QB_LAUNCH_FUSED(4, 1);
+    if (fl.KS1 == 1 && shape->L == 1) QB_LAUNCH_FUSED(1, 1, false);  // one log-sigma tile: nothing to gain
+    else if (fl.KS1 == 1 && shape->L == 2) QB_LAUNCH_FUSED(1, 2, false);
+    else if (fl.KS1 == 4 && shape->L == 1 && v4) QB_LAUNCH_FUSED(4, 1, true);
+    else if (fl.KS1 == 4 && shape->L == 1) QB_LAUNCH_FUSED(4, 1, false);
+    else if (fl.KS1 == 4 && shape->L == 2 && !v4) QB_LAUNCH_FUSED(4, 2, false);
     else
 #endif
-    if (fl.KS1 == 4 && shape->L == 2) QB_LAUNCH_FUSED(4, 2);
+    if (fl.KS1 == 4 && shape->L == 2 && v4) QB_LAUNCH_FUSED(4, 2, true);
     else {
         qb::set_error("wide_fused_fwd: shape not instantiated");
         return QBOLD_ERR_UNSUPPORTED;
@@ -862,13 +929,13 @@ extern "C" int qbold_encoder_fused_pack(const qbold_ctx* ctx, const qbold_encode
     hipStream_t s = (hipStream_t)stream;
     int frag = 0, op = 0;
     auto pack = [&](int KS, int MT, int korder, const float* W, const float* b, int nin, int nout, const float* W2,
-                    const float* b2, int nout2, int split_row, float add, int bias_off) {
+                    const float* b2, int nout2, int split_row, float add, int bias_off, float bias_mul = 1.0f) {
         float* scale = packed + fl.img_floats + fl.scale_off + 2 * op;
         hipLaunchKernelGGL(fused_scale_kernel, dim3(1), dim3(256), 0, s, W, (int64_t)nin * nout, W2,
                            W2 ? (int64_t)nin * nout2 : 0, scale);
         const int64_t n = (int64_t)MT * KS * 2 * 512 + 32 * MT;
         hipLaunchKernelGGL(fused_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, frag, KS, MT, korder,
-                           W, b, nin, nout, W2, b2, nout2, split_row, add, bias_off, scale, fl.img_floats, packed);
+                           W, b, nin, nout, W2, b2, nout2, split_row, add, bias_mul, bias_off, scale, fl.img_floats, packed);
         frag += MT * KS * 2;
         ++op;
     };
@@ -880,7 +947,8 @@ extern "C" int qbold_encoder_fused_pack(const qbold_ctx* ctx, const qbold_encode
         pack(fl.KS, fl.MT, 1, wb + c.Wc, wb + c.bc, U, U, nullptr, nullptr, 0, 0, 0.0f, b0);
         pack(fl.KS, fl.MT, 1, wb + c.Wr1 + ctr, wb + c.br1, U, U, nullptr, nullptr, 0, 0, 0.0f, b0 + U);
         pack(fl.KS, fl.MT, 1, wb + c.Wr2 + ctr, wb + c.br2, U, U, nullptr, nullptr, 0, 0, 0.0f, b0 + 2 * U);
-        pack(fl.KS, fl.MT, 1, wb + c.Wg, wb + c.bg, U, U, nullptr, nullptr, 0, 0, shape->gate_offset, b0 + 3 * U);
+        pack(fl.KS, fl.MT, 1, wb + c.Wg, wb + c.bg, U, U, nullptr, nullptr, 0, 0, shape->gate_offset, b0 + 3 * U,
+             -QB_LOG2E);
     }
     pack(fl.KS, fl.HT, 1, weights + c.Ws, weights + c.bs, U, T, weights + c.Wf, weights + c.bf, 5, 32 * fl.LT, 0.0f,
          fl.bias_head);

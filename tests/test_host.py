@@ -366,3 +366,20 @@ def test_hand_placed_lds_reads_are_not_touched_before_their_wait(tmp_path):
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:]
         assert "LDS reads checked, 0 hazards" in r.stdout and " 0 LDS reads" not in r.stdout, r.stdout
+        # the weight ring's handshakes wait with per-site vmcnt allowances (signal loads and head stores known to
+        # be younger than the awaited stage, wide_fused_kernels.hip sync_extras): replayed against the ISA; an
+        # allowance one too large at any site must be caught
+        chk = os.path.join(ROOT, "scripts", "check_vmcnt_ring.py")
+        r = subprocess.run([sys.executable, chk, str(out), key], capture_output=True, text=True)
+        assert r.returncode == 0 and " 0 violations" in r.stdout, r.stdout[-2000:]
+        assert int(r.stdout.split(" handshakes replayed")[0].split()[-1]) > 400
+        text = out.read_text()
+        import re
+        sites = sorted({int(n) for n in re.findall(r"s_waitcnt vmcnt\((\d+)\)\n\s*;;#ASMEND\n\s*s_barrier", text)})
+        assert len(sites) > 3, sites          # several different allowances are in use
+        for n in sites:
+            bad = tmp_path / "bad.s"
+            bad.write_text(re.sub(r"s_waitcnt vmcnt\(%d\)(\n\s*;;#ASMEND\n\s*s_barrier)" % n,
+                                  "s_waitcnt vmcnt(%d)\\1" % (n + 1), text))
+            r = subprocess.run([sys.executable, chk, str(bad), key], capture_output=True, text=True)
+            assert r.returncode == 1 and "still has" in r.stdout, (n, r.stdout[-500:])
