@@ -1,22 +1,32 @@
-// vi_kernels.hip -- the whole voxel-ELBO hot path in one launch (qbold_vi_fwd).
+// vi_kernels.hip -- the whole voxel-ELBO hot path behind one entry point (qbold_vi_fwd).
 //
-// Per 32-voxel wave tile: load x -> normalise -> encoder stream 2 on the f32 matrix cores
-// (encoder_core.h) -> posterior parameters + sigma stay in registers -> S reparameterised draws
-// through the forward model + K-draw Monte-Carlo KL on the VALU (elbo_core.h) -> per-voxel
-// (nll, kl), posterior parameters and the three masked sums.  This is the reference's
-// full_model([data, mask]) + fine_tune_loss_fn + kl_loss (model.py:239-286, 527-568, 654-665)
+// Narrow encoders (U <= 64, T = 11 or 24: BASELINE configs 1, 2, 4, 5) -- one launch, vi_fwd_kernel.  Per
+// 16-voxel wave tile: load x -> normalise -> encoder stream 2 on the f16 matrix cores (encoder_core.h: operands
+// split into two f16 halves, three v_mfma_f32_16x16x32_f16 passes hi.hi + hi.lo + lo.hi with f32 accumulation,
+// float32-grade products; QBOLD_ENC_BF16: operands rounded to bf16, one pass) -> posterior parameters and log
+// sigma stay in registers -> S reparameterised draws through the forward model + K-draw Monte-Carlo KL on the
+// vector pipe (elbo_core.h) -> per-voxel (nll, kl), posterior parameters and the three masked sums.  This is the
+// reference's full_model([data, mask]) + fine_tune_loss_fn + kl_loss (model.py:239-286, 527-568, 654-665)
 // evaluated for (N,1,1,1,T) voxel batches, with ELBO = nll + kl as train.py:351.
 //
-// HBM traffic per voxel (T=11): read x 44 + mask 4 + prior 20, write q 20 + (nll,kl) 8 = 96 B;
-// weights (145 KB), the F(x) table (4 KB) and constants are LDS/SGPR resident.  Work per voxel:
-// 60.8 kFLOP of MFMA + ~25 kFLOP-equivalent of VALU/transcendental at S=32, K=70: compute-bound
-// (arithmetic intensity ~900 flop/B against a machine balance of ~20 flop/B).
+// HBM traffic per voxel (T = 11): read x 44 + mask 4 + prior 20, write q 20 + (nll, kl) 8 = 96 B; the weight
+// image (~145 KB of split-f16 fragments), the F(x) table (4 KB) and constants are LDS / SGPR resident.  Work per
+// voxel at S = 32, K = 70: 60.8 kFLOP of encoder products (x 3 passes on the matrix pipe) and ~30 kFLOP of
+// sampling: compute-bound by the vector pipe's issue rate, ~900 flop/B against a machine balance
+// of ~20 flop/B.
 //
-// One 1024-thread workgroup per CU (the weight image takes ~145 KB of the 160 KB LDS).  With
-// 16-voxel tiles on v_mfma_f32_16x16x4_f32 the kernel fits 128 VGPRs, so four waves share each
-// SIMD: while some are in their VALU sampling phase others own the SIMD's matrix pipe, and the
-// LDS-table / transcendental latencies of the sampling phase are covered by thread-level
-// parallelism.
+// One 1024-thread workgroup per CU (the weight image takes ~145 KB of the 160 KB LDS), 128 VGPRs, so four waves
+// share each SIMD: while some are in their sampling phase others own the SIMD's matrix pipe, and the LDS-table /
+// transcendental latencies of the sampling phase are covered by thread-level parallelism.
+//
+// An activation or weight outside the f16 operand range (|v| > 65504) cannot be split: the pack kernel records
+// it in the image's flag slot, the encoder tracks the largest activation it split, and the voxel's terms come
+// out NaN -- never a silent clamp (include/qbold_hip.h, operand range; ops.vi_fwd(range_check=True) falls back to
+// the exact-f32 layer-wise path).
+//
+// Wide encoders (U = 256, T <= 16 or 49..64: BASELINE config 3) -- two launches: the one-launch encoder of
+// wide_fused_kernels.hip writes q and log sigma into the caller's workspace (qbold_vi_workspace_bytes), the
+// compile-time-T ELBO kernel of elbo_kernels.hip reads them back.
 #include "elbo_core.h"
 // Wave priorities (s_setprio): a wave starts a tile (signal loads, normalisation) at 3, runs its encoder
 // phase at 2 (3 inside the MFMA chains), its likelihood draws at 1, its KL draws at 3 and the tile's tail

@@ -1,35 +1,89 @@
 #!/usr/bin/env python3
-"""Copy the summaries of one profiling call (scripts/profile_bench.sh + scripts/pmc_mix.sh + bench.py runs,
-all under gpurun_out/) into profiles/ -- the tracked copies the numbers in DESIGN.md come from."""
+"""Copy the summaries of the round's profiling calls (scripts/profile_round2.sh a / b, all under
+gpurun_out/profiles_r02/) into profiles/ -- the tracked copies the numbers in DESIGN.md and README.md come
+from -- and derive the per-kernel counter files bench.py quotes (roofline.traffic / roofline.counters).  Every
+derived file carries the fingerprint of the kernel sources it was measured on (qbold_vi_amd.build.
+source_fingerprint, recorded on the GPU box by the profiling script); bench.py drops a file whose fingerprint
+is not the current build's."""
 import json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join(G, f"profiles_{tag}")
+NOTE = ("traffic = 2*FETCH_SIZE + WRITE_SIZE KiB (gfx950 correction of MI355X_MICROARCH.md, HBM section; the x2 is "
+        "calibrated there for 16 B/lane streams, so for dword-row reads the read side is an upper bound); FETCH_SIZE "
+        "and WRITE_SIZE from separate rocprofv3 --pmc passes of bench.py, per-dispatch means over the timed launches")
+
+
 def last_json_line(path):
     with open(path) as f:
         rows = [l for l in f if l.startswith("{") and '"metric"' in l]
-    return json.loads(rows[-1])
-src = os.path.join(G, f"profiles_{tag}")
-for name in (f"{tag}_kernel_stats.csv", f"{tag}_vi_fwd_summary.json", f"{tag}_bench_under_rocprof.json"):
-    shutil.copy(os.path.join(src, name), os.path.join(P, name))
-summ = json.load(open(os.path.join(src, f"{tag}_vi_fwd_summary.json")))
-fetch_kb = summ["pmc"]["FETCH_SIZE"]["mean"]; write_kb = summ["pmc"]["WRITE_SIZE"]["mean"]
+    return json.loads(rows[-1]) if rows else None
+
+
+def sha(part):
+    p = os.path.join(src, f"source_sha256_{part}.txt")
+    return open(p).read().strip() if os.path.exists(p) else None
+
+
+def pmc_file(summary_name, kernel, n, algorithmic, fingerprint, extra=None):
+    s = json.load(open(os.path.join(src, summary_name)))
+    c = {k: v["mean"] for k, v in s["pmc"].items()}
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        return None
+    d = {"kernel": kernel, "voxels": n, "source_sha256": fingerprint,
+         "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
+         "hbm_read_bytes_x2_gfx950": 2 * c["FETCH_SIZE"] * 1024, "hbm_write_bytes": c["WRITE_SIZE"] * 1024,
+         "hbm_bytes_per_launch": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024,
+         "algorithmic_bytes_per_launch": algorithmic,
+         "counters": {k: v for k, v in c.items() if k not in ("FETCH_SIZE", "WRITE_SIZE")},
+         "dispatch": s.get("dispatch"), "kernel_stats": s.get("kernel_stats"), "note": NOTE}
+    if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c and "SQ_WAVE_CYCLES" in c:
+        pass
+    d.update(extra or {})
+    return d
+
+
+def put(name, obj):
+    if obj is not None:
+        json.dump(obj, open(os.path.join(P, name), "w"), indent=1)
+
+
 n = 1 << 20
-pmc = {"kernel": "vi_fwd_kernel<11,2,2,true,false,false>", "voxels": n,
-       "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
-       "hbm_read_bytes_raw": fetch_kb * 1024, "hbm_read_bytes_x2_gfx950": 2 * fetch_kb * 1024,
-       "hbm_write_bytes": write_kb * 1024, "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024,
-       "algorithmic_bytes_per_launch": 96 * n,
-       "note": "traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction of MI355X_MICROARCH.md, HBM section; the x2 is "
-               "calibrated there for 16 B/lane streams, this kernel reads 44-byte rows with dword loads, so the read "
-               "side is an upper bound); separate --pmc passes"}
-json.dump(pmc, open(os.path.join(P, f"{tag}_vi_fwd_pmc.json"), "w"), indent=1)
-shutil.copy(os.path.join(G, "mix.json"), os.path.join(P, f"{tag}_vi_fwd_instruction_mix.json"))
-for src_name, dst in (("bench_final.json", f"{tag}_bench.json"), ("bench_bf16.json", f"{tag}_bench_bf16.json"),
-                      ("bench_4m.json", f"{tag}_bench_4m.json")):
-    p = os.path.join(G, src_name)
-    if os.path.exists(p):
-        json.dump(last_json_line(p), open(os.path.join(P, dst), "w"))
-if os.path.exists(os.path.join(G, "api.json")):
-    shutil.copy(os.path.join(G, "api.json"), os.path.join(P, f"{tag}_api_kernels.json"))
-print("profiles/ updated:", sorted(os.listdir(P)))
+copied = []
+for name in sorted(os.listdir(src)):
+    if name.startswith("source_sha256"):
+        continue
+    dst = os.path.join(P, name)
+    if name.startswith(f"{tag}_bench") and name.endswith(".json"):
+        line = last_json_line(os.path.join(src, name))
+        if line:
+            json.dump(line, open(dst, "w"))
+            copied.append(name)
+    else:
+        shutil.copy(os.path.join(src, name), dst)
+        copied.append(name)
+fa, fb = sha("a"), sha("b")
+if fa and os.path.exists(os.path.join(src, f"{tag}_vi_fwd_summary.json")):
+    put(f"{tag}_vi_fwd_pmc.json", pmc_file(f"{tag}_vi_fwd_summary.json", "vi_fwd_kernel<11,2,2,true,false,false>", n, 96 * n, fa))
+if fb:
+    if os.path.exists(os.path.join(src, f"{tag}_config3_wide_fused_summary.json")):
+        T = 64
+        enc = pmc_file(f"{tag}_config3_wide_fused_summary.json", "wide_fused_kernel<4, 2, true>", n, (4 * T + 4 * T + 20) * n, fb)
+        elbo = pmc_file(f"{tag}_config3_elbo_summary.json", "elbo_fwd_lds_kernel<64, 12, true>", n,
+                        (4 * T + 4 * T + 20 + 4 + 20 + 8) * n, fb)
+        if enc and elbo:
+            enc["step"] = {"launches": ["wide_fused_kernel", "elbo_fwd_lds_kernel"],
+                           "hbm_bytes": enc["hbm_bytes_per_launch"] + elbo["hbm_bytes_per_launch"],
+                           "algorithmic_bytes": (4 * T + 4 + 20 + 20 + 8) * n,
+                           "elbo_kernel": {k: elbo[k] for k in ("kernel", "FETCH_SIZE_KB", "WRITE_SIZE_KB", "hbm_bytes_per_launch",
+                                                                "algorithmic_bytes_per_launch", "counters", "dispatch")},
+                           "note": "the step's algorithmic bytes (SURVEY 8d) count signals, mask, prior in and q, (nll, kl) "
+                                   "out; the two-launch path also writes and re-reads log sigma (2 x 4T B) and q, and reads "
+                                   "the signals twice: its own floor is the sum of the two kernels' algorithmic bytes"}
+        put(f"{tag}_config3_pmc.json", enc)
+    for t, kernel, alg in (("p24", "vi_fwd_kernel<24,2,7,true,false,false>", (4 * 24 + 52) * n),
+                           ("bf16", "vi_fwd_kernel<11,2,2,true,false,true>", 96 * n)):
+        if os.path.exists(os.path.join(src, f"{tag}_{t}_vi_fwd_summary.json")):
+            put(f"{tag}_{t}_vi_fwd_pmc.json", pmc_file(f"{tag}_{t}_vi_fwd_summary.json", kernel, n, alg, fb))
+print("profiles/ updated:", copied)

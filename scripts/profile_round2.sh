@@ -1,0 +1,65 @@
+#!/bin/bash
+# Round-2 profiles (run on the GPU box via gpurun, in two calls: part a, then part b).  Each rocprofv3 pass is a
+# run of bench.py itself; counters never share a run with trace domains (pool rule).  Summaries land in
+# gpurun_out/profiles_r02/; scripts/collect_profiles.py r02 copies them into profiles/ with the fingerprint
+# of the kernel sources they were measured on.
+#   scripts/profile_round2.sh a   -- config 2 (headline): kernel trace, SQ / LDS / FETCH / WRITE counters,
+#                                    instruction mix; plain bench lines (default, 4 M voxels, bf16)
+#   scripts/profile_round2.sh b   -- config 3: kernel trace + counters of both kernels; --protocol 24 and
+#                                    --encoder_precision bf16 FETCH / WRITE counters; plain bench lines
+PART=${1:-a}
+export TMPDIR=/tmp
+R=$PWD
+G=$R/gpurun_out
+P=$G/profiles_r02
+mkdir -p $P
+prof() {   # prof <out dir> <rocprof args...> -- <bench args...>
+    local out=$1; shift
+    local rargs=(); while [ "$1" != "--" ]; do rargs+=("$1"); shift; done; shift
+    rm -rf $out; mkdir -p $out
+    (cd /tmp && rocprofv3 "${rargs[@]}" --output-format csv -d $out -- python3 $R/bench.py "$@" --no_cpu_baseline > $out/bench.log 2>&1) \
+        || echo "FAILED: $out"
+    echo "done $(basename $out) $(date +%T)"
+}
+SQ_A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY"
+SQ_B="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE"
+if [ "$PART" = a ]; then
+    D=$G/prof_r02
+    S="--steps 20 --warmup 5"
+    prof $D/trace --kernel-trace --stats -- $S
+    prof $D/pmc_sq --pmc $SQ_A -- $S
+    prof $D/pmc_lds --pmc $SQ_B -- $S
+    prof $D/pmc_fetch --pmc FETCH_SIZE -- $S
+    prof $D/pmc_write --pmc WRITE_SIZE -- $S
+    prof $D/pmc_mix --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_CVT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY -- $S
+    cp $D/trace/*/*_kernel_stats.csv $P/r02_kernel_stats.csv
+    python3 scripts/summarise_prof.py $D vi_fwd > $P/r02_vi_fwd_summary.json
+    grep -h '"metric"' $D/trace/bench.log | tail -1 > $P/r02_bench_under_rocprof.json
+    python3 bench.py > $P/r02_bench.json 2> $G/r02_bench.err; echo "bench default rc=$?"
+    python3 bench.py --voxels 4194304 --no_cpu_baseline > $P/r02_bench_4m.json 2>> $G/r02_bench.err
+    python3 bench.py --encoder_precision bf16 --no_cpu_baseline > $P/r02_bench_bf16.json 2>> $G/r02_bench.err
+else
+    D=$G/prof_r02c3
+    S="--config 3 --steps 6 --warmup 2 --ramp_ms 20"
+    prof $D/trace --kernel-trace --stats -- $S
+    prof $D/pmc_sq --pmc $SQ_A -- $S
+    prof $D/pmc_lds --pmc $SQ_B -- $S
+    prof $D/pmc_fetch --pmc FETCH_SIZE -- $S
+    prof $D/pmc_write --pmc WRITE_SIZE -- $S
+    cp $D/trace/*/*_kernel_stats.csv $P/r02_config3_kernel_stats.csv
+    python3 scripts/summarise_prof.py $D wide_fused > $P/r02_config3_wide_fused_summary.json
+    python3 scripts/summarise_prof.py $D elbo_fwd_lds > $P/r02_config3_elbo_summary.json
+    grep -h '"metric"' $D/trace/bench.log | tail -1 > $P/r02_bench_config3_under_rocprof.json
+    for v in p24:"--protocol 24" bf16:"--encoder_precision bf16"; do
+        tag=${v%%:*}; args=${v#*:}
+        D=$G/prof_r02$tag
+        prof $D/trace --kernel-trace --stats -- --steps 20 --warmup 5 $args
+        prof $D/pmc_fetch --pmc FETCH_SIZE -- --steps 20 --warmup 5 $args
+        prof $D/pmc_write --pmc WRITE_SIZE -- --steps 20 --warmup 5 $args
+        python3 scripts/summarise_prof.py $D vi_fwd > $P/r02_${tag}_vi_fwd_summary.json
+    done
+    python3 bench.py --config 3 > $P/r02_bench_config3.json 2> $G/r02_bench_c3.err; echo "bench config3 rc=$?"
+    python3 bench.py --protocol 24 --no_cpu_baseline > $P/r02_bench_p24.json 2>> $G/r02_bench_c3.err
+fi
+python3 -c "from qbold_vi_amd.build import source_fingerprint; print(source_fingerprint())" > $P/source_sha256_$PART.txt
+ls -la $P
