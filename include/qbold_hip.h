@@ -333,6 +333,14 @@ int64_t qbold_train_workspace_floats(const qbold_encoder_shape* shape, int64_t N
 int qbold_encoder_train_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* weights,
                             const float* x, int stream_sel, float* workspace, float* out_q,
                             float* out_log_sigma, int64_t N, void* stream);
+/* stream_sel = 2 of the call above in ONE launch for the shapes of the LDS-resident kernels (U <= 64, L <= 2,
+ * T = 11 or 24, channel-wise gating, QBOLD_ENC_F32; 0 < N < 2^24): `packed` is the image of
+ * qbold_encoder_pack; the workspace receives the same saved tensors, so qbold_encoder_train_bwd follows
+ * unchanged.  Products are the float32-grade split-f16 ones of qbold_encoder_fwd (operand range above: heads
+ * come out NaN beyond it), not the exact-f32 GEMMs of qbold_encoder_train_fwd. */
+int qbold_encoder_train_fwd_fused(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* packed,
+                                  const float* x, float* workspace, float* out_q, float* out_log_sigma,
+                                  int64_t N, void* stream);
 /* The same on image crops: geom->B*X*Y*Z voxels, stream 2 with its 3x3x1 'same' convolutions
  * (shape->spatial_taps must be 9).  geom = NULL is the voxel-batch call above. */
 int qbold_encoder_spatial_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* weights,

@@ -182,6 +182,110 @@ __global__ __launch_bounds__(kEncBlock) void encoder_fwd_kernel(
     }
 }
 
+
+// ---- training forward in one launch ------------------------------------------------------------------
+// Stream 2 with every tensor the layer-wise backward (train_kernels.hip, qbold_encoder_train_bwd) reads saved on
+// the way: the workspace slots of qbold_encoder_train_fwd, [N][64] float32 each -- 0: n (normalised signals,
+// columns T .. round-up-to-4 zeroed), 1: h, then per block skip, t, r, gate logits (without gate_offset: the
+// backward adds it), b_out.  Same arithmetic as encoder_fwd_kernel (activations in registers, split-f16 MFMA
+// products); the accumulator layout hands each lane four consecutive units of its voxel per 16-row tile, one
+// 16-byte store.  The layer-wise forward moves each tensor through HBM two to three times (1.70 ms per 1 M
+// voxels); this kernel writes each once.
+// (wave-uniform slot base + a 32-bit lane offset: the scalar-base store form, no 64-bit address per store; lanes
+// beyond the batch repeat the last voxel's row -- same values to the same address)
+__device__ __forceinline__ void save_rows(float* __restrict__ slot, uint32_t voff, const f32x4 (&a)[4]) {
+    char* sb = reinterpret_cast<char*>(slot);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        *reinterpret_cast<float4*>(sb + voff + 64 * m) = make_float4(a[m][0], a[m][1], a[m][2], a[m][3]);
+}
+
+template <int T, int NL>
+__global__ __launch_bounds__(kEncBlock) void encoder_train_fwd_kernel(
+    QbDev c, const float* __restrict__ packed, const float* __restrict__ x, float gate_offset,
+    float* __restrict__ ws, float* __restrict__ out_q, float* __restrict__ out_ls, int64_t N) {
+    constexpr EncLayout e = qb::make_enc_layout(T, 64, NL);
+    extern __shared__ __align__(16) float lds_w[];
+    for (int p = threadIdx.x; p < e.total / 4; p += kEncBlock)
+        reinterpret_cast<float4*>(lds_w)[p] = reinterpret_cast<const float4*>(packed)[p];
+    __syncthreads();
+
+    constexpr int HT = (5 + T + 15) / 16;
+    constexpr int WC = (T + 3) & ~3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    constexpr int NW = kEncBlock / 64;
+    const int64_t ntile = (N + 15) / 16;
+    const int64_t slot_floats = N * 64;
+    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntile; tile += (int64_t)gridDim.x * NW) {
+        const int64_t v = tile * 16 + i;
+        const bool live = v < N;
+        const int64_t vc = live ? v : N - 1;  // clamp: every lane takes part in the MFMAs
+        float xv[T], nv[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) xv[t] = x[vc * T + t];
+        qb::normalise<T>(c, xv, nv);
+        const uint32_t voff = (uint32_t)vc * 256u + 16u * (uint32_t)g;  // N < 2^24 voxels (checked by the host)
+        if (g == 0) {
+#pragma unroll
+            for (int t = 0; t < WC; ++t) ws[vc * 64 + t] = t < T ? nv[t < T ? t : 0] : 0.0f;
+        }
+        f32x4 b[4];
+        qb::dense_first<T, false>(lds_w + e.first_A, lds_w + e.first_b, nv, b, lane);
+        save_rows(ws + slot_floats, voff, b);
+        float amax = lds_w[e.flag];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {   // block_stream2 (encoder_core.h) with its tensors saved
+            const float* W = lds_w + e.blk0 + l * e.blk_stride;
+            float* base = ws + (int64_t)(2 + 5 * l) * slot_floats;
+            f32x4 skip[4], t[4], r[4];
+            qb::dense64<false>(W + qb::BLK_WC_A, W + qb::BLK_WC_B, b, skip, lane, &amax);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                skip[m] = qb::relu4(skip[m]);
+                b[m] = qb::relu4(b[m]);
+            }
+            save_rows(base, voff, skip);
+            qb::dense64<false>(W + qb::BLK_R1_A, W + qb::BLK_R1_B, b, t, lane);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) t[m] = qb::relu4(t[m]);
+            save_rows(base + slot_floats, voff, t);
+            qb::dense64<false>(W + qb::BLK_R2_A, W + qb::BLK_R2_B, t, r, lane, &amax);
+            save_rows(base + 2 * slot_floats, voff, r);
+            qb::dense64<false>(W + qb::BLK_G_A, W + qb::BLK_G_B, r, t, lane, &amax);  // logits + gate_offset
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float gate = qb::sigmoidf_(t[m][k]);
+                    b[m][k] = skip[m][k] * (1.0f - gate) + r[m][k] * gate;
+                    t[m][k] -= gate_offset;
+                }
+            }
+            save_rows(base + 3 * slot_floats, voff, t);
+            save_rows(base + 4 * slot_floats, voff, b);
+        }
+        f32x4 hd[HT];
+        qb::dense_head<HT, false>(lds_w + e.head_A, lds_w + e.head_b, b, hd, lane, &amax);
+        float o[5 + T];
+        qb::gather_head<5 + T, HT>(hd, o);
+        amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        if (qb::split_overflowed(amax)) {   // operand range guard: NaN heads, never a clamped number
+#pragma unroll
+            for (int k = 0; k < 5 + T; ++k) o[k] = __builtin_nanf("");
+        }
+        if (live && g == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) out_q[v * 5 + k] = o[k];
+        }
+        if (live && g == 1 && out_ls) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) out_ls[v * T + t] = o[5 + t];
+        }
+    }
+}
+
 }  // namespace
 
 namespace qb {
@@ -258,6 +362,46 @@ extern "C" int qbold_encoder_fwd(const qbold_ctx* ctx, const qbold_encoder_shape
         return QBOLD_ERR_UNSUPPORTED;
     }
 #undef QB_LAUNCH_ENC
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
+extern "C" int qbold_encoder_train_fwd_fused(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
+                                             const float* packed, const float* x, float* ws, float* out_q,
+                                             float* out_log_sigma, int64_t N, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    int rc = qb::check_encoder_shape(ctx, shape);
+    if (rc) return rc;
+    if (!shape->channelwise_gating || shape->precision != QBOLD_ENC_F32) {
+        qb::set_error("qbold_encoder_train_fwd_fused: built for channel-wise gating, QBOLD_ENC_F32");
+        return QBOLD_ERR_UNSUPPORTED;
+    }
+    QB_REQUIRE(N > 0 && N < ((int64_t)1 << 24) && packed && x && ws && out_q,
+               "qbold_encoder_train_fwd_fused: bad argument (0 < N < 2^24 voxels per call)");
+    QB_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 16 == 0 && reinterpret_cast<uintptr_t>(packed) % 16 == 0,
+               "qbold_encoder_train_fwd_fused: packed image and workspace must be 16-byte aligned");
+    const EncLayout e = qb::make_enc_layout(shape->T, shape->U, shape->L);
+    const size_t smem = sizeof(float) * e.total;
+    const int64_t ntile = (N + 15) / 16;
+    const int64_t nblk = (ntile + kEncBlock / 64 - 1) / (kEncBlock / 64);
+    const int grid = (int)(nblk < ctx->num_cus ? nblk : ctx->num_cus);
+#define QB_LAUNCH_TRAIN_FWD(TT, NL)                                                                  \
+    do {                                                                                             \
+        auto k = encoder_train_fwd_kernel<TT, NL>;                                                   \
+        QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                 \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));          \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kEncBlock), smem, (hipStream_t)stream, ctx->dev,      \
+                           packed, x, shape->gate_offset, ws, out_q, out_log_sigma, N);              \
+    } while (0)
+    if (shape->T == 11 && shape->L == 1) QB_LAUNCH_TRAIN_FWD(11, 1);
+    else if (shape->T == 11 && shape->L == 2) QB_LAUNCH_TRAIN_FWD(11, 2);
+    else if (shape->T == 24 && shape->L == 1) QB_LAUNCH_TRAIN_FWD(24, 1);
+    else if (shape->T == 24 && shape->L == 2) QB_LAUNCH_TRAIN_FWD(24, 2);
+    else {
+        qb::set_error("qbold_encoder_train_fwd_fused: kernels are built for T = 11 or 24 taus, L = 1 or 2");
+        return QBOLD_ERR_UNSUPPORTED;
+    }
+#undef QB_LAUNCH_TRAIN_FWD
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }

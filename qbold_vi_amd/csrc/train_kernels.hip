@@ -1304,6 +1304,163 @@ __global__ void gate_bwd_kernel(const float* __restrict__ d_b, const float* __re
     }
 }
 
+
+// ---- data side of one gated block's backward in ONE launch ------------------------------------------------
+// For voxel batches of the LDS-resident shapes.  Per 16-voxel wave tile (the lane layout of encoder_core.h: a
+// lane holds four consecutive units of its voxel per 16-row tile, so [N][64] rows load and store as float4):
+// read b_in and d b_out, RECOMPUTE the block (skip, t, r, gate: four dense64 on the block's forward image --
+// bit-identical to the forward that ran, so the relu masks agree), form the element-wise deltas, run the four
+// backward-data products on the TRANSPOSED image and write the four deltas the weight-gradient kernels need
+// plus d b_in:
+//   d gl  = d b (r - skip) g (1 - g)                         -> xtd(r, d gl)       = dWg
+//   d r   = d b g + d gl Wg^T                                -> xtd(t, d r)        = dWr2
+//   d t'  = (d r Wr2^T) (t > 0)                              -> xtd(relu b_in, d t') = dWr1
+//   d s'  = d b (1 - g) (skip > 0)                           -> xtd(b_in, d s')    = dWc
+//   d b_in = (d t' Wr1^T) (b_in > 0) + d s' Wc^T
+// 2 tensor reads + 5 writes instead of the 17 passes of gate_bwd_kernel + three xw64 launches.  Deltas carry
+// the 1 / sum(mask) of the loss (1e-6 and below): each product's input is scaled per voxel by a power of two
+// into [2^13, 2^14) before the f16 split and the output scaled back, exact in both directions.
+constexpr int kBlkThreads = 1024;
+constexpr uint32_t kDropped = 0x80000000u;   // beyond any row buffer (N < 2^23): the hardware drops the store
+
+// (columns U .. 63 of a row tensor are padding nobody is obliged to write: read as zero)
+__device__ __forceinline__ void load_rows(const float* __restrict__ slot, uint32_t voff, int g, int U, f32x4 (&a)[4]) {
+    const char* sb = reinterpret_cast<const char*>(slot);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float4 q = *reinterpret_cast<const float4*>(sb + voff + 64 * m);
+        a[m] = f32x4{q.x, q.y, q.z, q.w};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[3][k] = 48 + 4 * g + k < U ? a[3][k] : 0.0f;   // U > 48 on this path
+}
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_rows(__amdgpu_buffer_rsrc_t rs, uint32_t soff, const f32x4 (&a)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, a[m]), rs, soff + 64u * m, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_buffer(float* p, int64_t N) {
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, (uint32_t)(N * 256), 0x00020000);
+}
+// out = W in (no bias: the transposed image is packed with zero biases) with a per-voxel power-of-two scale
+__device__ __forceinline__ void dense64_scaled(const float* __restrict__ A, const float* __restrict__ bias,
+                                               const f32x4 (&in)[4], f32x4 (&out)[4], int lane) {
+    float mx = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx = fmaxf(mx, fabsf(in[m][k]));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));   // the voxel's largest delta (its units sit in four lanes)
+    int se = 267 - ((__float_as_int(mx) >> 23) & 0xff);   // 2^(13 - exponent) as a biased exponent
+    se = se < 1 ? 1 : (se > 250 ? 250 : se);
+    const float sc = __int_as_float(se << 23), inv = __int_as_float((254 - se) << 23);
+    f32x4 sin[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sin[m][k] = in[m][k] * sc;
+    qb::dense64<false>(A, bias, sin, out, lane);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[m][k] *= inv;
+}
+
+__global__ __launch_bounds__(kBlkThreads) void block_bwd_kernel(
+    const float* __restrict__ img_f, const float* __restrict__ img_b, const float* __restrict__ b_in,
+    const float* d_b, float* d_gl, float* d_r, float* d_t, float* d_s, float* d_bin, int U, int64_t N) {
+    extern __shared__ __align__(16) float lds_img[];
+    float* F = lds_img;
+    float* B = lds_img + qb::BLK_FLOATS;
+    for (int p = threadIdx.x; p < qb::BLK_FLOATS / 4; p += kBlkThreads) {
+        reinterpret_cast<float4*>(F)[p] = reinterpret_cast<const float4*>(img_f)[p];
+        reinterpret_cast<float4*>(B)[p] = reinterpret_cast<const float4*>(img_b)[p];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    constexpr int NW = kBlkThreads / 64;
+    const __amdgpu_buffer_rsrc_t o_gl = row_buffer(d_gl, N), o_r = row_buffer(d_r, N), o_t = row_buffer(d_t, N),
+                                 o_s = row_buffer(d_s, N), o_b = row_buffer(d_bin, N);
+    const int64_t ntile = (N + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntile; tile += (int64_t)gridDim.x * NW) {
+        const int64_t v = tile * 16 + i;
+        const bool live = v < N;
+        const uint32_t voff = (uint32_t)(live ? v : N - 1) * 256u + 16u * (uint32_t)g;
+        const uint32_t soff = live ? voff : kDropped;
+        f32x4 b[4], skip[4], t[4], r[4];
+        load_rows(b_in, voff, g, U, b);
+        uint32_t m_bin = 0u, m_t = 0u;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m_bin |= b[m][k] > 0.0f ? 1u << (4 * m + k) : 0u;
+        // the block again, as encoder_core.h block_stream2 computed it
+        qb::dense64<false>(F + qb::BLK_WC_A, F + qb::BLK_WC_B, b, skip, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            skip[m] = qb::relu4(skip[m]);
+            b[m] = qb::relu4(b[m]);
+        }
+        qb::dense64<false>(F + qb::BLK_R1_A, F + qb::BLK_R1_B, b, t, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            t[m] = qb::relu4(t[m]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m_t |= t[m][k] > 0.0f ? 1u << (4 * m + k) : 0u;
+        }
+        qb::dense64<false>(F + qb::BLK_R2_A, F + qb::BLK_R2_B, t, r, lane);
+        qb::dense64<false>(F + qb::BLK_G_A, F + qb::BLK_G_B, r, t, lane);   // gate logits + gate_offset
+        load_rows(d_b, voff, g, U, b);
+        // element-wise deltas: r <- d gl, skip <- d s', b <- d b g
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gate = qb::sigmoidf_(t[m][k]);
+                const float db = b[m][k], sk = skip[m][k];
+                r[m][k] = db * (r[m][k] - sk) * gate * (1.0f - gate);
+                skip[m][k] = sk > 0.0f ? db * (1.0f - gate) : 0.0f;
+                b[m][k] = db * gate;
+            }
+        }
+        store_rows(o_gl, soff, r);
+        store_rows(o_s, soff, skip);
+        dense64_scaled(B + qb::BLK_G_A, B + qb::BLK_G_B, r, t, lane);        // d gl Wg^T
+#pragma unroll
+        for (int m = 0; m < 4; ++m) b[m] += t[m];                            // d r
+        store_rows(o_r, soff, b);
+        dense64_scaled(B + qb::BLK_R2_A, B + qb::BLK_R2_B, b, t, lane);      // d r Wr2^T
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[m][k] = (m_t >> (4 * m + k)) & 1u ? t[m][k] : 0.0f;
+        store_rows(o_t, soff, t);
+        dense64_scaled(B + qb::BLK_R1_A, B + qb::BLK_R1_B, t, r, lane);      // d t' Wr1^T
+        dense64_scaled(B + qb::BLK_WC_A, B + qb::BLK_WC_B, skip, b, lane);   // d s' Wc^T
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b[m][k] += (m_bin >> (4 * m + k)) & 1u ? r[m][k] : 0.0f;
+        store_rows(o_b, soff, b);
+    }
+}
+
+// the block matrices of the canonical blob transposed in place of themselves (centre tap of 3x3x1 kernels),
+// everything else zero: packed by qbold_encoder_pack this is the image whose dense64 multiplies by W^T
+__global__ void blob_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, qb::CanonLayout c) {
+    const int U = c.U, ctr = c.taps == 9 ? 4 * U * U : 0;
+    const int per = 4 * U * U;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < c.L * per; e += gridDim.x * blockDim.x) {
+        const int l = e / per, q = e % per, which = q / (U * U), ij = q % (U * U), ii = ij / U, jj = ij % U;
+        const int off = c.blk0 + l * c.blk_stride +
+                        (which == 0 ? c.Wc : which == 1 ? c.Wr1 + ctr : which == 2 ? c.Wr2 + ctr : c.Wg);
+        wt[off + jj * U + ii] = w[off + ii * U + jj];
+    }
+}
+
 // out = in * (ref > 0): the relu adjoint
 __global__ void mask_mul_kernel(const float* __restrict__ in, const float* __restrict__ ref,
                                 float* __restrict__ out, int64_t n) {
@@ -1744,6 +1901,27 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
         }
     }
     // dB = gradient wrt the last activation tensor
+    // Voxel batches of the LDS-resident shapes: per block one launch for the data side (block_bwd_kernel).  Its
+    // two weight images (the block as the forward packs it, and its transpose) are packed here, into the ninth
+    // slab region of the workspace, which voxel batches do not use.
+    const bool blk_fused = stream_sel == 2 && !gm && U > 48 && U <= 64 && ld == kLd && G == U && L <= 2 && T <= 27 &&
+                           shape->precision == QBOLD_ENC_F32 && N < ((int64_t)1 << 23) &&
+                           !(ctx->dev.debug_skip & 131072);
+    const qb::EncLayout el = qb::make_enc_layout(T, 64, L);
+    float* img_f = partial + (int64_t)8 * kSlabBlocks * (64 * 64 + 64) + 64 * 64;
+    float* img_b = img_f + el.total;
+    if (blk_fused) {
+        float* wt = img_b + el.total;
+        // (images and blob zeroed first: the pack kernel writes the slots it owns, the workspace is uninitialised)
+        QB_HIP(hipMemsetAsync(img_f, 0, sizeof(float) * (2 * (size_t)el.total + c.total), k.s));
+        hipLaunchKernelGGL(blob_transpose_kernel, dim3(64), dim3(256), 0, k.s, w, wt, c);
+        qbold_encoder_shape plain = *shape;
+        plain.gate_offset = 0.0f;   // the transposed image carries no biases
+        rc = qbold_encoder_pack(ctx, shape, w, img_f, k.s);
+        if (rc) return rc;
+        rc = qbold_encoder_pack(ctx, &plain, wt, img_b, k.s);
+        if (rc) return rc;
+    }
     if (stream_sel == 1) {
         for (int l = L - 1; l >= 0; --l) {
             const float* wb = w + c.blk0 + l * c.blk_stride;
@@ -1763,6 +1941,21 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             const float* gl = slot(5 + 5 * l);
             const float* b_in = l == 0 ? slot(1) : slot(6 + 5 * (l - 1));
             bool fused_in = false;
+            if (blk_fused) {   // the block's data side in one launch (block_bwd_kernel), then its four weight gradients
+                const size_t smem = sizeof(float) * 2 * qb::BLK_FLOATS;
+                QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(block_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                const int64_t nb = (N + 255) / 256;
+                hipLaunchKernelGGL(block_bwd_kernel, dim3((unsigned)(nb < ctx->num_cus ? nb : ctx->num_cus)),
+                                   dim3(kBlkThreads), smem, k.s, img_f + el.blk0 + l * el.blk_stride,
+                                   img_b + el.blk0 + l * el.blk_stride, b_in, dB, dE, dD, dA, dC, dB, U, N);
+                const int ctr = c.taps == 9 ? 4 * U * U : 0;
+                k.xtd(r, U, dE, G, partial, slabs, gb + c.Wg, G, gb + c.bg, 0);
+                k.xtd(t, U, dD, U, partial, slabs, gb + c.Wr2 + ctr, U, gb + c.br2, 0);
+                k.xtd(b_in, U, dA, U, partial, slabs, gb + c.Wr1 + ctr, U, gb + c.br1, 0, 1);
+                k.xtd(b_in, U, dC, U, partial, slabs, gb + c.Wc, U, gb + c.bc, 0);
+                continue;
+            }
             // dB = d b_out.  dC = d skip_pre, dD = d r, dE = d gate logits
             hipLaunchKernelGGL(gate_bwd_kernel, dim3(k.grid()), dim3(256), 0, k.s, dB, gl, skip, r, dC, dD,
                                dE, shape->gate_offset, U, G, ld, N);

@@ -680,6 +680,9 @@ class TrainState:
         self.step = 0
         self._ws = None
         self._ws_n = 0
+        # stream-2 voxel batches of the LDS-resident shapes: forward with saved activations in one launch
+        # (False: the layer-wise exact-f32 GEMM forward, kept for comparison and for every other shape)
+        self.fused_forward = True
 
     def workspace(self, N):
         if self._ws is None or self._ws_n < N:
@@ -695,10 +698,18 @@ class TrainState:
         N = x.numel() // ctx.T
         q = torch.empty((N, 5), dtype=torch.float32, device=x.device)
         ls = torch.empty((N, ctx.T), dtype=torch.float32, device=x.device) if stream_sel == 2 else None
-        _lib.check(ctx.lib.qbold_encoder_train_fwd(ctx.handle, C.byref(self.weights.shape),
-                                                   _ptr(self.weights.flat), _ptr(x), int(stream_sel),
-                                                   _ptr(self.workspace(N)), _ptr(q), _ptr(ls), N,
-                                                   _stream()), "qbold_encoder_train_fwd")
+        sh = self.weights.shape
+        if (stream_sel == 2 and self.fused_forward and Context.fits_fused(sh) and sh.channelwise_gating
+                and sh.precision == 0 and 0 < N < (1 << 24)):
+            # one launch, every saved tensor written once (encoder_kernels.hip, encoder_train_fwd_kernel)
+            _lib.check(ctx.lib.qbold_encoder_train_fwd_fused(ctx.handle, C.byref(sh), self.weights.packed_ptr(),
+                                                             _ptr(x), _ptr(self.workspace(N)), _ptr(q), _ptr(ls), N,
+                                                             _stream()), "qbold_encoder_train_fwd_fused")
+        else:
+            _lib.check(ctx.lib.qbold_encoder_train_fwd(ctx.handle, C.byref(sh),
+                                                       _ptr(self.weights.flat), _ptr(x), int(stream_sel),
+                                                       _ptr(self.workspace(N)), _ptr(q), _ptr(ls), N,
+                                                       _stream()), "qbold_encoder_train_fwd")
         self._n = N
         return q, ls
 

@@ -500,3 +500,58 @@ def test_learned_inverse_gamma_hyper_prior(params):
     # the reference cannot run the pair (infer_inv_gamma, use_mvg=True): model.py:455 splits 9 channels in two
     with pytest.raises(NotImplementedError):
         EncoderTrainer(params, activation_type='relu', use_mvg=True, infer_inv_gamma=True, use_population_prior=False)
+
+
+@pytest.mark.parametrize("T,L", [(11, 2), (11, 1), (24, 2)])
+def test_one_launch_training_forward_and_block_backward(params, T, L, monkeypatch):
+    """Voxel batches of the LDS-resident shapes train through two fused kernels: qbold_encoder_train_fwd_fused
+    (stream 2 forward, every saved tensor written once) and block_bwd_kernel (a gated block's data-side backward
+    in one launch: block recomputed, deltas scaled per voxel into the f16 split's range).  Against the layer-wise
+    exact-f32 kernels: heads, every saved tensor the backward reads (n: columns < T; h and per block skip, t, r,
+    gate logits, b_out: columns < U), and the weight gradient -- with head gradients of the size a real loss
+    produces (divided by the voxel count: 1e-6 and below, far under f16's normal range).  Ragged N."""
+    from qbold_vi_amd.init import init_encoder_weights
+    from qbold_vi_amd.ops import Context, EncoderWeights, TrainState
+    p = dict(params)
+    if T == 24:
+        p.update(tau_start="-0.028", tau_end="0.065", tau_step="0.004")
+    U, N = 60, 16 * 37 + 5
+    w = init_encoder_weights(T=T, U=U, L=L, channelwise_gating=True, resid_init_std=0.3, im_loss_sigma=0.05, seed=4)
+    rng = np.random.default_rng(11)
+    x = torch.as_tensor(rng.uniform(0.2, 1.0, (N, T)).astype(np.float32), device="cuda")
+    scale = np.exp(rng.uniform(np.log(1e-9), np.log(1e-4), (N, 1)))      # per-voxel magnitudes over five decades
+    g_q = torch.as_tensor((rng.normal(size=(N, 5)) * scale).astype(np.float32), device="cuda")
+    g_ls = torch.as_tensor((rng.normal(size=(N, T)) * scale).astype(np.float32), device="cuda")
+    out = {}
+    for fused in (False, True):
+        if fused:
+            monkeypatch.delenv("QBOLD_DEBUG_SKIP", raising=False)
+        else:   # ablation switch 131072: the layer-wise backward (gate_bwd_kernel + xw64 launches)
+            monkeypatch.setenv("QBOLD_DEBUG_SKIP", "131072")
+            monkeypatch.setenv("QBOLD_ALLOW_ABLATION", "1")
+        ctx = Context(p, True, True)
+        ew = EncoderWeights(ctx, T, U, L, True, -3.0).set_from_arrays(w)
+        st = TrainState(ctx, ew)
+        st.fused_forward = fused
+        st.workspace(N).fill_(float("nan"))      # whatever the backward reads must have been written
+        q, ls = st.forward(x, 2)
+        slots = st.workspace(N)[: (2 + 5 * L) * N * 64].reshape(2 + 5 * L, N, 64).clone()
+        grad = st.backward(2, g_q, g_ls).clone()
+        out[fused] = (q.clone(), ls.clone(), slots, grad)
+    monkeypatch.delenv("QBOLD_DEBUG_SKIP", raising=False)
+    (q0, ls0, s0, g0), (q1, ls1, s1, g1) = out[False], out[True]
+    assert torch.isfinite(q1).all() and torch.isfinite(ls1).all() and torch.isfinite(g1).all()
+    assert (q1 - q0).abs().max() < 1e-5 * max(1.0, float(q0.abs().max()))      # split-f16 products vs exact f32
+    assert (ls1 - ls0).abs().max() < 1e-5 * max(1.0, float(ls0.abs().max()))
+    assert (s1[0, :, :T] - s0[0, :, :T]).abs().max() < 2e-6           # n = log(x / x_se)
+    assert (s1[0, :, T:(T + 3) & ~3] == 0).all()
+    for k in range(1, 2 + 5 * L):
+        d = (s1[k, :, :U] - s0[k, :, :U]).abs().max()
+        assert d < 3e-5 * max(1.0, float(s0[k, :, :U].abs().max())), (k, float(d))
+    # weight gradient, tensor by tensor (relative to each tensor's own largest entry)
+    for name, pieces in ew._slices().items():
+        for l, (off, shape) in enumerate(pieces):
+            cnt = int(np.prod(shape))
+            a, b = g0[off:off + cnt], g1[off:off + cnt]
+            assert (a - b).abs().max() <= 2e-4 * float(a.abs().max()) + 1e-30, \
+                (name, l, float((a - b).abs().max()), float(a.abs().max()))
