@@ -84,7 +84,8 @@ SIGNATURES = {
                                  _P, _I64, _P]),
     "qbold_train_workspace_floats": (_I64, [C.POINTER(EncoderShape), _I64]),
     "qbold_encoder_train_fwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, C.c_int, _P, _P, _P, _I64, _P]),
-    "qbold_encoder_train_fwd_fused": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, _P, _P, _P, _I64, _P]),
+    "qbold_encoder_train_fwd_fused": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, C.c_int, _P, _P, _P, _I64, _P]),
+    "qbold_encoder_train_bwd_recomputes": (C.c_int, [_P, C.POINTER(EncoderShape), _I64]),
     "qbold_encoder_train_bwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, C.c_int, _P, _P, _P, _P, _P,
                                           _I64, _P]),
     "qbold_encoder_spatial_fwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, C.POINTER(Geometry), _P, _P,

@@ -200,7 +200,9 @@ __device__ __forceinline__ void save_rows(float* __restrict__ slot, uint32_t vof
         *reinterpret_cast<float4*>(sb + voff + 64 * m) = make_float4(a[m][0], a[m][1], a[m][2], a[m][3]);
 }
 
-template <int T, int NL>
+// SAVE_ALL = false leaves out skip and the gate logits, which the one-launch block backward (train_kernels.hip,
+// block_bwd_kernel) recomputes: eight tensors instead of twelve.
+template <int T, int NL, bool SAVE_ALL>
 __global__ __launch_bounds__(kEncBlock) void encoder_train_fwd_kernel(
     QbDev c, const float* __restrict__ packed, const float* __restrict__ x, float gate_offset,
     float* __restrict__ ws, float* __restrict__ out_q, float* __restrict__ out_ls, int64_t N) {
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(kEncBlock) void encoder_train_fwd_kernel(
 #pragma unroll
         for (int t = 0; t < T; ++t) xv[t] = x[vc * T + t];
         qb::normalise<T>(c, xv, nv);
-        const uint32_t voff = (uint32_t)vc * 256u + 16u * (uint32_t)g;  // N < 2^24 voxels (checked by the host)
+        const uint32_t voff = (uint32_t)vc * 256u + 16u * (uint32_t)g;  // N < 2^23 voxels (checked by the host)
         if (g == 0) {
 #pragma unroll
             for (int t = 0; t < WC; ++t) ws[vc * 64 + t] = t < T ? nv[t < T ? t : 0] : 0.0f;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(kEncBlock) void encoder_train_fwd_kernel(
                 skip[m] = qb::relu4(skip[m]);
                 b[m] = qb::relu4(b[m]);
             }
-            save_rows(base, voff, skip);
+            if constexpr (SAVE_ALL) save_rows(base, voff, skip);
             qb::dense64<false>(W + qb::BLK_R1_A, W + qb::BLK_R1_B, b, t, lane);
 #pragma unroll
             for (int m = 0; m < 4; ++m) t[m] = qb::relu4(t[m]);
@@ -259,10 +261,10 @@ __global__ __launch_bounds__(kEncBlock) void encoder_train_fwd_kernel(
                 for (int k = 0; k < 4; ++k) {
                     const float gate = qb::sigmoidf_(t[m][k]);
                     b[m][k] = skip[m][k] * (1.0f - gate) + r[m][k] * gate;
-                    t[m][k] -= gate_offset;
+                    if constexpr (SAVE_ALL) t[m][k] -= gate_offset;
                 }
             }
-            save_rows(base + 3 * slot_floats, voff, t);
+            if constexpr (SAVE_ALL) save_rows(base + 3 * slot_floats, voff, t);
             save_rows(base + 4 * slot_floats, voff, b);
         }
         f32x4 hd[HT];
@@ -367,8 +369,8 @@ extern "C" int qbold_encoder_fwd(const qbold_ctx* ctx, const qbold_encoder_shape
 }
 
 extern "C" int qbold_encoder_train_fwd_fused(const qbold_ctx* ctx, const qbold_encoder_shape* shape,
-                                             const float* packed, const float* x, float* ws, float* out_q,
-                                             float* out_log_sigma, int64_t N, void* stream) {
+                                             const float* packed, const float* x, int save_all, float* ws,
+                                             float* out_q, float* out_log_sigma, int64_t N, void* stream) {
     QB_NEED_DEVICE(ctx);
     int rc = qb::check_encoder_shape(ctx, shape);
     if (rc) return rc;
@@ -376,8 +378,8 @@ extern "C" int qbold_encoder_train_fwd_fused(const qbold_ctx* ctx, const qbold_e
         qb::set_error("qbold_encoder_train_fwd_fused: built for channel-wise gating, QBOLD_ENC_F32");
         return QBOLD_ERR_UNSUPPORTED;
     }
-    QB_REQUIRE(N > 0 && N < ((int64_t)1 << 24) && packed && x && ws && out_q,
-               "qbold_encoder_train_fwd_fused: bad argument (0 < N < 2^24 voxels per call)");
+    QB_REQUIRE(N > 0 && N < ((int64_t)1 << 23) && packed && x && ws && out_q,
+               "qbold_encoder_train_fwd_fused: bad argument (0 < N < 2^23 voxels per call)");
     QB_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 16 == 0 && reinterpret_cast<uintptr_t>(packed) % 16 == 0,
                "qbold_encoder_train_fwd_fused: packed image and workspace must be 16-byte aligned");
     const EncLayout e = qb::make_enc_layout(shape->T, shape->U, shape->L);
@@ -387,7 +389,7 @@ extern "C" int qbold_encoder_train_fwd_fused(const qbold_ctx* ctx, const qbold_e
     const int grid = (int)(nblk < ctx->num_cus ? nblk : ctx->num_cus);
 #define QB_LAUNCH_TRAIN_FWD(TT, NL)                                                                  \
     do {                                                                                             \
-        auto k = encoder_train_fwd_kernel<TT, NL>;                                                   \
+        auto k = save_all ? encoder_train_fwd_kernel<TT, NL, true> : encoder_train_fwd_kernel<TT, NL, false>; \
         QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                 \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));          \
         hipLaunchKernelGGL(k, dim3(grid), dim3(kEncBlock), smem, (hipStream_t)stream, ctx->dev,      \

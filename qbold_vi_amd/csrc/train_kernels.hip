@@ -1332,7 +1332,9 @@ __device__ __forceinline__ void load_rows(const float* __restrict__ slot, uint32
         a[m] = f32x4{q.x, q.y, q.z, q.w};
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a[3][k] = 48 + 4 * g + k < U ? a[3][k] : 0.0f;   // U > 48 on this path
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[m][k] = 16 * m + 4 * g + k < U ? a[m][k] : 0.0f;
 }
 typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_rows(__amdgpu_buffer_rsrc_t rs, uint32_t soff, const f32x4 (&a)[4]) {
@@ -1837,6 +1839,17 @@ extern "C" int qbold_encoder_spatial_fwd(const qbold_ctx* ctx, const qbold_encod
     return train_fwd_impl(ctx, shape, w, x, 2, ws, out_q, out_log_sigma, N, stream, geom);
 }
 
+// the condition under which a stream-2 voxel-batch backward runs block_bwd_kernel (one definition: the forward
+// leaves out what that kernel recomputes only if this says so)
+static bool block_bwd_applies(const qbold_ctx* ctx, const qbold_encoder_shape* s, int64_t N) {
+    return ctx && s && s->U >= 1 && s->U <= 64 && s->channelwise_gating && s->L >= 1 && s->L <= 2 && s->T <= 27 &&
+           s->T == ctx->dev.T && s->precision == QBOLD_ENC_F32 && N > 0 && N < ((int64_t)1 << 23) &&
+           !(ctx->dev.debug_skip & 131072);
+}
+extern "C" int qbold_encoder_train_bwd_recomputes(const qbold_ctx* ctx, const qbold_encoder_shape* shape, int64_t N) {
+    return block_bwd_applies(ctx, shape, N) ? 1 : 0;
+}
+
 // g_head_q [N][5], g_head_ls [N][T] (stream 2 only; may be NULL), sums: device double[3] whose
 // third entry is sum(mask) (NULL = gradients already normalised).  grad: canonical layout, overwritten.
 static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* w,
@@ -1904,9 +1917,7 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     // Voxel batches of the LDS-resident shapes: per block one launch for the data side (block_bwd_kernel).  Its
     // two weight images (the block as the forward packs it, and its transpose) are packed here, into the ninth
     // slab region of the workspace, which voxel batches do not use.
-    const bool blk_fused = stream_sel == 2 && !gm && U > 48 && U <= 64 && ld == kLd && G == U && L <= 2 && T <= 27 &&
-                           shape->precision == QBOLD_ENC_F32 && N < ((int64_t)1 << 23) &&
-                           !(ctx->dev.debug_skip & 131072);
+    const bool blk_fused = stream_sel == 2 && !gm && block_bwd_applies(ctx, shape, N);
     const qb::EncLayout el = qb::make_enc_layout(T, 64, L);
     float* img_f = partial + (int64_t)8 * kSlabBlocks * (64 * 64 + 64) + 64 * 64;
     float* img_b = img_f + el.total;

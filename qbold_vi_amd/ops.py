@@ -700,11 +700,13 @@ class TrainState:
         ls = torch.empty((N, ctx.T), dtype=torch.float32, device=x.device) if stream_sel == 2 else None
         sh = self.weights.shape
         if (stream_sel == 2 and self.fused_forward and Context.fits_fused(sh) and sh.channelwise_gating
-                and sh.precision == 0 and 0 < N < (1 << 24)):
-            # one launch, every saved tensor written once (encoder_kernels.hip, encoder_train_fwd_kernel)
+                and sh.precision == 0 and 0 < N < (1 << 23)):
+            # one launch, every saved tensor written once (encoder_kernels.hip, encoder_train_fwd_kernel); the two
+            # tensors per block that the backward recomputes are left out when it says it will
+            save_all = 0 if ctx.lib.qbold_encoder_train_bwd_recomputes(ctx.handle, C.byref(sh), N) == 1 else 1
             _lib.check(ctx.lib.qbold_encoder_train_fwd_fused(ctx.handle, C.byref(sh), self.weights.packed_ptr(),
-                                                             _ptr(x), _ptr(self.workspace(N)), _ptr(q), _ptr(ls), N,
-                                                             _stream()), "qbold_encoder_train_fwd_fused")
+                                                             _ptr(x), save_all, _ptr(self.workspace(N)), _ptr(q),
+                                                             _ptr(ls), N, _stream()), "qbold_encoder_train_fwd_fused")
         else:
             _lib.check(ctx.lib.qbold_encoder_train_fwd(ctx.handle, C.byref(sh),
                                                        _ptr(self.weights.flat), _ptr(x), int(stream_sel),
