@@ -1345,9 +1345,10 @@ __device__ __forceinline__ void store_rows(__amdgpu_buffer_rsrc_t rs, uint32_t s
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_buffer(float* p, int64_t N) {
     return __builtin_amdgcn_make_buffer_rsrc(p, 0, (uint32_t)(N * 256), 0x00020000);
 }
-// out = W in (no bias: the transposed image is packed with zero biases) with a per-voxel power-of-two scale
+// out = W in (no bias: the transposed image is packed with zero biases) with a per-voxel power-of-two scale;
+// `in` is scaled in place (every caller is done with it)
 __device__ __forceinline__ void dense64_scaled(const float* __restrict__ A, const float* __restrict__ bias,
-                                               const f32x4 (&in)[4], f32x4 (&out)[4], int lane) {
+                                               f32x4 (&in)[4], f32x4 (&out)[4], int lane) {
     float mx = 0.0f;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -1358,12 +1359,11 @@ __device__ __forceinline__ void dense64_scaled(const float* __restrict__ A, cons
     int se = 267 - ((__float_as_int(mx) >> 23) & 0xff);   // 2^(13 - exponent) as a biased exponent
     se = se < 1 ? 1 : (se > 250 ? 250 : se);
     const float sc = __int_as_float(se << 23), inv = __int_as_float((254 - se) << 23);
-    f32x4 sin[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sin[m][k] = in[m][k] * sc;
-    qb::dense64<false>(A, bias, sin, out, lane);
+        for (int k = 0; k < 4; ++k) in[m][k] *= sc;
+    qb::dense64<false>(A, bias, in, out, lane);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
