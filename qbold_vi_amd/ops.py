@@ -322,6 +322,7 @@ class Context:
             st = getattr(weights, "_layerwise_state", None)
             if st is None:  # activation workspace is kept with the weights, not re-allocated per call
                 st = weights._layerwise_state = TrainState(self, weights, optimiser_state=False)
+                st.fused_forward = False
             x2 = x.reshape(N, self.T)
             o1 = o2 = sg = None
             if "out1" in want:
@@ -427,6 +428,7 @@ class Context:
         st = getattr(weights, "_layerwise_state", None)
         if st is None:
             st = weights._layerwise_state = TrainState(self, weights, optimiser_state=False)
+            st.fused_forward = False   # the exact-f32 GEMM forward: the whole point of this path
         q2, ls = st.forward(x.reshape(N, self.T), 2)
         sums, nk = self.elbo_fwd(x, mask, q2, prior, self.transform("exp", ls), S, K, seed=seed, voxel0=voxel0)
         return sums, q2, nk
