@@ -52,7 +52,7 @@ def put(name, obj):
 n = 1 << 20
 copied = []
 for name in sorted(os.listdir(src)):
-    if name.startswith("source_sha256"):
+    if name.startswith("source_sha256") or (name.startswith(f"{tag}_train_") and name.endswith("_summary.json")):
         continue
     dst = os.path.join(P, name)
     if name.startswith(f"{tag}_bench") and name.endswith(".json"):
@@ -86,4 +86,19 @@ if fb:
                            ("bf16", "vi_fwd_kernel<11,2,2,true,false,true>", 96 * n)):
         if os.path.exists(os.path.join(src, f"{tag}_{t}_vi_fwd_summary.json")):
             put(f"{tag}_{t}_vi_fwd_pmc.json", pmc_file(f"{tag}_{t}_vi_fwd_summary.json", kernel, n, alg, fb))
+fc = sha("c")
+if fc:
+    train = {"workload": "scripts/bench_train.py --only voxel: one fine-tuning step on 1,048,576 voxels ([N][64] float32 "
+                         "tensors = 268 MB each)", "source_sha256": fc, "note": NOTE, "kernels": {}}
+    for k in ("block_bwd_kernel", "encoder_train_fwd_kernel", "xtd_kernel", "elbo_bwd_kernel"):
+        f = os.path.join(src, f"{tag}_train_{k}_summary.json")
+        if os.path.exists(f):
+            s_ = json.load(open(f))
+            c_ = {n: v["mean"] for n, v in s_["pmc"].items()}
+            if "FETCH_SIZE" in c_ and "WRITE_SIZE" in c_:
+                train["kernels"][k] = {"FETCH_SIZE_KB": c_["FETCH_SIZE"], "WRITE_SIZE_KB": c_["WRITE_SIZE"],
+                                       "hbm_read_MB_x2_gfx950": 2 * c_["FETCH_SIZE"] * 1024 / 1e6,
+                                       "hbm_write_MB": c_["WRITE_SIZE"] * 1024 / 1e6,
+                                       "kernel_stats": [r for r in s_["kernel_stats"] if k in r["name"]]}
+    put(f"{tag}_train_pmc.json", train)
 print("profiles/ updated:", copied)

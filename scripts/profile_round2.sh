@@ -5,6 +5,8 @@
 # of the kernel sources they were measured on.
 #   scripts/profile_round2.sh a   -- config 2 (headline): kernel trace, SQ / LDS / FETCH / WRITE counters,
 #                                    instruction mix; plain bench lines (default, 4 M voxels, bf16)
+#   scripts/profile_round2.sh c   -- one fine-tuning step (scripts/bench_train.py): kernel trace, FETCH / WRITE
+#                                    counters of the voxel step's kernels, the step times
 #   scripts/profile_round2.sh b   -- config 3: kernel trace + counters of both kernels; --protocol 24 and
 #                                    --encoder_precision bf16 FETCH / WRITE counters; plain bench lines
 PART=${1:-a}
@@ -38,6 +40,17 @@ if [ "$PART" = a ]; then
     python3 bench.py > $P/r02_bench.json 2> $G/r02_bench.err; echo "bench default rc=$?"
     python3 bench.py --voxels 4194304 --no_cpu_baseline > $P/r02_bench_4m.json 2>> $G/r02_bench.err
     python3 bench.py --encoder_precision bf16 --no_cpu_baseline > $P/r02_bench_bf16.json 2>> $G/r02_bench.err
+elif [ "$PART" = c ]; then
+    D=$G/prof_r02train
+    rm -rf $D; mkdir -p $D
+    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $R/scripts/bench_train.py > $D/trace.log 2>&1) || echo "FAILED trace"
+    (cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -- python3 $R/scripts/bench_train.py --only voxel --steps 3 > $D/fetch.log 2>&1) || echo "FAILED fetch"
+    (cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -- python3 $R/scripts/bench_train.py --only voxel --steps 3 > $D/write.log 2>&1) || echo "FAILED write"
+    cp $D/trace/*/*_kernel_stats.csv $P/r02_train_step_kernel_stats.csv
+    for k in block_bwd_kernel encoder_train_fwd_kernel xtd_kernel elbo_bwd_kernel; do
+        python3 scripts/summarise_prof.py $D $k > $P/r02_train_${k}_summary.json
+    done
+    python3 scripts/bench_train.py > $P/r02_train_step.json 2> $G/r02_train.err; cat $P/r02_train_step.json
 else
     D=$G/prof_r02c3
     S="--config 3 --steps 6 --warmup 2 --ramp_ms 20"
