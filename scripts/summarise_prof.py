@@ -12,7 +12,8 @@ out = {"dir": d, "kernel_filter": kfilter, "kernel_stats": [], "pmc": {}}
 for f in glob.glob(f"{d}/trace/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         if any(k in r["Name"] for k in ("qb::", "anonymous namespace)::")) and "at::" not in r["Name"]:
-            out["kernel_stats"].append({"name": r["Name"].split("(")[0][-60:] if "<" not in r["Name"] else r["Name"][:90],
+            nm = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            out["kernel_stats"].append({"name": nm.split("(")[0][-60:] if "<" not in nm else nm[:90],
                                         "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                         "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])})
 for f in glob.glob(f"{d}/pmc_*/*/*_counter_collection.csv"):
