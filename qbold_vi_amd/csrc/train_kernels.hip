@@ -1320,7 +1320,12 @@ __global__ void gate_bwd_kernel(const float* __restrict__ d_b, const float* __re
 // 2 tensor reads + 5 writes instead of the 17 passes of gate_bwd_kernel + three xw64 launches.  Deltas carry
 // the 1 / sum(mask) of the loss (1e-6 and below): each product's input is scaled per voxel by a power of two
 // into [2^13, 2^14) before the f16 split and the output scaled back, exact in both directions.
-constexpr int kBlkThreads = 1024;
+// eight waves per workgroup (one per CU: the two images take 133 KB of LDS): 168 VGPRs, no scratch.  Measured per
+// 1 M-voxel step: 1024 threads (128 VGPRs, 116 B of scratch per lane) 3.47 ms, 768 3.24, 512 3.15, 256 3.39.
+#ifndef QB_BLK_THREADS
+#define QB_BLK_THREADS 512
+#endif
+constexpr int kBlkThreads = QB_BLK_THREADS;
 constexpr uint32_t kDropped = 0x80000000u;   // beyond any row buffer (N < 2^23): the hardware drops the store
 
 // (columns U .. 63 of a row tensor are padding nobody is obliged to write: read as zero)
@@ -1956,7 +1961,7 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                 const size_t smem = sizeof(float) * 2 * qb::BLK_FLOATS;
                 QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(block_bwd_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                const int64_t nb = (N + 255) / 256;
+                const int64_t per_blk = (kBlkThreads / 64) * 16, nb = (N + per_blk - 1) / per_blk;
                 hipLaunchKernelGGL(block_bwd_kernel, dim3((unsigned)(nb < ctx->num_cus ? nb : ctx->num_cus)),
                                    dim3(kBlkThreads), smem, k.s, img_f + el.blk0 + l * el.blk_stride,
                                    img_b + el.blk0 + l * el.blk_stride, b_in, dB, dE, dD, dA, dC, dB, U, N);
