@@ -438,7 +438,7 @@ def main():
     drain()
     fence()
     # per-launch durations: HIP events on the launch stream
-    every = max(1, min(args.event_every, args.steps))
+    every = max(1, args.event_every) if args.steps >= 4 * max(1, args.event_every) else 1   # short runs: every step
     evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) if k % every == 0 else None
            for k in range(args.steps)]
     t0 = time.perf_counter()

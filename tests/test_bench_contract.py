@@ -33,7 +33,7 @@ def check_line(d, expect_cpu_baseline):
     per_gpu = d["config"]["global_voxels"] // d["n_gpus"]
     assert abs(r["achieved"] - r["algorithmic_flops_per_voxel"] * per_gpu / (r["kernel_ms"] * 1e-3) / 1e12) \
         < 1e-6 * r["achieved"]
-    assert r["kernel_ms"] <= d["ms_per_step"] * 1.001
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.02   # bracketed steps carry their events' barrier packets
     assert r["traffic"] is None or r["traffic"] > 0
     if "counters" in r:   # only quoted when measured on this build's kernel sources
         assert r["counters"]["source"].startswith("profiles/") and r["counters"]["kernel"]
