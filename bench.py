@@ -438,7 +438,7 @@ def main():
     drain()
     fence()
     # per-launch durations: HIP events on the launch stream
-    every = max(1, args.event_every) if args.steps >= 4 * max(1, args.event_every) else 1   # short runs: every step
+    every = max(1, min(args.event_every, args.steps // 5))   # at least five bracketed steps (short runs: every step)
     evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) if k % every == 0 else None
            for k in range(args.steps)]
     t0 = time.perf_counter()
@@ -507,9 +507,11 @@ def main():
         else:
             kname = "vi_fwd_kernel"
             ach, peak = step_ach, step_peak
-            prof = measured_profile("r02_vi_fwd_pmc.json", "vi_fwd_kernel") \
-                if (args.config == 2 and args.protocol == 11 and args.tissue == "table" and n == 1 << 20
-                    and args.encoder_precision == "f32") else None
+            # the counter file of this very configuration, if one was measured on these sources
+            pmc_name = {(11, "f32"): "r02_vi_fwd_pmc.json", (24, "f32"): "r02_p24_vi_fwd_pmc.json",
+                        (11, "bf16"): "r02_bf16_vi_fwd_pmc.json"}.get((args.protocol, args.encoder_precision))
+            prof = measured_profile(pmc_name, "vi_fwd_kernel") \
+                if (pmc_name and args.config == 2 and args.tissue == "table" and n == 1 << 20) else None
             # what the counters say; without a valid counter file the kernel's known regime
             bound = "valu-issue"
             note = ("one launch on two pipes: 'peak' is the composite of MI355X_MICROARCH.md's dense peaks -- the "
