@@ -1455,6 +1455,185 @@ __global__ __launch_bounds__(kBlkThreads) void block_bwd_kernel(
     }
 }
 
+
+// ---- the same with the block's four weight gradients accumulated in the kernel ----------------------------
+// block_bwd_kernel still hands its four deltas to four xtd_kernel launches, which re-read each delta and its
+// activation from HBM (0.5 ms per block on 1 M voxels).  Here a wave keeps the four 64 x 64 float32 gradient
+// accumulators (256 registers) for the whole launch -- ONE wave per SIMD, so that it owns the 512-entry register
+// file -- and adds each 16-voxel tile's contribution  dW[in][out] += sum_v X[v][in] D[v][out]  on
+// v_mfma_f32_16x16x4_f32 (exact float32 products, k = voxel).  Both operands of that MFMA want the UNIT on the
+// lane, while everything else in the kernel has the VOXEL on the lane: each tensor takes one trip through a
+// 5 KB LDS tile per wave ([voxel][80] floats: the row stride keeps the 16 lanes of the two k groups of a
+// half-wave on different banks) -- 4 ds_write_b128, 16 ds_read_b32.  The only tensor written is d b_in: 2 reads +
+// 1 write instead of 2 + 5 and eight more for the xtd launches.  Gradients leave as one slab per wave and matrix
+// ([in][out] + 64 bias sums, the format slab_reduce_kernel adds up in a fixed order: bitwise reproducible).
+constexpr int kDwThreads = 256;
+constexpr int kTrStride = 80;
+
+struct TileFrags {   // a [16 voxel][64 unit] tile as MFMA operand: f[tile][ks] = T[voxel 4 ks + lane / 16][unit 16 tile + lane % 16]
+    float f[4][4];
+};
+__device__ __forceinline__ void to_frags(float* __restrict__ buf, int lane, const f32x4 (&a)[4], TileFrags& o) {
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        *reinterpret_cast<float4*>(buf + i * kTrStride + 16 * m + 4 * g) = make_float4(a[m][0], a[m][1], a[m][2], a[m][3]);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) o.f[t][ks] = buf[(4 * ks + g) * kTrStride + 16 * t + i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is free for the next tensor
+    __builtin_amdgcn_wave_barrier();
+}
+// acc[mt][nt] += X^T D over the tile's 16 voxels; bias[nt] += this lane's share of the column sums of D
+template <bool RELU_X>
+__device__ __forceinline__ void dw_accumulate(const TileFrags& X, const TileFrags& D, f32x4 (&acc)[4][4], float (&bias)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float a = RELU_X ? fmaxf(X.f[mt][ks], 0.0f) : X.f[mt][ks];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = QB_MFMA16F(a, D.f[nt][ks], acc[mt][nt]);
+        }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bias[nt] += D.f[nt][ks];
+}
+// this wave's slab of one matrix: [in][out] then the 64 bias sums
+__device__ __forceinline__ void write_slab(float* __restrict__ slab, int lane, const f32x4 (&acc)[4][4], float (&bias)[4]) {
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(16 * mt + 4 * g + r) * 64 + 16 * nt + j] = acc[mt][nt][r];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        float b = bias[nt];
+        b += __shfl_xor(b, 16, 64);
+        b += __shfl_xor(b, 32, 64);
+        if (g == 0) slab[64 * 64 + 16 * nt + j] = b;
+    }
+}
+
+__global__ __launch_bounds__(kDwThreads) void block_bwd_dw_kernel(
+    const float* __restrict__ img_f, const float* __restrict__ img_b, const float* __restrict__ b_in,
+    const float* d_b, float* d_bin, float* __restrict__ slabs, int nwaves_total, int U, int64_t N) {
+    extern __shared__ __align__(16) float lds_img[];
+    float* F = lds_img;
+    float* B = lds_img + qb::BLK_FLOATS;
+    for (int p = threadIdx.x; p < qb::BLK_FLOATS / 4; p += kDwThreads) {
+        reinterpret_cast<float4*>(F)[p] = reinterpret_cast<const float4*>(img_f)[p];
+        reinterpret_cast<float4*>(B)[p] = reinterpret_cast<const float4*>(img_b)[p];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    constexpr int NW = kDwThreads / 64;
+    float* tr = lds_img + 2 * qb::BLK_FLOATS + wave * (16 * kTrStride);
+    const __amdgpu_buffer_rsrc_t o_b = row_buffer(d_bin, N);
+    f32x4 acc_g[4][4], acc_r2[4][4], acc_r1[4][4], acc_c[4][4];
+    float bs_g[4] = {0, 0, 0, 0}, bs_r2[4] = {0, 0, 0, 0}, bs_r1[4] = {0, 0, 0, 0}, bs_c[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc_g[a][c] = f32x4{0, 0, 0, 0};
+            acc_r2[a][c] = f32x4{0, 0, 0, 0};
+            acc_r1[a][c] = f32x4{0, 0, 0, 0};
+            acc_c[a][c] = f32x4{0, 0, 0, 0};
+        }
+    const int64_t ntile = (N + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntile; tile += (int64_t)gridDim.x * NW) {
+        const int64_t v = tile * 16 + i;
+        const bool live = v < N;
+        const uint32_t voff = (uint32_t)(live ? v : N - 1) * 256u + 16u * (uint32_t)g;
+        const uint32_t soff = live ? voff : kDropped;
+        f32x4 b[4], skip[4], t[4], r[4];
+        load_rows(b_in, voff, g, U, b);
+        if (!live) {   // a lane beyond the batch repeats the last voxel for the MFMAs' sake: it must not count twice
+#pragma unroll
+            for (int m = 0; m < 4; ++m) b[m] = f32x4{0, 0, 0, 0};
+        }
+        TileFrags fb, fx, fd;
+        to_frags(tr, lane, b, fb);                                           // b_in, unit on the lane
+        uint32_t m_bin = 0u, m_t = 0u;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m_bin |= b[m][k] > 0.0f ? 1u << (4 * m + k) : 0u;
+        qb::dense64<false>(F + qb::BLK_WC_A, F + qb::BLK_WC_B, b, skip, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            skip[m] = qb::relu4(skip[m]);
+            b[m] = qb::relu4(b[m]);
+        }
+        qb::dense64<false>(F + qb::BLK_R1_A, F + qb::BLK_R1_B, b, t, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            t[m] = qb::relu4(t[m]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m_t |= t[m][k] > 0.0f ? 1u << (4 * m + k) : 0u;
+        }
+        qb::dense64<false>(F + qb::BLK_R2_A, F + qb::BLK_R2_B, t, r, lane);
+        TileFrags ft;
+        to_frags(tr, lane, t, ft);                                           // t
+        to_frags(tr, lane, r, fx);                                           // r
+        qb::dense64<false>(F + qb::BLK_G_A, F + qb::BLK_G_B, r, t, lane);   // gate logits + gate_offset
+        load_rows(d_b, voff, g, U, b);
+        if (!live) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) b[m] = f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gate = qb::sigmoidf_(t[m][k]);
+                const float db = b[m][k], sk = skip[m][k];
+                r[m][k] = db * (r[m][k] - sk) * gate * (1.0f - gate);
+                skip[m][k] = sk > 0.0f ? db * (1.0f - gate) : 0.0f;
+                b[m][k] = db * gate;
+            }
+        }
+        to_frags(tr, lane, r, fd);                                           // d gl
+        dw_accumulate<false>(fx, fd, acc_g, bs_g);                           // dWg += r^T d gl
+        to_frags(tr, lane, skip, fd);                                        // d s'
+        dw_accumulate<false>(fb, fd, acc_c, bs_c);                           // dWc += b_in^T d s'
+        dense64_scaled(B + qb::BLK_G_A, B + qb::BLK_G_B, r, t, lane);        // d gl Wg^T
+#pragma unroll
+        for (int m = 0; m < 4; ++m) b[m] += t[m];                            // d r
+        to_frags(tr, lane, b, fd);
+        dw_accumulate<false>(ft, fd, acc_r2, bs_r2);                         // dWr2 += t^T d r
+        dense64_scaled(B + qb::BLK_R2_A, B + qb::BLK_R2_B, b, t, lane);      // d r Wr2^T
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[m][k] = (m_t >> (4 * m + k)) & 1u ? t[m][k] : 0.0f;
+        to_frags(tr, lane, t, fd);
+        dw_accumulate<true>(fb, fd, acc_r1, bs_r1);                          // dWr1 += relu(b_in)^T d t'
+        dense64_scaled(B + qb::BLK_R1_A, B + qb::BLK_R1_B, t, r, lane);      // d t' Wr1^T
+        dense64_scaled(B + qb::BLK_WC_A, B + qb::BLK_WC_B, skip, b, lane);   // d s' Wc^T
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b[m][k] += (m_bin >> (4 * m + k)) & 1u ? r[m][k] : 0.0f;
+        store_rows(o_b, soff, b);
+    }
+    // slabs: matrix q of wave w at slabs[(q * nwaves_total + w) * (64 * 64 + 64)];  q: 0 Wg, 1 Wr2, 2 Wr1, 3 Wc
+    const int64_t w = (int64_t)blockIdx.x * NW + wave;
+    constexpr int64_t kSlab = 64 * 64 + 64;
+    write_slab(slabs + (0 * (int64_t)nwaves_total + w) * kSlab, lane, acc_g, bs_g);
+    write_slab(slabs + (1 * (int64_t)nwaves_total + w) * kSlab, lane, acc_r2, bs_r2);
+    write_slab(slabs + (2 * (int64_t)nwaves_total + w) * kSlab, lane, acc_r1, bs_r1);
+    write_slab(slabs + (3 * (int64_t)nwaves_total + w) * kSlab, lane, acc_c, bs_c);
+}
+
 // the block matrices of the canonical blob transposed in place of themselves (centre tap of 3x3x1 kernels),
 // everything else zero: packed by qbold_encoder_pack this is the image whose dense64 multiplies by W^T
 __global__ void blob_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, qb::CanonLayout c) {
@@ -1957,6 +2136,32 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             const float* gl = slot(5 + 5 * l);
             const float* b_in = l == 0 ? slot(1) : slot(6 + 5 * (l - 1));
             bool fused_in = false;
+            if (blk_fused && !(ctx->dev.debug_skip & 262144)) {
+                // data side AND the four weight gradients in one launch (block_bwd_dw_kernel), then four slab sums
+                const int64_t ntile = (N + 15) / 16, nb = (ntile + kDwThreads / 64 - 1) / (kDwThreads / 64);
+                const int grid = (int)(nb < ctx->num_cus ? nb : ctx->num_cus);
+                const int nw = grid * (kDwThreads / 64);
+                if (4 * (int64_t)nw <= 8 * (int64_t)kSlabBlocks) {
+                    const size_t smem = sizeof(float) * (2 * qb::BLK_FLOATS + (kDwThreads / 64) * 16 * kTrStride);
+                    QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(block_bwd_dw_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                    hipLaunchKernelGGL(block_bwd_dw_kernel, dim3(grid), dim3(kDwThreads), smem, k.s,
+                                       img_f + el.blk0 + l * el.blk_stride, img_b + el.blk0 + l * el.blk_stride, b_in,
+                                       dB, dB, partial, nw, U, N);
+                    const int ctr = c.taps == 9 ? 4 * U * U : 0;
+                    const int64_t per = (int64_t)nw * (64 * 64 + 64);
+                    const dim3 rg((64 * 64 + 64) / 64);
+                    hipLaunchKernelGGL(slab_reduce_kernel, rg, dim3(1024), 0, k.s, partial, nw, gb + c.Wg, G, U, G,
+                                       gb + c.bg, 0, 0);
+                    hipLaunchKernelGGL(slab_reduce_kernel, rg, dim3(1024), 0, k.s, partial + per, nw,
+                                       gb + c.Wr2 + ctr, U, U, U, gb + c.br2, 0, 0);
+                    hipLaunchKernelGGL(slab_reduce_kernel, rg, dim3(1024), 0, k.s, partial + 2 * per, nw,
+                                       gb + c.Wr1 + ctr, U, U, U, gb + c.br1, 0, 0);
+                    hipLaunchKernelGGL(slab_reduce_kernel, rg, dim3(1024), 0, k.s, partial + 3 * per, nw, gb + c.Wc, U,
+                                       U, U, gb + c.bc, 0, 0);
+                    continue;
+                }
+            }
             if (blk_fused) {   // the block's data side in one launch (block_bwd_kernel), then its four weight gradients
                 const size_t smem = sizeof(float) * 2 * qb::BLK_FLOATS;
                 QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(block_bwd_kernel),
