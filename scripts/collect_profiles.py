@@ -90,7 +90,7 @@ fc = sha("c")
 if fc:
     train = {"workload": "scripts/bench_train.py --only voxel: one fine-tuning step on 1,048,576 voxels ([N][64] float32 "
                          "tensors = 268 MB each)", "source_sha256": fc, "note": NOTE, "kernels": {}}
-    for k in ("block_bwd_kernel", "encoder_train_fwd_kernel", "xtd_kernel", "elbo_bwd_kernel"):
+    for k in ("block_bwd_dw_kernel", "block_bwd_kernel", "encoder_train_fwd_kernel", "xtd_kernel", "elbo_bwd_kernel"):
         f = os.path.join(src, f"{tag}_train_{k}_summary.json")
         if os.path.exists(f):
             s_ = json.load(open(f))

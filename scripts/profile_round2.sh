@@ -47,7 +47,7 @@ elif [ "$PART" = c ]; then
     (cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -- python3 $R/scripts/bench_train.py --only voxel --steps 3 > $D/fetch.log 2>&1) || echo "FAILED fetch"
     (cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -- python3 $R/scripts/bench_train.py --only voxel --steps 3 > $D/write.log 2>&1) || echo "FAILED write"
     cp $D/trace/*/*_kernel_stats.csv $P/r02_train_step_kernel_stats.csv
-    for k in block_bwd_kernel encoder_train_fwd_kernel xtd_kernel elbo_bwd_kernel; do
+    for k in block_bwd_dw_kernel block_bwd_kernel encoder_train_fwd_kernel xtd_kernel elbo_bwd_kernel; do
         python3 scripts/summarise_prof.py $D $k > $P/r02_train_${k}_summary.json
     done
     python3 scripts/bench_train.py > $P/r02_train_step.json 2> $G/r02_train.err; cat $P/r02_train_step.json
