@@ -383,3 +383,23 @@ def test_hand_placed_lds_reads_are_not_touched_before_their_wait(tmp_path):
                                   "s_waitcnt vmcnt(%d)\\1" % (n + 1), text))
             r = subprocess.run([sys.executable, chk, str(bad), key], capture_output=True, text=True)
             assert r.returncode == 1 and "still has" in r.stdout, (n, r.stdout[-500:])
+
+
+def test_training_backward_says_when_it_recomputes(params):
+    """qbold_encoder_train_bwd_recomputes is the one predicate both sides of the training step use: the one-launch
+    forward leaves out skip and the gate logits only where the backward will recompute them."""
+    from qbold_vi_amd import _lib
+    from qbold_vi_amd.ops import Context
+    lib = _lib.load()
+    ctx = Context(params, host_only=True)
+    yes = _lib.EncoderShape(11, 60, 2, 1, -3.0, 9)
+    assert lib.qbold_encoder_train_bwd_recomputes(ctx.handle, C.byref(yes), 1 << 20) == 1
+    assert lib.qbold_encoder_train_bwd_recomputes(ctx.handle, C.byref(yes), 1 << 23) == 0      # 32-bit row offsets
+    assert lib.qbold_encoder_train_bwd_recomputes(ctx.handle, C.byref(yes), 0) == 0
+    for shape in (_lib.EncoderShape(11, 256, 2, 1, -3.0, 1),      # wide: layer-wise kernels
+                  _lib.EncoderShape(11, 60, 3, 1, -3.0, 1),       # three blocks: not an LDS-resident shape
+                  _lib.EncoderShape(11, 60, 2, 0, -3.0, 1),       # shared gate
+                  _lib.EncoderShape(24, 60, 2, 1, -3.0, 1),       # another protocol than the context's
+                  _lib.EncoderShape(11, 60, 2, 1, -3.0, 1, 1)):   # bf16 encoder mode
+        assert lib.qbold_encoder_train_bwd_recomputes(ctx.handle, C.byref(shape), 1 << 20) == 0
+    assert lib.qbold_encoder_train_bwd_recomputes(None, C.byref(yes), 1 << 20) == 0
