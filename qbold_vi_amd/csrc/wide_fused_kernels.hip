@@ -599,7 +599,7 @@ __device__ __forceinline__ void load_x(const FusedArgs& a, int64_t v, int h, XRa
     for (int s = 0; s < KS1; ++s) {
         const int t0 = 16 * s + 8 * h;
         if (V4 || ((a.T & 3) == 0 && a.T >= 8)) {  // wave-uniform; V4 (four k-steps, T % 4 == 0): known here
-            const int tc = t0 + 8 <= a.T ? t0 : a.T - 8;  // clamped: values past the row are masked in convert_x
+            const int tc = t0 + 8 <= a.T ? t0 : a.T - 8;  // clamped: convert_x picks the row's tail out of the window
 #ifdef QB_FUSED_X_NT
             const float4 lo4 = __builtin_nontemporal_load(reinterpret_cast<const float4*>(xv + tc));
             const float4 hi4 = __builtin_nontemporal_load(reinterpret_cast<const float4*>(xv + tc + 4));
@@ -625,11 +625,15 @@ __device__ __forceinline__ void convert_x(const FusedArgs& a, int h, const XRaw<
 #pragma unroll
     for (int s = 0; s < KS1; ++s) {
         const int t0 = 16 * s + 8 * h;
-        const bool whole = !wide_rows || t0 + 8 <= a.T;  // else the clamped load fetched other taus
+        // a window that would cross the end of the row was fetched from T - 8 instead (load_x): with T % 4 == 0
+        // and t0 % 8 == 0 the row's last four taus then sit in the window's upper half
+        const bool shifted = wide_rows && t0 + 8 > a.T;
         float f[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)  // v_log_f32 as the LDS-resident kernels (encoder_core.h normalise)
-            f[j] = (whole && t0 + j < a.T) ? QB_LN2 * qb::log2f_(qb::clampf_(xr.f[s][j], 1e-2f, 1e8f) * inv_den) : 0.0f;
+        for (int j = 0; j < 8; ++j) {  // v_log_f32 as the LDS-resident kernels (encoder_core.h normalise)
+            const float raw = shifted ? xr.f[s][(j + 4) & 7] : xr.f[s][j];
+            f[j] = t0 + j < a.T ? QB_LN2 * qb::log2f_(qb::clampf_(raw, 1e-2f, 1e8f) * inv_den) : 0.0f;
+        }
 #pragma unroll
         for (int d = 0; d < 4; ++d) split_pair(f[2 * d], f[2 * d + 1], X.hi[s][d], X.lo[s][d], amax);
     }

@@ -874,3 +874,32 @@ def test_split_operand_range(ctx, weights, oracle32):
     assert np.isfinite(sums).all()
     # absolute resolution 2^-35 per operand, 60 terms, x 2e4 head weights: a few 1e-5 on an O(1) head output
     assert np.max(np.abs(q - q_want)) < 2e-4
+
+
+@pytest.mark.parametrize("T", [49, 50, 52, 60, 63, 12, 16])
+def test_one_launch_wide_encoder_on_partly_filled_tau_tiles(params, T):
+    """The one-launch wide encoder on tau counts that fill their tiles only partly: 49..63 taus (four first-layer
+    k-steps whose last is partly padding, two log-sigma tiles whose second holds T - 32 live rows) and 12 / 16 (one
+    k-step).  T % 4 != 0 takes the dword head stores and scalar signal loads; T % 4 == 0 the 16-byte forms with
+    their per-handshake vmcnt allowances, and with T % 8 == 4 the signal window that is fetched from T - 8 and
+    picked apart in convert_x (a round-2 bug: the row's last four taus used to be dropped).  Heads against the
+    oracle, ragged voxel counts around the 128-voxel pass."""
+    from oracle.oracle import Oracle, init_weights
+    from qbold_vi_amd.ops import Context, EncoderWeights
+    p = dict(params, tau_start="-0.010", tau_end=str(-0.010 + 0.001 * T - 0.0005), tau_step="0.001")
+    orc = Oracle("f32", p)
+    ctx = Context(p, True, True)
+    assert ctx.T == orc.T == T and ctx.se_idx == 10
+    w = init_weights(T=T, U=256, L=2, seed=T)
+    rng = np.random.default_rng(T)
+    for nm in ("b0", "bc", "br1", "br2", "bg", "bf", "bs"):
+        w[nm] = (w[nm] + 0.1 * rng.standard_normal(w[nm].shape)).astype(np.float32)
+    w["gate_offset"] = -3.0
+    ew = EncoderWeights(ctx, T, 256, 2, True, -3.0).set_from_arrays(w)
+    assert ew.fused_wide
+    for n in (1, 127, 130, 517):
+        x = rng.uniform(0.2, 1.0, (n, T)).astype(np.float32)
+        _, q_want, sg_want = orc.encoder_fwd(w, x)
+        _, q, sg = ctx.encoder_fwd(ew, torch.as_tensor(x, device="cuda"), want=("out2", "sigma"))
+        assert np.abs(q.cpu().numpy() - q_want).max() < 5e-5, (T, n)
+        assert (np.abs(sg.cpu().numpy() - sg_want) / sg_want).max() < 5e-5, (T, n)
