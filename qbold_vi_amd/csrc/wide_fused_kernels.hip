@@ -599,13 +599,16 @@ __device__ __forceinline__ void load_x(const FusedArgs& a, int64_t v, int h, XRa
     for (int s = 0; s < KS1; ++s) {
         const int t0 = 16 * s + 8 * h;
         if (V4 || ((a.T & 3) == 0 && a.T >= 8)) {  // wave-uniform; V4 (four k-steps, T % 4 == 0): known here
-            const int tc = t0 + 8 <= a.T ? t0 : a.T - 8;  // clamped: convert_x picks the row's tail out of the window
+            // each 16-byte half clamped into the row on its own: a half that starts inside the row is fetched from its
+            // own address (T % 4 == 0: it then lies wholly inside), one beyond it fetches the row's last four taus and
+            // is masked in convert_x -- no window ever has to be picked apart
+            const int tl = t0 <= a.T - 4 ? t0 : a.T - 4, th = t0 + 4 <= a.T - 4 ? t0 + 4 : a.T - 4;
 #ifdef QB_FUSED_X_NT
-            const float4 lo4 = __builtin_nontemporal_load(reinterpret_cast<const float4*>(xv + tc));
-            const float4 hi4 = __builtin_nontemporal_load(reinterpret_cast<const float4*>(xv + tc + 4));
+            const float4 lo4 = __builtin_nontemporal_load(reinterpret_cast<const float4*>(xv + tl));
+            const float4 hi4 = __builtin_nontemporal_load(reinterpret_cast<const float4*>(xv + th));
 #else
-            const float4 lo4 = *reinterpret_cast<const float4*>(xv + tc);
-            const float4 hi4 = *reinterpret_cast<const float4*>(xv + tc + 4);
+            const float4 lo4 = *reinterpret_cast<const float4*>(xv + tl);
+            const float4 hi4 = *reinterpret_cast<const float4*>(xv + th);
 #endif
             xr.f[s][0] = lo4.x; xr.f[s][1] = lo4.y; xr.f[s][2] = lo4.z; xr.f[s][3] = lo4.w;
             xr.f[s][4] = hi4.x; xr.f[s][5] = hi4.y; xr.f[s][6] = hi4.z; xr.f[s][7] = hi4.w;
@@ -620,20 +623,15 @@ template <int KS1>
 __device__ __forceinline__ void convert_x(const FusedArgs& a, int h, const XRaw<KS1>& xr, Panel<KS1>& X, float& amax) {
     float den = qb::clampf_(xr.d[1], 1e-2f, 1e8f);
     if (a.multi_norm) den = (qb::clampf_(xr.d[0], 1e-2f, 1e8f) + den + qb::clampf_(xr.d[2], 1e-2f, 1e8f)) / 3.0f;
-    const bool wide_rows = (a.T & 3) == 0 && a.T >= 8;
     const float inv_den = 1.0f / den;
 #pragma unroll
     for (int s = 0; s < KS1; ++s) {
         const int t0 = 16 * s + 8 * h;
-        // a window that would cross the end of the row was fetched from T - 8 instead (load_x): with T % 4 == 0
-        // and t0 % 8 == 0 the row's last four taus then sit in the window's upper half
-        const bool shifted = wide_rows && t0 + 8 > a.T;
         float f[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {  // v_log_f32 as the LDS-resident kernels (encoder_core.h normalise)
-            const float raw = shifted ? xr.f[s][(j + 4) & 7] : xr.f[s][j];
-            f[j] = t0 + j < a.T ? QB_LN2 * qb::log2f_(qb::clampf_(raw, 1e-2f, 1e8f) * inv_den) : 0.0f;
-        }
+        for (int j = 0; j < 8; ++j)  // v_log_f32 as the LDS-resident kernels (encoder_core.h normalise); taus beyond the
+                                     // row (whatever load_x fetched for them) are zero
+            f[j] = t0 + j < a.T ? QB_LN2 * qb::log2f_(qb::clampf_(xr.f[s][j], 1e-2f, 1e8f) * inv_den) : 0.0f;
 #pragma unroll
         for (int d = 0; d < 4; ++d) split_pair(f[2 * d], f[2 * d + 1], X.hi[s][d], X.lo[s][d], amax);
     }
