@@ -336,15 +336,16 @@ int qbold_encoder_train_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
 /* stream_sel = 2 of the call above in ONE launch for the shapes of the LDS-resident kernels (U <= 64, L <= 2,
  * T = 11 or 24, channel-wise gating, QBOLD_ENC_F32; 0 < N < 2^23): `packed` is the image of
  * qbold_encoder_pack; the workspace receives the same saved tensors, so qbold_encoder_train_bwd follows
- * unchanged.  save_all = 0 leaves out the two tensors per block (skip, gate logits) that qbold_encoder_train_bwd
- * recomputes when qbold_encoder_train_bwd_recomputes(ctx, shape, N) is 1 -- pass that function's result negated,
- * or 1.  Products are the float32-grade split-f16 ones of qbold_encoder_fwd (operand range above: heads come out
- * NaN beyond it), not the exact-f32 GEMMs of qbold_encoder_train_fwd. */
+ * unchanged.  save_all = 2 saves every tensor; 1 leaves out the two per block (skip, gate logits) and 0 the four
+ * per block (also t, r) that qbold_encoder_train_bwd recomputes -- pass 2 - qbold_encoder_train_bwd_recomputes(ctx,
+ * shape, N), or 2.  Products are the float32-grade split-f16 ones of qbold_encoder_fwd (operand range above: heads
+ * come out NaN beyond it), not the exact-f32 GEMMs of qbold_encoder_train_fwd. */
 int qbold_encoder_train_fwd_fused(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* packed,
                                   const float* x, int save_all, float* workspace, float* out_q,
                                   float* out_log_sigma, int64_t N, void* stream);
-/* 1 if qbold_encoder_train_bwd (stream 2, voxel batch) runs each gated block's data side in one launch that
- * recomputes the block from its input (so skip and the gate logits need not have been saved), else 0. */
+/* What qbold_encoder_train_bwd (stream 2, voxel batch) recomputes from each gated block's input instead of
+ * reading it: 0 nothing (the layer-wise backward), 1 skip and the gate logits (one launch per block for the data
+ * side), 2 also t and r (the same launch accumulates the block's weight gradients). */
 int qbold_encoder_train_bwd_recomputes(const qbold_ctx* ctx, const qbold_encoder_shape* shape, int64_t N);
 /* The same on image crops: geom->B*X*Y*Z voxels, stream 2 with its 3x3x1 'same' convolutions
  * (shape->spatial_taps must be 9).  geom = NULL is the voxel-batch call above. */

@@ -200,9 +200,21 @@ __device__ __forceinline__ void save_rows(float* __restrict__ slot, uint32_t vof
         *reinterpret_cast<float4*>(sb + voff + 64 * m) = make_float4(a[m][0], a[m][1], a[m][2], a[m][3]);
 }
 
-// SAVE_ALL = false leaves out skip and the gate logits, which the one-launch block backward (train_kernels.hip,
-// block_bwd_kernel) recomputes: eight tensors instead of twelve.
-template <int T, int NL, bool SAVE_ALL>
+// The same four store instructions into a buffer resource of zero records: the hardware's range check drops them,
+// nothing reaches memory.  Why issue them at all: with the stores of t and r simply removed (SAVE = 0) the compiler
+// merges the block's stages and the 128-VGPR kernel spills 200 bytes per lane -- 0.66 ms against 0.58 ms WITH the
+// stores; scheduling and memory barriers in their place did not change that, stores nobody receives do.
+typedef uint32_t u32x4e __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void drop_rows(__amdgpu_buffer_rsrc_t nowhere, const f32x4 (&a)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4e, a[m]), nowhere, 64u * m, 0, 0);
+}
+
+// SAVE: 2 = every tensor; 1 leaves out skip and the gate logits, which block_bwd_kernel (train_kernels.hip)
+// recomputes: eight tensors instead of twelve; 0 leaves out t and r as well, which block_bwd_dw_kernel also
+// recomputes (its weight gradients read them from registers): n, h and each block's output, four tensors.
+template <int T, int NL, int SAVE>
 __global__ __launch_bounds__(kEncBlock) void encoder_train_fwd_kernel(
     QbDev c, const float* __restrict__ packed, const float* __restrict__ x, float gate_offset,
     float* __restrict__ ws, float* __restrict__ out_q, float* __restrict__ out_ls, int64_t N) {
@@ -219,6 +231,7 @@ __global__ __launch_bounds__(kEncBlock) void encoder_train_fwd_kernel(
     constexpr int NW = kEncBlock / 64;
     const int64_t ntile = (N + 15) / 16;
     const int64_t slot_floats = N * 64;
+    const __amdgpu_buffer_rsrc_t nowhere = __builtin_amdgcn_make_buffer_rsrc(ws, 0, 0, 0x00020000);
     for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntile; tile += (int64_t)gridDim.x * NW) {
         const int64_t v = tile * 16 + i;
         const bool live = v < N;
@@ -247,13 +260,15 @@ __global__ __launch_bounds__(kEncBlock) void encoder_train_fwd_kernel(
                 skip[m] = qb::relu4(skip[m]);
                 b[m] = qb::relu4(b[m]);
             }
-            if constexpr (SAVE_ALL) save_rows(base, voff, skip);
+            if constexpr (SAVE >= 2) save_rows(base, voff, skip);
             qb::dense64<false>(W + qb::BLK_R1_A, W + qb::BLK_R1_B, b, t, lane);
 #pragma unroll
             for (int m = 0; m < 4; ++m) t[m] = qb::relu4(t[m]);
-            save_rows(base + slot_floats, voff, t);
+            if constexpr (SAVE >= 1) save_rows(base + slot_floats, voff, t);
+            else drop_rows(nowhere, t);   // (see drop_rows)
             qb::dense64<false>(W + qb::BLK_R2_A, W + qb::BLK_R2_B, t, r, lane, &amax);
-            save_rows(base + 2 * slot_floats, voff, r);
+            if constexpr (SAVE >= 1) save_rows(base + 2 * slot_floats, voff, r);
+            else drop_rows(nowhere, r);
             qb::dense64<false>(W + qb::BLK_G_A, W + qb::BLK_G_B, r, t, lane, &amax);  // logits + gate_offset
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -261,10 +276,10 @@ __global__ __launch_bounds__(kEncBlock) void encoder_train_fwd_kernel(
                 for (int k = 0; k < 4; ++k) {
                     const float gate = qb::sigmoidf_(t[m][k]);
                     b[m][k] = skip[m][k] * (1.0f - gate) + r[m][k] * gate;
-                    if constexpr (SAVE_ALL) t[m][k] -= gate_offset;
+                    if constexpr (SAVE >= 2) t[m][k] -= gate_offset;
                 }
             }
-            if constexpr (SAVE_ALL) save_rows(base + 3 * slot_floats, voff, t);
+            if constexpr (SAVE >= 2) save_rows(base + 3 * slot_floats, voff, t);
             save_rows(base + 4 * slot_floats, voff, b);
         }
         f32x4 hd[HT];
@@ -389,7 +404,8 @@ extern "C" int qbold_encoder_train_fwd_fused(const qbold_ctx* ctx, const qbold_e
     const int grid = (int)(nblk < ctx->num_cus ? nblk : ctx->num_cus);
 #define QB_LAUNCH_TRAIN_FWD(TT, NL)                                                                  \
     do {                                                                                             \
-        auto k = save_all ? encoder_train_fwd_kernel<TT, NL, true> : encoder_train_fwd_kernel<TT, NL, false>; \
+        auto k = save_all >= 2 ? encoder_train_fwd_kernel<TT, NL, 2>                                         \
+                 : save_all == 1 ? encoder_train_fwd_kernel<TT, NL, 1> : encoder_train_fwd_kernel<TT, NL, 0>; \
         QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                 \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));          \
         hipLaunchKernelGGL(k, dim3(grid), dim3(kEncBlock), smem, (hipStream_t)stream, ctx->dev,      \

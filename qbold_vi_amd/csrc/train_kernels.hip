@@ -2032,8 +2032,17 @@ static bool block_bwd_applies(const qbold_ctx* ctx, const qbold_encoder_shape* s
            s->T == ctx->dev.T && s->precision == QBOLD_ENC_F32 && N > 0 && N < ((int64_t)1 << 23) &&
            !(ctx->dev.debug_skip & 131072);
 }
+// ... and the one under which the block kernel also accumulates the weight gradients (block_bwd_dw_kernel)
+static int dw_grid(const qbold_ctx* ctx, int64_t N) {
+    const int64_t ntile = (N + 15) / 16, nb = (ntile + kDwThreads / 64 - 1) / (kDwThreads / 64);
+    return (int)(nb < ctx->num_cus ? nb : ctx->num_cus);
+}
+static bool block_bwd_dw_applies(const qbold_ctx* ctx, const qbold_encoder_shape* s, int64_t N) {
+    return block_bwd_applies(ctx, s, N) && !(ctx->dev.debug_skip & 262144) &&
+           4 * (int64_t)dw_grid(ctx, N) * (kDwThreads / 64) <= 8 * (int64_t)kSlabBlocks;
+}
 extern "C" int qbold_encoder_train_bwd_recomputes(const qbold_ctx* ctx, const qbold_encoder_shape* shape, int64_t N) {
-    return block_bwd_applies(ctx, shape, N) ? 1 : 0;
+    return block_bwd_dw_applies(ctx, shape, N) ? 2 : (block_bwd_applies(ctx, shape, N) ? 1 : 0);
 }
 
 // g_head_q [N][5], g_head_ls [N][T] (stream 2 only; may be NULL), sums: device double[3] whose
@@ -2138,12 +2147,11 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             const float* gl = slot(5 + 5 * l);
             const float* b_in = l == 0 ? slot(1) : slot(6 + 5 * (l - 1));
             bool fused_in = false;
-            if (blk_fused && !(ctx->dev.debug_skip & 262144)) {
+            if (blk_fused && block_bwd_dw_applies(ctx, shape, N)) {
                 // data side AND the four weight gradients in one launch (block_bwd_dw_kernel), then four slab sums
-                const int64_t ntile = (N + 15) / 16, nb = (ntile + kDwThreads / 64 - 1) / (kDwThreads / 64);
-                const int grid = (int)(nb < ctx->num_cus ? nb : ctx->num_cus);
+                const int grid = dw_grid(ctx, N);
                 const int nw = grid * (kDwThreads / 64);
-                if (4 * (int64_t)nw <= 8 * (int64_t)kSlabBlocks) {
+                {
                     const size_t smem = sizeof(float) * (2 * qb::BLK_FLOATS + (kDwThreads / 64) * 16 * kTrStride);
                     QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(block_bwd_dw_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -704,8 +704,8 @@ class TrainState:
         if (stream_sel == 2 and self.fused_forward and Context.fits_fused(sh) and sh.channelwise_gating
                 and sh.precision == 0 and 0 < N < (1 << 23)):
             # one launch, every saved tensor written once (encoder_kernels.hip, encoder_train_fwd_kernel); the two
-            # tensors per block that the backward recomputes are left out when it says it will
-            save_all = 0 if ctx.lib.qbold_encoder_train_bwd_recomputes(ctx.handle, C.byref(sh), N) == 1 else 1
+            # tensors per block that the backward will recompute (it says which) are left out
+            save_all = 2 - max(0, min(2, int(ctx.lib.qbold_encoder_train_bwd_recomputes(ctx.handle, C.byref(sh), N))))
             _lib.check(ctx.lib.qbold_encoder_train_fwd_fused(ctx.handle, C.byref(sh), self.weights.packed_ptr(),
                                                              _ptr(x), save_all, _ptr(self.workspace(N)), _ptr(q),
                                                              _ptr(ls), N, _stream()), "qbold_encoder_train_fwd_fused")

@@ -387,13 +387,13 @@ def test_hand_placed_lds_reads_are_not_touched_before_their_wait(tmp_path):
 
 def test_training_backward_says_when_it_recomputes(params):
     """qbold_encoder_train_bwd_recomputes is the one predicate both sides of the training step use: the one-launch
-    forward leaves out skip and the gate logits only where the backward will recompute them."""
+    forward leaves out exactly what the backward says it will recompute (2: skip, gate logits, t and r)."""
     from qbold_vi_amd import _lib
     from qbold_vi_amd.ops import Context
     lib = _lib.load()
     ctx = Context(params, host_only=True)
     yes = _lib.EncoderShape(11, 60, 2, 1, -3.0, 9)
-    assert lib.qbold_encoder_train_bwd_recomputes(ctx.handle, C.byref(yes), 1 << 20) == 1
+    assert lib.qbold_encoder_train_bwd_recomputes(ctx.handle, C.byref(yes), 1 << 20) == 2
     assert lib.qbold_encoder_train_bwd_recomputes(ctx.handle, C.byref(yes), 1 << 23) == 0      # 32-bit row offsets
     assert lib.qbold_encoder_train_bwd_recomputes(ctx.handle, C.byref(yes), 0) == 0
     for shape in (_lib.EncoderShape(11, 256, 2, 1, -3.0, 1),      # wide: layer-wise kernels
