@@ -1456,6 +1456,33 @@ __global__ __launch_bounds__(kBlkThreads) void block_bwd_kernel(
 }
 
 
+// slab_reduce_kernel for many slabs (one per wave of block_bwd_dw_kernel: 1,024): 16 elements x 64 interleaved
+// parts per workgroup, so that 260 workgroups share the 17 MB instead of 66; parts added in a fixed order.
+__global__ __launch_bounds__(1024) void slab_reduce_many_kernel(const float* __restrict__ partial, int nblk,
+                                                                 float* __restrict__ dW, int ldw, int kdim, int ndim,
+                                                                 float* __restrict__ db) {
+    constexpr int kParts = 64, kElems = 16, kSlab = 64 * 64 + 64;
+    __shared__ double part[kParts][kElems];
+    const int le = threadIdx.x & (kElems - 1), p = threadIdx.x / kElems;
+    const int e = blockIdx.x * kElems + le;
+    double a = 0.0;
+    if (e < kSlab)
+        for (int bk = p; bk < nblk; bk += kParts) a += (double)partial[(int64_t)bk * kSlab + e];
+    part[p][le] = a;
+    __syncthreads();
+    if (p != 0 || e >= kSlab) return;
+    a = 0.0;
+#pragma unroll 8
+    for (int q = 0; q < kParts; ++q) a += part[q][le];
+    if (e < 64 * 64) {
+        const int i = e >> 6, j = e & 63;
+        if (i < kdim && j < ndim) dW[i * ldw + j] = (float)a;
+    } else {
+        const int j = e - 64 * 64;
+        if (db && j < ndim) db[j] = (float)a;
+    }
+}
+
 // ---- the same with the block's four weight gradients accumulated in the kernel ----------------------------
 // block_bwd_kernel still hands its four deltas to four xtd_kernel launches, which re-read each delta and its
 // activation from HBM (0.5 ms per block on 1 M voxels).  Here a wave keeps the four 64 x 64 float32 gradient
@@ -2160,15 +2187,15 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                                        dB, dB, partial, nw, U, N);
                     const int ctr = c.taps == 9 ? 4 * U * U : 0;
                     const int64_t per = (int64_t)nw * (64 * 64 + 64);
-                    const dim3 rg((64 * 64 + 64) / 64);
-                    hipLaunchKernelGGL(slab_reduce_kernel, rg, dim3(1024), 0, k.s, partial, nw, gb + c.Wg, G, U, G,
-                                       gb + c.bg, 0, 0);
-                    hipLaunchKernelGGL(slab_reduce_kernel, rg, dim3(1024), 0, k.s, partial + per, nw,
-                                       gb + c.Wr2 + ctr, U, U, U, gb + c.br2, 0, 0);
-                    hipLaunchKernelGGL(slab_reduce_kernel, rg, dim3(1024), 0, k.s, partial + 2 * per, nw,
-                                       gb + c.Wr1 + ctr, U, U, U, gb + c.br1, 0, 0);
-                    hipLaunchKernelGGL(slab_reduce_kernel, rg, dim3(1024), 0, k.s, partial + 3 * per, nw, gb + c.Wc, U,
-                                       U, U, gb + c.bc, 0, 0);
+                    const dim3 rg((64 * 64 + 64) / 16);
+                    hipLaunchKernelGGL(slab_reduce_many_kernel, rg, dim3(1024), 0, k.s, partial, nw, gb + c.Wg, G, U, G,
+                                       gb + c.bg);
+                    hipLaunchKernelGGL(slab_reduce_many_kernel, rg, dim3(1024), 0, k.s, partial + per, nw,
+                                       gb + c.Wr2 + ctr, U, U, U, gb + c.br2);
+                    hipLaunchKernelGGL(slab_reduce_many_kernel, rg, dim3(1024), 0, k.s, partial + 2 * per, nw,
+                                       gb + c.Wr1 + ctr, U, U, U, gb + c.br1);
+                    hipLaunchKernelGGL(slab_reduce_many_kernel, rg, dim3(1024), 0, k.s, partial + 3 * per, nw, gb + c.Wc, U,
+                                       U, U, gb + c.bc);
                     continue;
                 }
             }
