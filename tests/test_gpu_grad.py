@@ -502,8 +502,8 @@ def test_learned_inverse_gamma_hyper_prior(params):
         EncoderTrainer(params, activation_type='relu', use_mvg=True, infer_inv_gamma=True, use_population_prior=False)
 
 
-@pytest.mark.parametrize("T,L", [(11, 2), (11, 1), (24, 2)])
-def test_one_launch_training_forward_and_block_backward(params, T, L, monkeypatch):
+@pytest.mark.parametrize("T,L,taps", [(11, 2, 1), (11, 1, 1), (24, 2, 1), (11, 2, 9)])
+def test_one_launch_training_forward_and_block_backward(params, T, L, taps, monkeypatch):
     """Voxel batches of the LDS-resident shapes train through two fused kernels: qbold_encoder_train_fwd_fused
     (stream 2 forward, every saved tensor written once) and block_bwd_kernel (a gated block's data-side backward
     in one launch: block recomputed, deltas scaled per voxel into the f16 split's range).  Against the layer-wise
@@ -516,7 +516,8 @@ def test_one_launch_training_forward_and_block_backward(params, T, L, monkeypatc
     if T == 24:
         p.update(tau_start="-0.028", tau_end="0.065", tau_step="0.004")
     U, N = 60, 16 * 37 + 5
-    w = init_encoder_weights(T=T, U=U, L=L, channelwise_gating=True, resid_init_std=0.3, im_loss_sigma=0.05, seed=4)
+    w = init_encoder_weights(T=T, U=U, L=L, channelwise_gating=True, resid_init_std=0.3, im_loss_sigma=0.05, seed=4,
+                             spatial_taps=taps)      # 9: Keras 3x3x1 kernels, of which a voxel batch sees the centre tap
     rng = np.random.default_rng(11)
     x = torch.as_tensor(rng.uniform(0.2, 1.0, (N, T)).astype(np.float32), device="cuda")
     scale = np.exp(rng.uniform(np.log(1e-9), np.log(1e-4), (N, 1)))      # per-voxel magnitudes over five decades
@@ -530,7 +531,7 @@ def test_one_launch_training_forward_and_block_backward(params, T, L, monkeypatc
             monkeypatch.setenv("QBOLD_DEBUG_SKIP", "131072")
             monkeypatch.setenv("QBOLD_ALLOW_ABLATION", "1")
         ctx = Context(p, True, True)
-        ew = EncoderWeights(ctx, T, U, L, True, -3.0).set_from_arrays(w)
+        ew = EncoderWeights(ctx, T, U, L, True, -3.0, spatial_taps=taps).set_from_arrays(w)
         st = TrainState(ctx, ew)
         st.fused_forward = fused
         st.workspace(N).fill_(float("nan"))      # whatever the backward reads must have been written
