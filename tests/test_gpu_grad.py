@@ -558,3 +558,43 @@ def test_one_launch_training_forward_and_block_backward(params, T, L, taps, monk
             a, b = g0[off:off + cnt], g1[off:off + cnt]
             assert (a - b).abs().max() <= 2e-4 * float(a.abs().max()) + 1e-30, \
                 (name, l, float((a - b).abs().max()), float(a.abs().max()))
+
+
+def test_fused_training_kernels_over_widths_and_batch_sizes(params, monkeypatch):
+    """The fused training kernels against the layer-wise exact-f32 path over widths that pad the 64-unit tiles
+    differently (8 .. 64), one and two blocks, and batch sizes from a single voxel to several workgroups' worth."""
+    from qbold_vi_amd.init import init_encoder_weights
+    from qbold_vi_amd.ops import Context, EncoderWeights, TrainState
+    rng = np.random.default_rng(2024)
+    cases = [(8, 1, 1), (16, 2, 17), (33, 2, 64), (48, 1, 255), (49, 2, 256), (60, 2, 4097), (64, 2, 1000), (64, 1, 16)]
+    for U, L, N in cases:
+        w = init_encoder_weights(T=11, U=U, L=L, channelwise_gating=True, resid_init_std=0.3, im_loss_sigma=0.05,
+                                 seed=U + L)
+        x = torch.as_tensor(rng.uniform(0.2, 1.0, (N, 11)).astype(np.float32), device="cuda")
+        g_q = torch.as_tensor((rng.normal(size=(N, 5)) / N).astype(np.float32), device="cuda")
+        g_ls = torch.as_tensor((rng.normal(size=(N, 11)) / N).astype(np.float32), device="cuda")
+        out = {}
+        for fused in (False, True):
+            if fused:
+                monkeypatch.delenv("QBOLD_DEBUG_SKIP", raising=False)
+            else:
+                monkeypatch.setenv("QBOLD_DEBUG_SKIP", "131072")
+                monkeypatch.setenv("QBOLD_ALLOW_ABLATION", "1")
+            ctx = Context(params, True, True)
+            ew = EncoderWeights(ctx, 11, U, L, True, -3.0).set_from_arrays(w)
+            st = TrainState(ctx, ew)
+            st.fused_forward = fused
+            st.workspace(N).fill_(float("nan"))
+            q, ls = st.forward(x, 2)
+            out[fused] = (q.clone(), ls.clone(), st.backward(2, g_q, g_ls).clone())
+        monkeypatch.delenv("QBOLD_DEBUG_SKIP", raising=False)
+        (q0, ls0, g0), (q1, ls1, g1) = out[False], out[True]
+        assert torch.isfinite(g1).all(), (U, L, N)
+        assert (q1 - q0).abs().max() < 1e-5 * max(1.0, float(q0.abs().max())), (U, L, N)
+        assert (ls1 - ls0).abs().max() < 1e-5 * max(1.0, float(ls0.abs().max())), (U, L, N)
+        for name, pieces in ew._slices().items():
+            for l, (off, shape) in enumerate(pieces):
+                cnt = int(np.prod(shape))
+                a, b = g0[off:off + cnt], g1[off:off + cnt]
+                assert (a - b).abs().max() <= 3e-4 * float(a.abs().max()) + 1e-30, \
+                    (U, L, N, name, l, float((a - b).abs().max()), float(a.abs().max()))
