@@ -284,6 +284,252 @@ def rehearse_launch(args, world, rank):
         dist.destroy_process_group()
 
 
+class Spec:
+    """One workload of the bench: which BASELINE configuration, how many voxels, which encoder arithmetic."""
+
+    def __init__(self, config=2, protocol=11, voxels=1 << 20, encoder_precision="f32", tissue="table", exact=False):
+        self.config, self.protocol, self.voxels = config, protocol, voxels
+        self.encoder_precision, self.tissue, self.exact = encoder_precision, tissue, exact
+
+
+def run_workload(spec, args, steps, warmup, rank, device, use_pg, world, S, K):
+    """Builds the workload's inputs in HBM, ramps the clocks, runs `warmup` untimed and `steps` timed steps
+    (barrier + device synchronise on both sides), and returns the measurements of THIS rank plus what the
+    roofline objects need.  One step = one pass of the hot path over the whole batch."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+    from qbold_vi_amd import _lib
+    from qbold_vi_amd.init import init_encoder_weights
+    from qbold_vi_amd.ops import EncoderWeights, _ptr, _stream
+
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(ROOT, "config"))
+    params = dict(cfg["DEFAULT"])
+    T, U, L = 11, 60, 2  # configurations/optimal.yaml
+    if spec.config == 3:  # SURVEY H6: 64 taus from -0.015 s in 1.25 ms steps (se_idx 12), width 256
+        params.update(tau_start="-0.015", tau_end="0.065", tau_step="0.00125")
+        T, U = 64, 256
+    elif spec.protocol == 24:
+        params.update(tau_start="-0.028", tau_end="0.065", tau_step="0.004")
+        T = 24
+    n = spec.voxels
+    ctx, x = make_inputs(n, params, seed=1 + rank, device=device)
+    ctx.set_tissue_mode(spec.tissue)
+    w = init_encoder_weights(T=T, U=U, L=L, channelwise_gating=True, resid_init_std=0.05,
+                             im_loss_sigma=0.05, seed=1)
+    if spec.encoder_precision == "bf16" and spec.config != 2:
+        raise SystemExit("--encoder_precision bf16 applies to the fused kernel (config 2)")
+    ew = EncoderWeights(ctx, T, U, L, True, -3.0, precision=spec.encoder_precision).set_from_arrays(w)
+    mask = torch.ones(n, device=device)
+    prior, _, _ = ctx.encoder_fwd(ew, x, want=("out1",))  # prior = stream-1 output (train.py:26-31)
+    q_buf, nk_buf = torch.empty((n, 5), device=device), torch.empty((n, 2), device=device)
+    # The three masked sums of every step are all-reduced (RCCL over xGMI).  A ring of result buffers
+    # lets step k+1's kernel run while step k's 24-byte all-reduce is in flight on RCCL's stream: the
+    # reduced ELBO is consumed a few steps later, as a training loop consumes its loss (SURVEY 8e).
+    RING = 4
+    outs = [(torch.empty(3, dtype=torch.float64, device=device), q_buf, nk_buf) for _ in range(RING)]
+    pending = [None] * RING
+    voxel0 = rank * n
+
+    # Config 3 runs as two launches (the one-launch wide encoder, then the ELBO kernel on its heads): the bench
+    # issues them through the two C entry points qbold_vi_fwd itself chains, with an event between them, so that
+    # the dominant kernel's duration is measured live in the timed region.
+    two_launch = bool(getattr(ew, "fused_wide", False)) and not spec.exact
+    if two_launch:
+        ls_buf = torch.empty((n, T), device=device)
+        ws = ctx._workspace()
+
+    def launch(slot, mid_event=None):
+        sums = outs[slot][0]
+        if spec.exact:
+            # the strictly-float32 encoder: layer-wise v_mfma_f32_16x16x4_f32 GEMMs (activations through HBM),
+            # then the ELBO kernel on its heads -- the path vi_fwd(range_check=True) falls back to
+            s2, _, _ = ctx.vi_fwd_exact(ew, x, mask, prior, S, K, seed=1, voxel0=voxel0)
+            sums.copy_(s2)
+            return sums
+        if not two_launch:
+            ctx.vi_fwd(ew, x, mask, prior, S, K, seed=1, voxel0=voxel0, out=outs[slot])
+            return sums
+        _lib.check(ctx.lib.qbold_encoder_fused_fwd(ctx.handle, C.byref(ew.shape), ew.fused_ptr(), _ptr(x), _ptr(q_buf),
+                                                   _ptr(ls_buf), n, _stream()), "qbold_encoder_fused_fwd")
+        if mid_event is not None:
+            mid_event.record()
+        _lib.check(ctx.lib.qbold_elbo_fwd_logsigma(ctx.handle, _ptr(x), _ptr(mask), _ptr(q_buf), _ptr(prior),
+                                                   _ptr(ls_buf), int(S), int(K), 1, int(voxel0), _ptr(nk_buf),
+                                                   _ptr(sums), _ptr(ws), n, _stream()), "qbold_elbo_fwd_logsigma")
+        return sums
+
+    def step(k, mid_event=None):
+        slot = k % RING
+        if pending[slot] is not None:
+            pending[slot].wait()   # stream-level wait: the slot's previous all-reduce has finished
+            pending[slot] = None
+        sums = launch(slot, mid_event)
+        if use_pg:
+            pending[slot] = dist.all_reduce(sums, async_op=True)  # sum m*nll, sum kl, sum m
+        return sums
+
+    def drain():
+        for slot in range(RING):
+            if pending[slot] is not None:
+                pending[slot].wait()
+                pending[slot] = None
+
+    def fence():
+        if use_pg:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # clock ramp (setup, like input generation above): same work, never timed
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+        for k in range(8):
+            step(k)
+        drain()
+        torch.cuda.synchronize()
+    for k in range(warmup):
+        step(k)
+    drain()
+    fence()
+    # per-launch durations: HIP events on the launch stream
+    every = max(1, min(args.event_every, steps // 5))   # at least five bracketed steps (short runs: every step)
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) if k % every == 0 else None
+           for k in range(steps)]
+    n_allreduce = 0
+    t0 = time.perf_counter()
+    for k, ev in enumerate(evs):
+        slot = k % RING
+        if pending[slot] is not None:
+            pending[slot].wait()
+            pending[slot] = None
+        if ev is not None:
+            ev[0].record()
+        sums = launch(slot, ev[1] if (two_launch and ev is not None) else None)
+        if ev is not None:
+            ev[2].record()
+        if use_pg:
+            pending[slot] = dist.all_reduce(sums, async_op=True)
+            n_allreduce += 1
+    drain()
+    fence()
+    elapsed = time.perf_counter() - t0
+    evs = [ev for ev in evs if ev is not None]
+    step_kernel_ms = float(np.mean([ea.elapsed_time(eb) for ea, em, eb in evs]))
+    enc_kernel_ms = float(np.mean([ea.elapsed_time(em) for ea, em, eb in evs])) if two_launch else None
+    s = sums.cpu().numpy()
+    return dict(params=params, w=w, T=T, U=U, L=L, n=n, two_launch=two_launch, elapsed=elapsed,
+                step_kernel_ms=step_kernel_ms, enc_kernel_ms=enc_kernel_ms, sums=s, n_allreduce=n_allreduce)
+
+
+def roofline_of(spec, m, S, K, step_kernel_ms, kernel_ms):
+    """The roofline object of one workload (see the notes inside): dominant kernel, its bound, achieved / peak."""
+    T, U, L, n, two_launch = m["T"], m["U"], m["L"], m["n"], m["two_launch"]
+    enc_flops_v = 2.0 * encoder_macs_per_voxel(T, U, L)
+    flops_v = float(algorithmic_flops_per_voxel(T, U, L, S, K))
+    passes = 1.0 if spec.encoder_precision == "bf16" else 3.0
+    byts = algorithmic_bytes_per_voxel(T) * n
+    # Two pipes share the step: the encoder's MACs run on the f16/bf16 matrix pipe (three split-f16 passes
+    # in f32 mode, one pass in bf16 mode), sampling + ELBO on the f32 vector pipe.  The step's roof is their
+    # serial sum (no overlap assumed), expressed as one composite peak so that frac = achieved / peak.
+    if spec.exact:   # every flop of this path, the encoder's included, runs at the f32 rate
+        t_min = flops_v / (F32_MFMA_PEAK_TFLOPS * 1e12) * n
+    else:
+        t_min = (passes * enc_flops_v / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
+                 (flops_v - enc_flops_v) / (F32_MFMA_PEAK_TFLOPS * 1e12)) * n
+    step_ach = flops_v * n / (step_kernel_ms * 1e-3) / 1e12
+    step_peak = flops_v * n / t_min / 1e12
+    prof = None
+    if two_launch:
+        # dominant kernel: the one-launch encoder, on the f16 matrix pipe
+        kname, bound = "wide_fused_kernel<4, 2, true>", "mfma"
+        ach = enc_flops_v * n / (kernel_ms * 1e-3) / 1e12
+        peak = BF16_MFMA_PEAK_TFLOPS / passes
+        prof = measured_profile(PROFILE_TAG + "_config3_pmc.json", "wide_fused_kernel") if n == 1 << 20 else None
+        note = ("dominant kernel = the one-launch wide encoder (activations in registers, weights streamed "
+                "L2 -> LDS): 'achieved' = SURVEY 8(d)'s encoder flops per voxel x voxels / its launch duration "
+                "(HIP events inside the timed region); 'peak' = the guide's dense f16 MFMA peak / 3, because "
+                "float32-grade products take three f16 MFMA passes; under this kernel's matrix load the chip "
+                "holds ~1.6-2.0 GHz, not the 2.4 GHz the peak assumes (DESIGN 4.7); the second launch "
+                "(elbo_fwd_lds_kernel, VALU-bound) and the step's composite two-pipe figure are in 'step'")
+    elif spec.exact:
+        kname, bound = "xw64_kernel / xw64_fork_kernel / xw64_gate_kernel / xw64_heads_kernel + elbo_fwd_kernel", "mfma"
+        ach, peak = step_ach, step_peak
+        note = ("the strictly-float32 encoder (v_mfma_f32_16x16x4_f32 GEMMs, one launch per layer, float32 "
+                "activations through HBM) + the ELBO kernel: every flop priced at the f32 matrix / vector peak; the "
+                "layer GEMMs are HBM-bound (DESIGN 4.5), which is why the headline path splits operands instead")
+    else:
+        kname = "vi_fwd_kernel"
+        ach, peak = step_ach, step_peak
+        # the counter file of this very configuration, if one was measured on these sources
+        pmc_name = {(11, "f32"): "_vi_fwd_pmc.json", (24, "f32"): "_p24_vi_fwd_pmc.json",
+                    (11, "bf16"): "_bf16_vi_fwd_pmc.json"}.get((spec.protocol, spec.encoder_precision))
+        prof = measured_profile(PROFILE_TAG + pmc_name, "vi_fwd_kernel") \
+            if (pmc_name and spec.config == 2 and spec.tissue == "table" and n == 1 << 20) else None
+        # what the counters say; without a valid counter file the kernel's known regime (DESIGN 4.4)
+        bound = "valu-issue"
+        note = ("one launch on two pipes: 'peak' is the composite of MI355X_MICROARCH.md's dense peaks -- the "
+                "encoder's flops at the f16/bf16 MFMA peak (x the split passes), sampling + ELBO at the f32 "
+                "vector (= f32 matrix) peak, serial sum, no overlap assumed; the kernel is bound by the vector "
+                "pipe's ISSUE rate (SQ_ACTIVE_INST_VALU ~0.9 of SIMD cycles; scalar f32 instructions cost "
+                "2.9-8.5 cycles each, DESIGN 4.4), hence 'valu-issue'; 'single_pipe_f32_frac' prices ALL of "
+                "SURVEY 8(d)'s flops at the f32 peak alone and can pass 1 because the encoder's share runs "
+                "concurrently on the matrix pipe; the metric's HBM roofline (BASELINE.json) is 'hbm': the path "
+                "moves 96 B per voxel against ~90 kFLOP, so its HBM fraction is ~0.02 by arithmetic (SURVEY H1)")
+    counters, traffic = {}, None
+    if prof:
+        traffic = prof.get("hbm_bytes_per_launch")
+        counters = dict(prof.get("counters", {}), source="profiles/" + prof.get("_file", ""),
+                        measured_on_sources=prof.get("source_sha256", "")[:12], kernel=prof.get("kernel"))
+    ach_gbs = byts / (step_kernel_ms * 1e-3) / 1e9
+    return {"kernel": kname, "bound": bound, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+            "frac": ach / peak, "traffic": traffic, "kernel_ms": kernel_ms,
+            **({"counters": counters} if counters else {}),
+            "algorithmic_flops_per_voxel": enc_flops_v if two_launch else flops_v,
+            "peak_components": {"f32_matrix_or_packed_vector_tflops": F32_MFMA_PEAK_TFLOPS,
+                                "f16_bf16_mfma_tflops": BF16_MFMA_PEAK_TFLOPS,
+                                "encoder_mfma_passes": passes,
+                                "encoder_flops_per_voxel": enc_flops_v},
+            "single_pipe_f32_frac": step_ach / F32_MFMA_PEAK_TFLOPS,
+            "step": {"launches": (["wide_fused_kernel", "elbo_fwd_lds_kernel", "reduce_partials_kernel"] if two_launch
+                                  else ["layer-wise encoder (9 launches)", "elbo_fwd_kernel", "reduce_partials_kernel"]
+                                  if spec.exact else ["vi_fwd_kernel", "reduce_partials_kernel"]),
+                     "kernel_ms": step_kernel_ms, "algorithmic_flops_per_voxel": flops_v,
+                     "achieved": step_ach, "peak": step_peak, "frac": step_ach / step_peak,
+                     "unit": "TFLOP/s", "bound": "two pipes, serial sum (composite)"},
+            "note": note,
+            "hbm": {"algorithmic_bytes_per_voxel": algorithmic_bytes_per_voxel(T),
+                    "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach_gbs / HBM_PEAK_GBS}}
+
+
+def workload_text(spec, m, S, K):
+    T, U, L, n = m["T"], m["U"], m["L"], m["n"]
+    if spec.exact:
+        arith = "exact float32 (v_mfma_f32_16x16x4_f32, one launch per layer)"
+    elif spec.encoder_precision == "f32":
+        arith = ("operands split in two f16 halves, three MFMA passes (hi.hi, hi.lo, lo.hi), f32 accumulate: "
+                 "float32-grade (~22 significant bits), |x| < 65504")
+    else:
+        arith = "operands rounded to bf16, one MFMA pass, f32 accumulate"
+    entry = ("qbold_encoder_train_fwd + qbold_elbo_fwd (vi_fwd_exact)" if spec.exact else
+             "qbold_encoder_fused_fwd + qbold_elbo_fwd_logsigma (= qbold_vi_fwd)" if m["two_launch"] else "fused qbold_vi_fwd")
+    return (f"{n} synthetic voxels/GPU x {T} tau, S={S} likelihood draws, K={K} KL draws, encoder U={U}, L={L} "
+            f"({'optimal.yaml' if U == 60 else 'BASELINE config 3'}), {entry}, tissue integral: {spec.tissue}; "
+            f"encoder arithmetic: {arith}; sampling, forward model and ELBO sums: f32")
+
+
+PROFILE_TAG = "r03"
+# what the default N = 1 run times after the headline (VERDICT round 2, item 3): every configuration a summary
+# quotes, so that each number has a driver-witnessed line
+VARIANTS = (("config3_64tau_width256", dict(config=3)),
+            ("bf16_encoder", dict(encoder_precision="bf16")),
+            ("voxels_4194304", dict(voxels=4194304)),
+            ("protocol_24tau", dict(protocol=24)),
+            ("exact_f32_encoder", dict(exact=True)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -304,10 +550,16 @@ def main():
     ap.add_argument("--encoder_precision", choices=["f32", "bf16"], default="f32",
                     help="f32 (headline): float32-grade split-f16 MFMA; bf16: BASELINE config 5's "
                          "'bf16 forward / fp32 ELBO accum' (encoder products on bf16 operands)")
+    ap.add_argument("--exact_f32", action="store_true",
+                    help="the strictly-float32 encoder (f32-input MFMA, layer-wise) instead of the split-f16 one")
     ap.add_argument("--rehearse_launch", action="store_true",
                     help="run the N-rank launcher, rendezvous, all-reduce ring and JSON line with no kernel in the step "
                          "(host tensors over gloo; reports no throughput) -- the CPU-container check of --gpus N")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_variants", action="store_true",
+                    help="skip the variant workloads the default N = 1 headline run times after the headline")
+    ap.add_argument("--variants", action="store_true", help="time the variant workloads even on a non-default run")
+    ap.add_argument("--variant_steps", type=int, default=20)
     ap.add_argument("--event_every", type=int, default=8,
                     help="HIP events bracket every M-th timed step (a timing event is a barrier packet in the queue: "
                          "around every step they cost up to 5 %% of a 0.5 ms step on some boxes)")
@@ -333,8 +585,6 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from qbold_vi_amd.init import init_encoder_weights
-    from qbold_vi_amd.ops import EncoderWeights
 
     ndev = torch.cuda.device_count()
     if ndev == 0:
@@ -342,236 +592,100 @@ def main():
     dev_index = local_rank % ndev   # one rank per GPU on a real node; rehearsals may share a card
     torch.cuda.set_device(dev_index)
     device = torch.device(f"cuda:{dev_index}")
-    if world > 1:
+    # QBOLD_FORCE_PG=1: build the process group for a single rank too, so that a one-GPU box executes the
+    # very RCCL path of the N-rank job (communicator on device_id, async all-reduce ring on device buffers)
+    use_pg = world > 1 or os.environ.get("QBOLD_FORCE_PG", "0") not in ("", "0")
+    if use_pg:
         # RCCL ("nccl" on ROCm) over xGMI; QBOLD_DIST_BACKEND=gloo only for single-card rehearsals
         backend = os.environ.get("QBOLD_DIST_BACKEND", "nccl")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    cfg = configparser.ConfigParser()
-    cfg.read(os.path.join(ROOT, "config"))
-    params = dict(cfg["DEFAULT"])
-    T, U, L = 11, 60, 2  # configurations/optimal.yaml
-    if args.config == 3:  # 64 taus from -0.015 s in 1.25 ms steps (se_idx 12), width 256
-        params.update(tau_start="-0.015", tau_end="0.065", tau_step="0.00125")
-        T, U = 64, 256
-    elif args.protocol == 24:
-        params.update(tau_start="-0.028", tau_end="0.065", tau_step="0.004")
-        T = 24
-    S, K, n = args.mc_samples, args.kl_samples, args.voxels
-
-    ctx, x = make_inputs(n, params, seed=1 + rank, device=device)
-    ctx.set_tissue_mode(args.tissue)
-    w = init_encoder_weights(T=T, U=U, L=L, channelwise_gating=True, resid_init_std=0.05,
-                             im_loss_sigma=0.05, seed=1)
-    if args.encoder_precision == "bf16" and args.config != 2:
-        raise SystemExit("--encoder_precision bf16 applies to the fused kernel (config 2)")
-    ew = EncoderWeights(ctx, T, U, L, True, -3.0, precision=args.encoder_precision).set_from_arrays(w)
-    mask = torch.ones(n, device=device)
-    prior, _, _ = ctx.encoder_fwd(ew, x, want=("out1",))  # prior = stream-1 output (train.py:26-31)
-    q_buf, nk_buf = torch.empty((n, 5), device=device), torch.empty((n, 2), device=device)
-    # The three masked sums of every step are all-reduced (RCCL over xGMI).  A ring of result buffers
-    # lets step k+1's kernel run while step k's 24-byte all-reduce is in flight on RCCL's stream: the
-    # reduced ELBO is consumed a few steps later, as a training loop consumes its loss.
-    RING = 4
-    outs = [(torch.empty(3, dtype=torch.float64, device=device), q_buf, nk_buf) for _ in range(RING)]
-    pending = [None] * RING
-    voxel0 = rank * n
-
-    # Config 3 runs as two launches (the one-launch wide encoder, then the ELBO kernel on its heads): the bench
-    # issues them through the two C entry points qbold_vi_fwd itself chains, with an event between them, so that
-    # the dominant kernel's duration is measured live in the timed region.
-    import ctypes as C
-    from qbold_vi_amd import _lib
-    from qbold_vi_amd.ops import _ptr, _stream
-    two_launch = bool(getattr(ew, "fused_wide", False))
-    if two_launch:
-        ls_buf = torch.empty((n, T), device=device)
-        ws = ctx._workspace()
-
-    def launch(slot, mid_event=None):
-        sums = outs[slot][0]
-        if not two_launch:
-            ctx.vi_fwd(ew, x, mask, prior, S, K, seed=1, voxel0=voxel0, out=outs[slot])
-            return sums
-        _lib.check(ctx.lib.qbold_encoder_fused_fwd(ctx.handle, C.byref(ew.shape), ew.fused_ptr(), _ptr(x), _ptr(q_buf),
-                                                   _ptr(ls_buf), n, _stream()), "qbold_encoder_fused_fwd")
-        if mid_event is not None:
-            mid_event.record()
-        _lib.check(ctx.lib.qbold_elbo_fwd_logsigma(ctx.handle, _ptr(x), _ptr(mask), _ptr(q_buf), _ptr(prior),
-                                                   _ptr(ls_buf), int(S), int(K), 1, int(voxel0), _ptr(nk_buf),
-                                                   _ptr(sums), _ptr(ws), n, _stream()), "qbold_elbo_fwd_logsigma")
-        return sums
-
-    def step(k, mid_event=None):
-        slot = k % RING
-        if pending[slot] is not None:
-            pending[slot].wait()   # stream-level wait: the slot's previous all-reduce has finished
-            pending[slot] = None
-        sums = launch(slot, mid_event)
-        if world > 1:
-            pending[slot] = dist.all_reduce(sums, async_op=True)  # sum m*nll, sum kl, sum m
-        return sums
-
-    def drain():
-        for slot in range(RING):
-            if pending[slot] is not None:
-                pending[slot].wait()
-                pending[slot] = None
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # clock ramp (setup, like input generation above): same work, never timed
-    t_ramp = time.perf_counter()
-    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
-        for k in range(8):
-            step(k)
-        drain()
-        torch.cuda.synchronize()
-    for k in range(args.warmup):
-        step(k)
-    drain()
-    fence()
-    # per-launch durations: HIP events on the launch stream
-    every = max(1, min(args.event_every, args.steps // 5))   # at least five bracketed steps (short runs: every step)
-    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) if k % every == 0 else None
-           for k in range(args.steps)]
-    t0 = time.perf_counter()
-    for k, ev in enumerate(evs):
-        slot = k % RING
-        if pending[slot] is not None:
-            pending[slot].wait()
-            pending[slot] = None
-        if ev is not None:
-            ev[0].record()
-        sums = launch(slot, ev[1] if (two_launch and ev is not None) else None)
-        if ev is not None:
-            ev[2].record()
-        if world > 1:
-            pending[slot] = dist.all_reduce(sums, async_op=True)
-    drain()
-    fence()
-    elapsed = time.perf_counter() - t0
-    evs = [ev for ev in evs if ev is not None]
-    step_kernel_ms = float(np.mean([ea.elapsed_time(eb) for ea, em, eb in evs]))
-    enc_kernel_ms = float(np.mean([ea.elapsed_time(em) for ea, em, eb in evs])) if two_launch else None
-    kernel_ms = enc_kernel_ms if two_launch else step_kernel_ms   # the dominant kernel's launch duration
+    S, K = args.mc_samples, args.kl_samples
+    spec = Spec(args.config, args.protocol, args.voxels, args.encoder_precision, args.tissue, args.exact_f32)
+    m = run_workload(spec, args, args.steps, args.warmup, rank, device, use_pg, world, S, K)
+    n, T = m["n"], m["T"]
+    kernel_ms = m["enc_kernel_ms"] if m["two_launch"] else m["step_kernel_ms"]   # the dominant kernel's launch
     # every rank's own wall time and kernel time; the step time of the job is the MAX over ranks
-    mine = torch.tensor([elapsed / args.steps * 1e3, kernel_ms], dtype=torch.float64, device=device)
+    mine = torch.tensor([m["elapsed"] / args.steps * 1e3, kernel_ms], dtype=torch.float64, device=device)
     per_rank = [torch.zeros_like(mine) for _ in range(world)]
-    if world > 1:
+    if use_pg:
         dist.all_gather(per_rank, mine)
     else:
         per_rank = [mine]
     per_rank = torch.stack(per_rank).cpu().numpy()
     elapsed = float(per_rank[:, 0].max()) * 1e-3 * args.steps
-    s = sums.cpu().numpy()
+    s = m["sums"]
     neg_elbo = float((s[0] + s[1]) / s[2])
     if not np.isfinite(neg_elbo):
         raise SystemExit("non-finite ELBO")  # the reference's TerminateOnNaN (train.py:375)
+    if use_pg and abs(float(s[2]) - float(n) * world) > 0.5:
+        raise SystemExit(f"all-reduce of the masked sums is wrong: sum(mask) = {s[2]} for {n} x {world} voxels")
 
     if rank == 0:
         total_vox = n * world
         value = total_vox * args.steps / elapsed
-        enc_flops_v = 2.0 * encoder_macs_per_voxel(T, U, L)
-        flops_v = float(algorithmic_flops_per_voxel(T, U, L, S, K))
-        passes = 1.0 if args.encoder_precision == "bf16" else 3.0
-        byts = algorithmic_bytes_per_voxel(T) * n
-        # Two pipes share the step: the encoder's MACs run on the f16/bf16 matrix pipe (three split-f16 passes
-        # in f32 mode, one pass in bf16 mode), sampling + ELBO on the f32 vector pipe.  The step's roof is their
-        # serial sum (no overlap assumed), expressed as one composite peak so that frac = achieved / peak.
-        t_min = (passes * enc_flops_v / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
-                 (flops_v - enc_flops_v) / (F32_MFMA_PEAK_TFLOPS * 1e12)) * n
-        step_ach = flops_v * n / (step_kernel_ms * 1e-3) / 1e12
-        step_peak = flops_v * n / t_min / 1e12
-        arith = ("operands split in two f16 halves, three MFMA passes (hi.hi, hi.lo, lo.hi), f32 accumulate: "
-                 "float32-grade (~22 significant bits), |x| < 65504" if args.encoder_precision == "f32"
-                 else "operands rounded to bf16, one MFMA pass, f32 accumulate")
-        if two_launch:
-            # dominant kernel: the one-launch encoder, on the f16 matrix pipe
-            kname, bound = "wide_fused_kernel<4, 2, true>", "mfma"
-            ach = enc_flops_v * n / (kernel_ms * 1e-3) / 1e12
-            peak = BF16_MFMA_PEAK_TFLOPS / passes
-            prof = measured_profile("r02_config3_pmc.json", "wide_fused_kernel")
-            note = ("dominant kernel = the one-launch wide encoder (activations in registers, weights streamed "
-                    "L2 -> LDS): 'achieved' = SURVEY 8(d)'s encoder flops per voxel x voxels / its launch duration "
-                    "(HIP events inside the timed region); 'peak' = the guide's dense f16 MFMA peak / 3, because "
-                    "float32-grade products take three f16 MFMA passes; under this kernel's matrix load the chip "
-                    "holds ~1.6-2.0 GHz, not the 2.4 GHz the peak assumes (DESIGN 4.7); the second launch "
-                    "(elbo_fwd_lds_kernel, VALU-bound) and the step's composite two-pipe figure are in 'step'")
-        else:
-            kname = "vi_fwd_kernel"
-            ach, peak = step_ach, step_peak
-            # the counter file of this very configuration, if one was measured on these sources
-            pmc_name = {(11, "f32"): "r02_vi_fwd_pmc.json", (24, "f32"): "r02_p24_vi_fwd_pmc.json",
-                        (11, "bf16"): "r02_bf16_vi_fwd_pmc.json"}.get((args.protocol, args.encoder_precision))
-            prof = measured_profile(pmc_name, "vi_fwd_kernel") \
-                if (pmc_name and args.config == 2 and args.tissue == "table" and n == 1 << 20) else None
-            # what the counters say; without a valid counter file the kernel's known regime
-            bound = "valu-issue"
-            note = ("one launch on two pipes: 'peak' is the composite of MI355X_MICROARCH.md's dense peaks -- the "
-                    "encoder's flops at the f16/bf16 MFMA peak (x the split passes), sampling + ELBO at the f32 "
-                    "vector (= f32 matrix) peak, serial sum, no overlap assumed; the kernel is bound by the vector "
-                    "pipe's ISSUE rate (SQ_ACTIVE_INST_VALU ~0.9 of SIMD cycles; scalar f32 instructions cost "
-                    "2.9-8.5 cycles each, DESIGN 4.4), hence 'valu-issue'; 'single_pipe_f32_frac' prices ALL of "
-                    "SURVEY 8(d)'s flops at the f32 peak alone and can pass 1 because the encoder's share runs "
-                    "concurrently on the matrix pipe; the metric's HBM view is in 'hbm'")
-        counters, traffic = {}, None
-        if prof:
-            traffic = prof.get("hbm_bytes_per_launch")
-            counters = dict(prof.get("counters", {}), source="profiles/" + prof.get("_file", ""),
-                            measured_on_sources=prof.get("source_sha256", "")[:12], kernel=prof.get("kernel"))
-        ach_gbs = byts / (step_kernel_ms * 1e-3) / 1e9
+        default_headline = (args.config == 2 and args.protocol == 11 and args.encoder_precision == "f32"
+                            and args.tissue == "table" and not args.exact_f32 and n == 1 << 20)
         line = {
             "metric": "voxel-ELBO evals/sec", "value": value, "unit": "voxel-ELBO evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.encoder_precision == "f32" else "bf16 encoder products / f32 accumulate, sampling and ELBO",
+            "dtype": ("f32" if args.encoder_precision == "f32"
+                      else "bf16 encoder products / f32 accumulate, sampling and ELBO"),
             "data": "synthetic",
-            "config": {"workload": f"{n} synthetic voxels/GPU x {T} tau, S={S} likelihood draws, "
-                                   f"K={K} KL draws, encoder U={U}, L={L} "
-                                   f"({'optimal.yaml' if U == 60 else 'BASELINE config 3'}), "
-                                   f"{'qbold_encoder_fused_fwd + qbold_elbo_fwd_logsigma (= qbold_vi_fwd)' if two_launch else 'fused qbold_vi_fwd'}, "
-                                   f"tissue integral: {args.tissue}; encoder arithmetic: {arith}; sampling, forward "
-                                   f"model and ELBO sums: f32",
+            "config": {"workload": workload_text(spec, m, S, K),
                        "global_voxels": total_vox, "parallelism": f"voxel-shard x{world}",
-                       "collective": "all_reduce(3 x f64)/step, overlapped with the next step" if world > 1 else "none"},
+                       "collective": "all_reduce(3 x f64)/step, overlapped with the next step" if use_pg else "none"},
             "neg_elbo": neg_elbo,
-            "ranks_seen": dist.get_world_size() if world > 1 else 1,
-            "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none",
+            "ranks_seen": dist.get_world_size() if use_pg else 1,
+            "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if use_pg else "none",
+            **({"allreduce_per_timed_step": m["n_allreduce"] / args.steps} if use_pg else {}),
             "rank_ms_per_step": {"min": float(per_rank[:, 0].min()), "max": float(per_rank[:, 0].max())},
             "rank_kernel_ms": {"min": float(per_rank[:, 1].min()), "max": float(per_rank[:, 1].max())},
             **({"ablation": "QBOLD_DEBUG_SKIP=" + os.environ["QBOLD_DEBUG_SKIP"] + " (NOT a benchmark result)"}
                if os.environ.get("QBOLD_DEBUG_SKIP", "0") not in ("", "0") else {}),
-            "roofline": {"kernel": kname, "bound": bound, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "traffic": traffic, "kernel_ms": kernel_ms,
-                         **({"counters": counters} if counters else {}),
-                         "algorithmic_flops_per_voxel": enc_flops_v if two_launch else flops_v,
-                         "peak_components": {"f32_matrix_or_packed_vector_tflops": F32_MFMA_PEAK_TFLOPS,
-                                             "f16_bf16_mfma_tflops": BF16_MFMA_PEAK_TFLOPS,
-                                             "encoder_mfma_passes": passes,
-                                             "encoder_flops_per_voxel": enc_flops_v},
-                         "single_pipe_f32_frac": step_ach / F32_MFMA_PEAK_TFLOPS,
-                         "step": {"launches": ["wide_fused_kernel", "elbo_fwd_lds_kernel", "reduce_partials_kernel"]
-                                  if two_launch else ["vi_fwd_kernel", "reduce_partials_kernel"],
-                                  "kernel_ms": step_kernel_ms, "algorithmic_flops_per_voxel": flops_v,
-                                  "achieved": step_ach, "peak": step_peak, "frac": step_ach / step_peak,
-                                  "unit": "TFLOP/s", "bound": "two pipes, serial sum (composite)"},
-                         "note": note,
-                         "hbm": {"algorithmic_bytes_per_voxel": algorithmic_bytes_per_voxel(T),
-                                 "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": ach_gbs / HBM_PEAK_GBS}},
+            "roofline": roofline_of(spec, m, S, K, m["step_kernel_ms"], kernel_ms),
         }
+        if world == 1 and (args.variants or (default_headline and not args.no_variants)):
+            # the other configurations the summaries quote, each timed here like the headline (same ramp, HIP
+            # events, barrier-bracketed wall clock) so that every quoted number is in this one line
+            vsteps = max(args.variant_steps, 20)
+            line["variants"] = {}
+            w_headline, params_headline = m["w"], m["params"]
+            del m
+            for name, kw in VARIANTS:
+                torch.cuda.empty_cache()
+                vs = Spec(**kw)
+                try:
+                    vm = run_workload(vs, args, vsteps, min(args.warmup, 5), rank, device, use_pg, world, S, K)
+                except Exception as e:   # a variant never takes the headline down
+                    line["variants"][name] = {"error": repr(e)}
+                    continue
+                vk = vm["enc_kernel_ms"] if vm["two_launch"] else vm["step_kernel_ms"]
+                vms = vm["elapsed"] / vsteps * 1e3
+                vsum = vm["sums"]
+                r = roofline_of(vs, vm, S, K, vm["step_kernel_ms"], vk)
+                line["variants"][name] = {
+                    "workload": workload_text(vs, vm, S, K), "steps": vsteps, "ms_per_step": vms,
+                    "value": vm["n"] * 1e3 / vms, "unit": "voxel-ELBO evals/s",
+                    "neg_elbo": float((vsum[0] + vsum[1]) / vsum[2]),
+                    "roofline": {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                   "kernel_ms", "algorithmic_flops_per_voxel")}
+                                | {"step_kernel_ms": vm["step_kernel_ms"], "hbm_frac": r["hbm"]["frac"],
+                                   "step_frac": r["step"]["frac"]}}
+                del vm
+            m = {"w": w_headline, "params": params_headline}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(params, w, S, K, args.cpu_budget_s)
+            line["cpu_baseline"] = cpu_baseline(m["params"], m["w"], S, K, args.cpu_budget_s)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -322,21 +322,24 @@ def _train_full_model_crops(config_dict, trainer, full_model, study_dataset, tra
     gv = torch.Generator(device=dev)
     gv.manual_seed(3)
     step = 0
+    nxt = train_dataset.next_batch(g)
     for epoch in range(int(_get(config_dict, "no_ft_epochs"))):
         tot = torch.zeros(4, dtype=torch.float64, device=dev)
         for _ in range(steps_per_epoch):
-            x5, m5, p5 = train_dataset.next_batch(g)
+            x5, m5, p5 = nxt
             n = m5.numel()
             q, ls = state.forward_spatial(x5)
             sums, gq, gls = _elbo_bwd(trainer, x5.reshape(n, -1), m5.reshape(n), q, p5.reshape(n, 5), ls, S,
                                       kl_samples, 1000 + step, rank * n)
             tv = ctx.smoothness(q.reshape(m5.shape + (5,)), m5, weight=sw, g_q=gq)
             red = torch.cat([sums, tv])
-            if world > 1:
-                torch.distributed.all_reduce(red)
+            qd.allreduce_(red, "allreduce_sums")
             state.backward_spatial(gq, gls, red[:3].contiguous())
-            if world > 1:
-                torch.distributed.all_reduce(state.grad)
+            # the gradient all-reduce runs on RCCL's stream while this rank draws and gathers its next crops
+            work = qd.allreduce_grad_(state.grad, async_op=True)
+            nxt = train_dataset.next_batch(g)
+            if work is not None:
+                work.wait()
             wd = lr_schedule(decay0, step, steps_per_epoch) if decay0 > 0.0 else 0.0
             state.adamw(lr_schedule(lr0, step, steps_per_epoch), wd, 0.9, beta2, 1e-7)
             tot += red
@@ -390,19 +393,28 @@ def train_full_model(config_dict, trainer, full_model, study_dataset, train_data
     g = torch.Generator(device=x.device)
     g.manual_seed(2)
     step = 0
+
+    def draw_batch():
+        idx = torch.randint(0, n, (min(batch_voxels, n),), generator=g, device=x.device)
+        a, b = qd.shard_range(idx.numel(), rank, world)
+        sel = idx[a:b]
+        return a, x[sel], mask[sel], prior[sel]
+
+    nxt = draw_batch()
     for epoch in range(int(_get(config_dict, "no_ft_epochs"))):
         tot = torch.zeros(3, dtype=torch.float64, device=x.device)
         for _ in range(steps_per_epoch):
-            idx = torch.randint(0, n, (min(batch_voxels, n),), generator=g, device=x.device)
-            a, b = qd.shard_range(idx.numel(), rank, world)
-            sel = idx[a:b]
-            xb, mb, pb = x[sel], mask[sel], prior[sel]
+            a, xb, mb, pb = nxt
             q2, ls = state.forward(xb, 2)
             sums, gq, gls = _elbo_bwd(trainer, xb, mb, q2, pb, ls, S, kl_samples, 1000 + step, a)
             qd.allreduce_sums(sums)          # global sum(mask) before the gradient is normalised
             state.backward(2, gq, gls, sums)
-            if world > 1:
-                torch.distributed.all_reduce(state.grad)  # shard gradients add up (same 1/sum(m))
+            # shard gradients add up (same 1/sum(m)); the all-reduce runs on RCCL's stream while this rank
+            # draws and gathers its next batch (the next forward itself needs the updated weights)
+            work = qd.allreduce_grad_(state.grad, async_op=True)
+            nxt = draw_batch()
+            if work is not None:
+                work.wait()
             wd = lr_schedule(decay0, step, steps_per_epoch) if decay0 > 0.0 else 0.0
             state.adamw(lr_schedule(lr0, step, steps_per_epoch), wd, 0.9, beta2, 1e-7)
             tot += sums

@@ -49,6 +49,38 @@ def check_line(d, expect_cpu_baseline):
         assert set(c["cases"]) == {"i_forward_model_only", "ii_elbo_reference_defaults_S1_K70", "iii_elbo_bench_workload"}
         assert all(v["value"] > 0 for v in c["cases"].values())
         assert c["op_granularity"].get("value", 0) > 0, c["op_granularity"]
+    if "variants" in d:
+        check_variants(d)
+
+
+VARIANT_NAMES = {"config3_64tau_width256", "bf16_encoder", "voxels_4194304", "protocol_24tau", "exact_f32_encoder"}
+
+
+def check_variants(d):
+    """Every configuration a summary quotes is timed in the default run and embedded in the ONE line."""
+    v = d["variants"]
+    assert set(v) == VARIANT_NAMES
+    for name, e in v.items():
+        assert "error" not in e, (name, e)
+        assert e["steps"] >= 20 and e["ms_per_step"] > 0 and e["unit"] == d["unit"]
+        n = 4194304 if name == "voxels_4194304" else 1 << 20
+        assert str(n) in e["workload"]
+        assert abs(e["value"] - n * 1e3 / e["ms_per_step"]) < 1e-6 * e["value"]
+        r = e["roofline"]
+        for k in ("kernel", "frac", "kernel_ms", "traffic", "bound", "achieved", "peak"):
+            assert k in r, (name, k)
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] <= 1.0
+        assert r["kernel_ms"] <= e["ms_per_step"] * 1.02 and 0.0 < r["hbm_frac"] < 1.0
+        assert e["neg_elbo"] == e["neg_elbo"]
+    assert v["config3_64tau_width256"]["roofline"]["kernel"].startswith("wide_fused_kernel")
+    assert v["config3_64tau_width256"]["roofline"]["bound"] == "mfma"
+    assert "exact float32" in v["exact_f32_encoder"]["workload"]
+    # the bf16 mode and the exact-f32 mode evaluate the headline's inputs: -ELBO within the re-stated tolerances
+    assert abs(v["bf16_encoder"]["neg_elbo"] / d["neg_elbo"] - 1) < 1e-3
+    assert abs(v["exact_f32_encoder"]["neg_elbo"] / d["neg_elbo"] - 1) < 1e-5
+    # the split-f16 headline beats the strictly-float32 encoder, and 4 M voxels run at the 1 M rate
+    assert v["exact_f32_encoder"]["ms_per_step"] > d["ms_per_step"]
+    assert 0.8 < v["voxels_4194304"]["value"] / d["value"] < 1.25
 
 
 def test_committed_bench_line_keeps_the_contract():
@@ -134,6 +166,19 @@ def test_self_launched_two_ranks_on_one_card():
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo"
     assert d["config"]["global_voxels"] == 2 * 65536
     assert d["rank_ms_per_step"]["max"] == pytest.approx(d["ms_per_step"])
+
+
+@pytest.mark.gpu
+def test_driver_command_line_carries_every_variant():
+    """The driver's own N = 1 command: headline keys unchanged, and the variants object beside them."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                        "--cpu_budget_s", "1"], capture_output=True, text=True, cwd=ROOT, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    check_line(d, expect_cpu_baseline=True)
+    assert "variants" in d and d["config"]["global_voxels"] == 1 << 20 and d["dtype"] == "f32"
 
 
 @pytest.mark.gpu

@@ -88,3 +88,26 @@ def test_single_process_helpers_are_noops():
     assert qd.allreduce_sums(s) is s
     nll, kl, elbo = qd.elbo_from_sums(s)
     assert (float(nll), float(kl), float(elbo)) == (1.0, 2.0, 3.0)
+
+
+def test_forced_single_rank_group_issues_the_collectives():
+    """QBOLD_FORCE_PG=1: a one-rank process group (gloo here, RCCL on the GPU box -- tests/test_gpu_rccl.py)
+    goes through the same init / all-reduce calls as the N-rank job and leaves the numbers unchanged."""
+    import subprocess
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torch, torch.distributed as dist\n"
+        "from qbold_vi_amd import distributed as qd\n"
+        "r, w, _ = qd.init_from_env(backend='gloo')\n"
+        "assert (r, w) == (0, 1) and qd.active() and dist.get_world_size() == 1 and qd.backend_name() == 'gloo'\n"
+        "s = torch.tensor([2.0, 4.0, 2.0], dtype=torch.float64)\n"
+        "qd.allreduce_sums(s); assert s.tolist() == [2.0, 4.0, 2.0]\n"
+        "g = torch.arange(5, dtype=torch.float32)\n"
+        "h = qd.allreduce_grad_(g, async_op=True); h.wait(); assert g.tolist() == [0, 1, 2, 3, 4]\n"
+        "qd.allreduce_mean_(g); assert g.tolist() == [0, 1, 2, 3, 4]\n"
+        "assert qd.STATS == {'allreduce_sums': 1, 'allreduce_grad': 2, 'allreduce_other': 0}, qd.STATS\n"
+        "dist.destroy_process_group(); print('ok')\n") % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["QBOLD_FORCE_PG"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
