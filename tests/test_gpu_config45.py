@@ -67,8 +67,8 @@ def test_eight_shards_of_4m_voxels_equal_the_32m_voxel_job(job, oracle32, precis
         assert torch.equal(nk_r, nk_all[sl]) and torch.equal(q_r, q_all[sl])   # independent of the sharding
         # the shard's sums are the masked checksum of its per-voxel outputs
         md = mask[sl].double()
-        assert abs(float((nk_r[:, 0].double() * md).sum()) / float(s_r[0]) - 1) < 1e-9
-        assert abs(float(nk_r[:, 1].double()[mask[sl] > 0].sum()) / float(s_r[1]) - 1) < 1e-9
+        assert abs(float((nk_r[:, 0].double() * md).sum()) / float(s_r[0]) - 1) < 1e-8   # lane partials are float32
+        assert abs(float(nk_r[:, 1].double()[mask[sl] > 0].sum()) / float(s_r[1]) - 1) < 1e-8
         assert float(s_r[2]) == float(md.sum())
         acc += s_r
         # a shard keyed by the WRONG offset draws other normals: the global key is what is being tested
