@@ -284,6 +284,12 @@ class Oracle:
         self.lib.qbo_kl_diag(self._p(q), self._p(prior), self._p(out), C.c_int64(q.shape[0]))
         return out
 
+    def population_prior_cost(self, prior4, batch):
+        """model.py:710-716: the inverse-gamma(1, 2) cost on the population prior's log-variances x batch size."""
+        p = self._a(prior4, (4,))
+        self.lib.qbo_population_prior_cost.restype = C.c_double
+        return self.lib.qbo_population_prior_cost(self._p(p), C.c_int(int(batch)))
+
     def logit_gaussian_nlogp(self, y, p):
         y = self._a(y, (-1, 2))
         p = self._a(p, (-1, 5))

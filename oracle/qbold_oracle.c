@@ -794,6 +794,24 @@ void qbo_kl_diag(const real *q, const real *prior, real *kl, int64_t N) {
     }
 }
 
+/* kl_loss, diagonal family WITH the population prior (use_mvg = False, use_population_prior = True,
+ * mog_components = 1) -- model.py:687-690, 704-716: 'predictions' carries [q4 | prior4]; the per-voxel
+ * "true" tensor contributes its mask only.  Per voxel the KL is qbo_kl_diag against the one population
+ * prior.  The returned value is the batch cost that joins the KL numerator (:710-713, :721):
+ *   ig = InverseGamma(1, 2);  cost = -ig.log_prob(exp(2 mean(p_dbv_log_std))) - ig.log_prob(exp(2 mean(
+ *   p_oef_log_std)));  cost *= shape(predicted)[0]       (the BATCH axis, not the voxel count)
+ * with log_std = transform_std(raw); tfp InverseGamma.log_prob(x) = c log s - lgamma(c) - (c + 1) log x - s / x. */
+double qbo_population_prior_cost(const real *prior4 /*[4]*/, int batch) {
+    double cost = 0;
+    const int order[2] = {3, 1}; /* DBV first, then OEF (:711-712) */
+    for (int k = 0; k < 2; ++k) {
+        double log_std = (double)transform_std(prior4[order[k]]);
+        double v = exp(2.0 * log_std);
+        cost -= 1.0 * log(2.0) - lgamma(1.0) - (1.0 + 1.0) * log(v) - 2.0 / v;
+    }
+    return cost * (double)batch;
+}
+
 /* logit_gaussian_log_prob (diagonal family, model.py:406-421): NEGATIVE log-density up to the
  * reference's own constant -- gaussian_nll (:403-404) carries no log sqrt(2 pi).  p rows 5 wide. */
 void qbo_logit_gaussian_nlogp(const real *y, const real *p, real *out, int64_t N) {

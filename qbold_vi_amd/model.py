@@ -12,6 +12,8 @@ Scope: the branches optimal.yaml disables -- population prior / MoG 
 NotImplementedError instead of silently computing something else.  Image crops [B, X, Y, Z, C]
  take the layer-wise spatial kernels; voxel batches the fused ones.
 """
+import math
+
 import numpy as np
 import torch
 
@@ -154,6 +156,13 @@ class FineTuner:
         self.encoder_model = encoder_model
         self.signal_generation_layer = signal_generation_layer
         self._rpl = ReparamTrickLayer(trainer)
+        # heteroscedastic_noise=False (model.py:277-281): ONE exp-activated scalar, a variable of the fine-tuner
+        # (not of the encoder: the weight files do not carry it), initial value log(initial_im_sigma)
+        self.log_sigma = None if trainer._heteroscedastic_noise else math.log(float(trainer._initial_im_sigma))
+        # use_population_prior with the diagonal family (model.py:262-271): a 4-vector variable of the fine-tuner,
+        # [mu_oef, raw_s_oef, mu_dbv, raw_s_dbv], appended to 'predictions' as constant channels
+        self.pop_prior = (np.array([-0.97, 0.4, -1.14, 0.6], np.float32)
+                          if trainer._use_population_prior else None)
 
     def __call__(self, inputs):
         return self.predict(inputs)
@@ -166,7 +175,13 @@ class FineTuner:
         qs = torch.cat([q] * S, 0)          # model.py:245
         sig = torch.cat([sigma] * S, 0)     # model.py:246
         sampled = self._rpl((qs, mask))     # model.py:248
+        if self.pop_prior is not None:      # model.py:268-270
+            pp = torch.as_tensor(self.pop_prior, device=qs.device)
+            qs = torch.cat([qs, pp.expand(qs.shape[:-1] + (4,))], -1)
         output = self.signal_generation_layer(sampled)  # model.py:273
+        if self.log_sigma is not None:      # model.py:277-281: one channel holding the scalar sigma
+            sig = torch.full(output.shape[:-1] + (1,), math.exp(self.log_sigma), dtype=output.dtype,
+                             device=output.device)
         # 'predictions' is the S-fold tiled distribution, as in the reference (model.py:245,285)
         return {'predictions': qs, 'predicted_images': torch.cat([output, sig], -1)}
 
@@ -187,10 +202,15 @@ class FineTuner:
         m = None if mask is None else mask.reshape(-1)
         p5 = _pad5(_flat(prior, prior.shape[-1])).contiguous()
         K = kl_samples if tr._use_mvg else 0   # diagonal family: closed-form KL below (model.py:686-716)
-        if tr._is_spatial(data):
+        if self.pop_prior is not None:   # the per-voxel prior is ignored (model.py:687-690): one population prior
+            p5 = _pad5(torch.as_tensor(self.pop_prior, device=x.device).expand(x.shape[0], 4)).contiguous()
+        if tr._is_spatial(data) or self.log_sigma is not None:
             _, q5, sg5 = self.encoder_model.predict(data, want=("out2", "sigma"))
             q = _pad5(_flat(q5, q5.shape[-1])).contiguous()
-            sums, nll_kl = tr._ctx.elbo_fwd(x, m, q, p5, _flat(sg5, x.shape[-1]), S, K, seed=seed, voxel0=voxel0)
+            sg = _flat(sg5, x.shape[-1])
+            if self.log_sigma is not None:   # the encoder's sigma head is not part of this model (model.py:277-281)
+                sg = torch.full_like(sg, math.exp(self.log_sigma))
+            sums, nll_kl = tr._ctx.elbo_fwd(x, m, q, p5, sg, S, K, seed=seed, voxel0=voxel0)
         else:
             # range_check: activations beyond the f16 operand split's 65504 show as non-finite sums and are
             # recomputed on the exact-float32 layer-wise path (ops.Context.vi_fwd)
@@ -201,6 +221,8 @@ class FineTuner:
             sums[1] = ksums[1]
             nll_kl[:, 1] = kl_v
             q = q[:, :4].contiguous()
+            if self.pop_prior is not None:   # model.py:710-716: the hyper-prior's cost joins the KL numerator
+                sums[1] = sums[1] + tr.population_prior_cost(self.pop_prior, data.shape[0])
         return dict(sums=sums, q=q, nll_kl=nll_kl, nll=sums[0] / sums[2], kl=sums[1] / sums[2],
                     elbo=(sums[0] + sums[1]) / sums[2])
 
@@ -264,10 +286,13 @@ class EncoderTrainer:
             # (5 + 4) in two (tf.split(y_pred_orig, 2, axis=-1), model.py:455)
             unsupported.append("infer_inv_gamma with use_mvg=True (a shape error in the reference, model.py:455; "
                                "the learned hyper-prior runs with the diagonal family, use_mvg=False)")
-        if use_population_prior:
-            unsupported.append("use_population_prior (model.py:252-271)")
-        if not heteroscedastic_noise:
-            unsupported.append("heteroscedastic_noise=False (model.py:277-281)")
+        if use_population_prior and use_mvg:
+            # the reference cannot run this pair either: kl_loss hands the 10-channel 'predictions' to
+            # logit_gaussian_mvg_log_prob, which reshapes them to (-1, 5) and so doubles the rows (model.py:596, 378)
+            unsupported.append("use_population_prior with use_mvg=True (a shape error in the reference, model.py:596; "
+                               "the population prior runs with the diagonal family, use_mvg=False)")
+        if use_population_prior and mog_components > 1:
+            unsupported.append("mog_components > 1 (model.py:666-685)")
         if unsupported:
             raise NotImplementedError("configuration outside the accelerated path (disabled by "
                                       "configurations/optimal.yaml): " + "; ".join(unsupported))
@@ -435,16 +460,21 @@ class EncoderTrainer:
 
     # -- objective terms ---------------------------------------------------------------------
     def fine_tune_loss_fn(self, y_true, y_pred, return_mean=True):
-        """model.py:527-568.  y_true [..., T+1] = [data, mask]; y_pred [S*..., 2T] = [signal, sigma]."""
+        """model.py:527-568.  y_true [..., T+1] = [data, mask]; y_pred [S*..., 2T] = [signal, sigma], or
+        [S*..., T+1] = [signal, one channel of the scalar sigma] with heteroscedastic_noise=False (:535-537)."""
         T = self._ctx.T
         yt = _flat(y_true, T + 1)
-        yp = _flat(y_pred, 2 * T)
+        yp = _flat(y_pred, 2 * T if self._heteroscedastic_noise else T + 1)
         S = self._no_samples
         N = yt.shape[0]
         if yp.shape[0] != N * S:
             raise ValueError("y_pred must hold no_samples copies of the batch")
         mask = yt[:, T].contiguous()
-        nll = self._ctx.nll_fwd(yt[:, :T], mask, yp[:, :T], yp[:, T:], S)
+        if self._heteroscedastic_noise:
+            sig = yp[:, T:]
+        else:   # sigma = reduce_mean(y_pred[..., -1:]) (model.py:536): the mean of the constant channel
+            sig = yp[:, T:].mean().expand(yp.shape[0], T).contiguous()
+        nll = self._ctx.nll_fwd(yt[:, :T], mask, yp[:, :T], sig, S)
         nll = nll * mask.repeat(S)                       # model.py:564
         if return_mean:
             return nll.sum() / (mask.sum() * S)          # model.py:566 (mask is tiled S times)
@@ -462,20 +492,39 @@ class EncoderTrainer:
 
     def kl_loss(self, true, predicted, return_mean=True, no_samples=70, seed=None):  # model.py:654-724
         true = torch.cat([true] * self._no_samples, 0)
-        if not self._use_mvg:  # closed form per dimension, model.py:686-721 (no population prior)
+        if not self._use_mvg:  # closed form per dimension, model.py:686-721
             pr = _flat(true, 5)   # [p_oef_mean, p_oef_log_std, p_dbv_mean, p_dbv_log_std, mask]
-            _, kl = self._ctx.kl_diag(_pad5(_flat(predicted, predicted.shape[-1])[:, :4]).contiguous(),
-                                      _pad5(pr[:, :4]).contiguous())
+            pred = _flat(predicted, predicted.shape[-1])
+            prior_cost = 0.0
+            if self._use_population_prior:   # 'predictions' = [q4 | population prior 4]; `true` gives the mask only
+                if pred.shape[-1] != 8:
+                    raise ValueError("use_population_prior: predictions must carry 4 + 4 channels (model.py:268-270)")
+                prior4 = pred[:, 4:8]
+                prior_cost = self.population_prior_cost(prior4[0], predicted.shape[0])
+            else:
+                prior4 = pr[:, :4]
+            _, kl = self._ctx.kl_diag(_pad5(pred[:, :4]).contiguous(), _pad5(prior4).contiguous())
             kl_op = kl.reshape(predicted.shape[:-1] + (1,))
             mask = true[..., 4:5]
             kl_op = torch.where(mask > 0, kl_op, torch.zeros_like(kl_op))
-            return kl_op.sum() / mask.sum() if return_mean else kl_op
+            return (kl_op.sum() + prior_cost) / mask.sum() if return_mean else kl_op
         kl_op = self.mvg_kl_samples(true, predicted, no_samples=no_samples, seed=seed)
         mask = true[..., 5:6]
         kl_op = torch.where(mask > 0, kl_op, torch.zeros_like(kl_op))
         if return_mean:
             return kl_op.sum() / mask.sum()
         return kl_op
+
+    def population_prior_cost(self, prior4, batch):
+        """model.py:710-716: -log IG(1, 2) of exp(2 * log-std) for the population prior's DBV and OEF log-stds (after
+        transform_std), times the size of the batch axis (tf.shape(predicted)[0]).  Four scalars: host float64."""
+        p = [float(v) for v in (prior4.tolist() if hasattr(prior4, "tolist") else prior4)]
+        cost = 0.0
+        for raw in (p[3], p[1]):
+            log_std = 3.0 * math.tanh(raw) - 1.0
+            v = math.exp(2.0 * log_std)
+            cost -= math.log(2.0) - 2.0 * math.log(v) - 2.0 / v     # log IG(v; 1, 2)
+        return cost * float(batch)
 
     def smoothness_loss(self, true_params, pred_params):
         """Total-variation term (model.py:726-754): sum of |differences| of the range-scaled

@@ -87,6 +87,7 @@ def create_encoder_model(config_dict, params, device=None):
                              infer_inv_gamma=_get(config_dict, "infer_inv_gamma"),
                              use_population_prior=_get(config_dict, "use_population_prior"),
                              use_mvg=_get(config_dict, "use_mvg"),
+                             heteroscedastic_noise=_get(config_dict, "heteroscedastic_noise", True),
                              predict_log_data=_get(config_dict, "predict_log_data"),
                              no_samples=max(1, int(_get(config_dict, "mc_samples", 1) or 1)),
                              full_model=_get(config_dict, "full_model", True),
@@ -156,6 +157,40 @@ class HyperPriorState:
         th = self.model.hyper_raw
         th = th - wd * th
         self.model.hyper_raw = th - lr_t * self.m / (np.sqrt(self.v) + eps)
+
+
+class ScalarAdamW:
+    """One host-side scalar under the fine-tuning optimiser (tfa AdamW: decoupled decay, Keras Adam moments and
+    bias correction, eps 1e-7) -- the exp-activated sigma variable of heteroscedastic_noise=False
+    (model.py:277-281), which belongs to the fine-tuner, not to the encoder's weight blob."""
+
+    def __init__(self, value):
+        self.value, self.m, self.v, self.t = float(value), 0.0, 0.0, 0
+
+    def step(self, g, lr, wd, beta1=0.9, beta2=0.999, eps=1e-7):
+        self.t += 1
+        self.m = beta1 * self.m + (1 - beta1) * g
+        self.v = beta2 * self.v + (1 - beta2) * g * g
+        lr_t = lr * math.sqrt(1 - beta2 ** self.t) / (1 - beta1 ** self.t)
+        self.value = self.value - wd * self.value - lr_t * self.m / (math.sqrt(self.v) + eps)
+        return self.value
+
+
+def _fine_tuner_guards(trainer, full_model):
+    if getattr(full_model, "pop_prior", None) is not None:
+        # train.py:318-320 always adds smoothness_loss, which splits the 8-channel 'predictions' of the population
+        # prior into 4 groups and fails on the range division (model.py:729-739): the reference cannot fine-tune
+        # with it; the evaluation side (kl_loss, FineTuner.elbo) is built
+        raise NotImplementedError("fine-tuning with use_population_prior: the reference's own smoothness_loss "
+                                  "raises a shape error on its 8-channel predictions (model.py:729-739)")
+    homo = getattr(full_model, "log_sigma", None) is not None
+    # heteroscedastic_noise=False: the encoder's sigma head is outside the trained graph (gradient None: no update,
+    # no decay); one scalar log sigma is optimised instead
+    ranges = None
+    if homo:
+        w = full_model.encoder_model.weights
+        ranges = w.param_ranges([n for n in w.NAMES if n not in ("Ws", "bs")])
+    return (ScalarAdamW(full_model.log_sigma) if homo else None), ranges
 
 
 def prepare_synthetic_dataset(x, y):
@@ -322,6 +357,7 @@ def _train_full_model_crops(config_dict, trainer, full_model, study_dataset, tra
     gv = torch.Generator(device=dev)
     gv.manual_seed(3)
     step = 0
+    sigma_opt, ranges = _fine_tuner_guards(trainer, full_model)
     nxt = train_dataset.next_batch(g)
     for epoch in range(int(_get(config_dict, "no_ft_epochs"))):
         tot = torch.zeros(4, dtype=torch.float64, device=dev)
@@ -329,19 +365,25 @@ def _train_full_model_crops(config_dict, trainer, full_model, study_dataset, tra
             x5, m5, p5 = nxt
             n = m5.numel()
             q, ls = state.forward_spatial(x5)
+            if sigma_opt:
+                ls = torch.full_like(ls, sigma_opt.value)
             sums, gq, gls = _elbo_bwd(trainer, x5.reshape(n, -1), m5.reshape(n), q, p5.reshape(n, 5), ls, S,
                                       kl_samples, 1000 + step, rank * n)
             tv = ctx.smoothness(q.reshape(m5.shape + (5,)), m5, weight=sw, g_q=gq)
-            red = torch.cat([sums, tv])
+            red = torch.cat([sums, tv] + ([gls.sum(dtype=torch.float64).reshape(1)] if sigma_opt else []))
             qd.allreduce_(red, "allreduce_sums")
-            state.backward_spatial(gq, gls, red[:3].contiguous())
+            g_sigma = float(red[4] / red[2]) if sigma_opt else None
+            red = red[:4]
+            state.backward_spatial(gq, None if sigma_opt else gls, red[:3].contiguous())
             # the gradient all-reduce runs on RCCL's stream while this rank draws and gathers its next crops
             work = qd.allreduce_grad_(state.grad, async_op=True)
             nxt = train_dataset.next_batch(g)
             if work is not None:
                 work.wait()
             wd = lr_schedule(decay0, step, steps_per_epoch) if decay0 > 0.0 else 0.0
-            state.adamw(lr_schedule(lr0, step, steps_per_epoch), wd, 0.9, beta2, 1e-7)
+            state.adamw(lr_schedule(lr0, step, steps_per_epoch), wd, 0.9, beta2, 1e-7, ranges=ranges)
+            if sigma_opt:
+                full_model.log_sigma = sigma_opt.step(g_sigma, lr_schedule(lr0, step, steps_per_epoch), wd, 0.9, beta2)
             tot += red
             step += 1
             if max_steps and step >= max_steps:
@@ -400,15 +442,22 @@ def train_full_model(config_dict, trainer, full_model, study_dataset, train_data
         sel = idx[a:b]
         return a, x[sel], mask[sel], prior[sel]
 
+    sigma_opt, ranges = _fine_tuner_guards(trainer, full_model)
     nxt = draw_batch()
     for epoch in range(int(_get(config_dict, "no_ft_epochs"))):
         tot = torch.zeros(3, dtype=torch.float64, device=x.device)
         for _ in range(steps_per_epoch):
             a, xb, mb, pb = nxt
             q2, ls = state.forward(xb, 2)
+            if sigma_opt:
+                ls = torch.full_like(ls, sigma_opt.value)
             sums, gq, gls = _elbo_bwd(trainer, xb, mb, q2, pb, ls, S, kl_samples, 1000 + step, a)
+            if sigma_opt:   # d loss / d log sigma = sum over voxels and taus of the per-tau gradients / sum(mask)
+                sums = torch.cat([sums, gls.sum(dtype=torch.float64).reshape(1)])
             qd.allreduce_sums(sums)          # global sum(mask) before the gradient is normalised
-            state.backward(2, gq, gls, sums)
+            if sigma_opt:
+                g_sigma, sums = float(sums[3] / sums[2]), sums[:3].contiguous()
+            state.backward(2, gq, None if sigma_opt else gls, sums)
             # shard gradients add up (same 1/sum(m)); the all-reduce runs on RCCL's stream while this rank
             # draws and gathers its next batch (the next forward itself needs the updated weights)
             work = qd.allreduce_grad_(state.grad, async_op=True)
@@ -416,7 +465,9 @@ def train_full_model(config_dict, trainer, full_model, study_dataset, train_data
             if work is not None:
                 work.wait()
             wd = lr_schedule(decay0, step, steps_per_epoch) if decay0 > 0.0 else 0.0
-            state.adamw(lr_schedule(lr0, step, steps_per_epoch), wd, 0.9, beta2, 1e-7)
+            state.adamw(lr_schedule(lr0, step, steps_per_epoch), wd, 0.9, beta2, 1e-7, ranges=ranges)
+            if sigma_opt:
+                full_model.log_sigma = sigma_opt.step(g_sigma, lr_schedule(lr0, step, steps_per_epoch), wd, 0.9, beta2)
             tot += sums
             step += 1
             if max_steps and step >= max_steps:

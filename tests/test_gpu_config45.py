@@ -79,10 +79,10 @@ def test_eight_shards_of_4m_voxels_equal_the_32m_voxel_job(job, oracle32, precis
             assert not torch.equal(s_bad, s_ok)
     assert torch.allclose(acc, whole, rtol=1e-9, atol=0)   # what the all-reduce adds up == the one-launch job
     assert float(whole[2]) == float(mask.double().sum())
-    # oracle windows in shards 0, 3 and 7: global Philox keys beyond 2^24 (float32 cannot hold them exactly)
-    for r, off in ((0, 1_000), (3, 2_222_222), (7, SHARD - 1536)):
+    # oracle windows in shards 0, 3, 4 and 7: global Philox keys up to and beyond 2^24 (float32 cannot hold them exactly)
+    for r, off in ((0, 1_000), (3, 2_222_222), (4, 17), (7, SHARD - 1536)):
         v0, n = r * SHARD + off, 1536
-        assert r == 0 or v0 > (1 << 24)
+        assert r < 4 or v0 > (1 << 24)
         xs, ms, ps = (t[v0:v0 + n].cpu().numpy() for t in (x, mask, prior))
         qg = q_all[v0:v0 + n].cpu().numpy()
         if precision == "f32":

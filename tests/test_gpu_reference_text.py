@@ -260,3 +260,44 @@ def test_fine_tuner_elbo_from_the_reference_text(params):
     close(nk[:, 1].cpu().numpy() * (m > 0), kl_rows.reshape(S, n).mean(0), rtol=1e-4, atol=1e-4)
     true_c = dev(np.concatenate([prior, mask[..., None]], -1))
     close(tr.smoothness_loss(true_c, torch.cat([q] * S)), g("fine_tuner", "smoothness"), rtol=2e-5)
+
+
+def test_population_prior_kl_diag(params):
+    """kl_loss with use_population_prior and the diagonal family (model.py:687-716)."""
+    q, prior, mask = g("kl/sampled", "q", "prior", "mask")
+    pop = g("kl/population_diag", "pop_prior")
+    n = len(q)
+    tp = trainer(params, use_mvg=False, use_population_prior=True, mog_components=1)
+    true5 = dev(np.concatenate([prior[:, :4], mask[:, None]], -1).reshape(n, 1, 1, 1, 5))
+    pred8 = dev(np.concatenate([q[:, :4], np.broadcast_to(pop, (n, 4))], -1).reshape(n, 1, 1, 1, 8))
+    close(tp.kl_loss(true5, pred8), g("kl/population_diag", "mean"), rtol=1e-4)
+    close(tp.kl_loss(true5, pred8, return_mean=False).reshape(n), g("kl/population_diag", "per_voxel"), rtol=1e-4, atol=1e-5)
+    with pytest.raises(NotImplementedError, match="shape error in the reference"):
+        trainer(params, use_mvg=True, use_population_prior=True)
+
+
+def test_homoscedastic_fine_tuner(params):
+    """heteroscedastic_noise=False (model.py:277-281, 535-537)."""
+    from qbold_vi_amd.signals import SignalGenerationLayer
+    data, zs, imgs = g("fine_tuner_homoscedastic", "data", "zs", "predicted_images")
+    s0 = float(g("fine_tuner_homoscedastic", "initial_im_sigma"))
+    tr, model = encoder_of(params, "fine_tuner_homoscedastic", heteroscedastic_noise=False, initial_im_sigma=s0)
+    full = tr.build_fine_tuner(model, SignalGenerationLayer(dict(params, simulate_noise="False"), True, True))
+    n = len(data)
+    x5 = dev(data.reshape(n, 1, 1, 1, 11))
+    m5 = torch.ones(n, 1, 1, 1, 1, device="cuda")
+    out = full([x5, m5])                                    # the library's own draws: shapes and the sigma channel
+    assert tuple(out["predicted_images"].shape) == (n, 1, 1, 1, 12) and tuple(out["predictions"].shape) == (n, 1, 1, 1, 5)
+    close(out["predicted_images"][..., 11].reshape(n), np.full(n, s0), rtol=1e-6)
+    # the reference's draws
+    q = model(x5)[1]
+    signal = full.signal_generation_layer(full._rpl((q, None), z=dev(zs)))
+    close(signal.reshape(n, 11), imgs[:, :11], rtol=3e-5)
+    y_pred = torch.cat([signal, torch.full((n, 1, 1, 1, 1), s0, device="cuda")], -1)
+    close(tr.fine_tune_loss_fn(torch.cat([x5, m5], -1), y_pred), g("fine_tuner_homoscedastic", "nll"), rtol=2e-5)
+    # the fused evaluation uses the scalar, not the encoder's sigma head
+    prior = model(x5)[0].reshape(n, 5)
+    e = full.elbo(x5, m5, prior, no_samples=64, kl_samples=8, seed=3)
+    sg = torch.full((n, 11), s0, device="cuda")
+    sums, _ = tr.context.elbo_fwd(dev(data), None, q.reshape(n, 5).contiguous(), prior, sg, 64, 8, seed=3)
+    assert torch.equal(e["sums"], sums)

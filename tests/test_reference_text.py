@@ -252,3 +252,32 @@ def test_fine_tuner_elbo_from_the_reference_text(oracle32):
     close(out["elbo"], g("fine_tuner", "neg_elbo"), rtol=1e-4)                 # the north-star's ELBO tolerance
     close(oracle32.smoothness_loss(np.concatenate([q] * S), np.concatenate([mask] * S)), g("fine_tuner", "smoothness"),
           rtol=2e-5)
+
+
+def test_population_prior_kl_diag(oracle32):
+    """kl_loss with use_population_prior (diagonal family, model.py:687-716): every voxel against ONE prior carried
+    in the predictions, plus the inverse-gamma cost on that prior times the batch axis."""
+    q, prior, mask = g("kl/sampled", "q", "prior", "mask")
+    pop = g("kl/population_diag", "pop_prior")
+    n = len(q)
+    pop5 = np.concatenate([np.broadcast_to(pop, (n, 4)), np.zeros((n, 1), np.float32)], -1)
+    kd = oracle32.kl_diag(q, pop5) * (mask > 0)
+    close(kd, g("kl/population_diag", "per_voxel"), rtol=1e-4, atol=1e-5)
+    cost = oracle32.population_prior_cost(pop, n)        # the fixture's batch axis is the voxel axis: [N,1,1,1,8]
+    close((kd.astype(np.float64).sum() + cost) / mask.sum(), g("kl/population_diag", "mean"), rtol=1e-4)
+    assert abs(cost) > 1.0
+
+
+def test_homoscedastic_fine_tuner(params, oracle32):
+    """heteroscedastic_noise=False (model.py:277-281, 535-537): 'predicted_images' = [signal, one channel holding
+    the exp-activated scalar], and fine_tune_loss_fn scores every tau with that one sigma."""
+    w = weights_of("fine_tuner_homoscedastic")
+    data, zs, imgs = g("fine_tuner_homoscedastic", "data", "zs", "predicted_images")
+    s0 = float(g("fine_tuner_homoscedastic", "initial_im_sigma"))
+    assert imgs.shape == (64, 12)
+    close(imgs[:, 11], np.full(64, s0), rtol=1e-6)
+    _, q, _ = oracle32.encoder_fwd(centre_taps(w), data)
+    pred = oracle32.signal_fwd(oracle32.reparam(q, zs))
+    close(pred, imgs[:, :11], rtol=3e-5)
+    nll = oracle32.nll(data, np.ones(64, np.float32), pred, np.full_like(pred, s0))
+    close(nll.astype(np.float64).mean(), g("fine_tuner_homoscedastic", "nll"), rtol=2e-5)
