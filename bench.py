@@ -566,11 +566,12 @@ def main():
     ap.add_argument("--cpu_budget_s", type=float, default=15.0)
     args = ap.parse_args()
     if os.environ.get("QBOLD_DEBUG_SKIP", "0") not in ("", "0"):
-        os.environ["QBOLD_ALLOW_ABLATION"] = "1"   # the library ignores QBOLD_DEBUG_SKIP without it
-        # the ablation hooks of the kernels (phases switched off for timing experiments)
-        # must never reach a reported number
-        print("bench.py: QBOLD_DEBUG_SKIP is set -- kernels would skip work; this run is an ablation, not a "
-              "benchmark", file=sys.stderr)
+        # The default build of the library has no ablation hook at all (they compile in only with -DQBOLD_ABLATION,
+        # scripts/dev/build_ablation.sh); with such a build loaded, the run is marked so that the phases switched
+        # off for timing experiments never reach a reported number.
+        os.environ["QBOLD_ALLOW_ABLATION"] = "1"
+        print("bench.py: QBOLD_DEBUG_SKIP is set -- an ablation build of the library would skip work; this run is an "
+              "ablation, not a benchmark", file=sys.stderr)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under torchrun: become the launcher BEFORE anything touches the GPU (torch is not even imported)

@@ -128,6 +128,23 @@ int qbold_ctx_tissue_mode(const qbold_ctx* ctx);
  * Simpson sum over all 129 nodes; 0 = the exact derivative of the float32 forward value, in which
  * node 0 is flat.  They differ by 1.95e-3 * x. */
 int qbold_ctx_set_grad_node0(qbold_ctx* ctx, int on);
+/* Which of several EQUIVALENT kernels an entry point dispatches to (default 0 = the fastest form of each).  Every bit
+ * selects an older / simpler kernel that computes the same result; the tests use them to hold the fused kernels to
+ * the layer-wise ones.  No bit skips work (the work-skipping hooks of the timing experiments exist only in
+ * -DQBOLD_ABLATION builds, scripts/dev/build_ablation.sh). */
+#define QBOLD_KSEL_RUNTIME_SE_IDX 4          /* ELBO kernels: run-time instead of compile-time spin-echo index */
+#define QBOLD_KSEL_CONV_PER_TAP 256          /* 3x3x1 convolution as nine gathered GEMM launches */
+#define QBOLD_KSEL_GENERAL_GEMM 512          /* layer GEMMs on the general xw_kernel */
+#define QBOLD_KSEL_SEPARATE_GATE 2048        /* gate blend as its own launch */
+#define QBOLD_KSEL_SEPARATE_BWD_DATA 4096    /* a block's two backward-data GEMMs as two launches */
+#define QBOLD_KSEL_SEPARATE_FORK 8192        /* skip / t of a block as two GEMMs */
+#define QBOLD_KSEL_PER_HEAD_BWD 16384        /* one backward pass per head */
+#define QBOLD_KSEL_PER_HEAD_FWD 32768        /* one forward GEMM per head */
+#define QBOLD_KSEL_CONV_EXACT_F32 65536      /* 3x3x1 convolution on the f32-input MFMA */
+#define QBOLD_KSEL_LAYERWISE_BWD 131072      /* voxel batches: layer-wise backward instead of the one-launch block kernels */
+#define QBOLD_KSEL_BLOCK_BWD_SPLIT_DW 262144 /* block backward with separate weight-gradient launches */
+#define QBOLD_KSEL_ALL (4 | 256 | 512 | 2048 | 4096 | 8192 | 16384 | 32768 | 65536 | 131072 | 262144)
+int qbold_ctx_set_kernel_selection(qbold_ctx* ctx, int mask);
 /* Host-side evaluation of the uploaded table (for tests): F(x) and dF/dx, HOST arrays. */
 int qbold_ctx_table_eval(const qbold_ctx* ctx, const float* host_x, float* host_F, float* host_dF,
                          int64_t n);
@@ -202,6 +219,12 @@ int qbold_reparam(const qbold_ctx* ctx, const float* q, const float* z, float* o
  * y [N][2] under params [N][5] -> out [N]. */
 int qbold_logit_mvn_nlogp(const qbold_ctx* ctx, const float* y, const float* params, float* out,
                           int64_t N, void* stream);
+/* EncoderTrainer.squared_whitened_residual (model.py:423-441) = LogitMVN.squared_whitened_residual
+ * (logit_mvn.py:20-38), a static method there and context-free here: obs, mean [N][2]; oef_log_std, dbv_log_std,
+ * oef_dbv_cov [N] (already transformed) -> out [N] = || L^-1 (obs - mean) ||^2. */
+int qbold_squared_whitened_residual(const float* obs, const float* mean, const float* oef_log_std,
+                                    const float* dbv_log_std, const float* oef_dbv_cov, float* out, int64_t N,
+                                    void* stream);
 /* calculate_means(include_r2p=True, return_stds=True) (model.py:318-343): q [N][5] ->
  * means [N][3], vars [N][3] over n_samples reparameterised draws.  z = explicit normals
  * [N][n_samples][2] or NULL for the in-kernel Philox stream (seed, global voxel = voxel0+i). */

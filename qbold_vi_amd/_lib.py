@@ -58,6 +58,8 @@ SIGNATURES = {
     "qbold_ctx_set_tissue_mode": (C.c_int, [_P, C.c_int]),
     "qbold_ctx_tissue_mode": (C.c_int, [_P]),
     "qbold_ctx_set_grad_node0": (C.c_int, [_P, C.c_int]),
+    "qbold_ctx_set_kernel_selection": (C.c_int, [_P, C.c_int]),
+    "qbold_squared_whitened_residual": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P]),
     "qbold_ctx_table_eval": (C.c_int, [_P, _P, _P, _P, _I64]),
     "qbold_signal_fwd": (C.c_int, [_P, _P, _P, _I64, _P]),
     "qbold_signal_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _P]),

@@ -111,14 +111,18 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
         return QBOLD_ERR_INVALID;
     }
     d.tissue_mode = QBOLD_TISSUE_TABLE;
-    // Ablation hooks of the timing experiments: honoured only together with
-    // QBOLD_ALLOW_ABLATION=1, which bench.py and the scripts/ harnesses set for such runs and which marks their
-    // output as an ablation.  A stray QBOLD_DEBUG_SKIP in the environment of train.py or of a library user is
-    // ignored (its result-changing bits would otherwise skip work silently).
+#ifdef QBOLD_ABLATION
+    // Ablation build only (scripts/dev/build_ablation.sh; never the library the tests, the driver or bench.py load):
+    // QBOLD_DEBUG_SKIP switches phases of the kernels off for the timing experiments of DESIGN 4.4 / 4.5 / 4.7 and
+    // selects among equivalent kernels; honoured only together with QBOLD_ALLOW_ABLATION=1.
     if (const char* dbg = getenv("QBOLD_DEBUG_SKIP")) {
         const char* allow = getenv("QBOLD_ALLOW_ABLATION");
-        if (allow && atoi(allow) == 1) d.debug_skip = atoi(dbg);
+        if (allow && atoi(allow) == 1) {
+            d.debug_skip = atoi(dbg);
+            ctx->kernel_sel = atoi(dbg);
+        }
     }
+#endif
 
     d.dw_coef = (float)((4.0 / 3.0) * M_PI * P->gamma * P->b0 * P->dchi * P->hct);
     d.dw_coef_nohct = (float)((4.0 / 3.0) * M_PI * P->gamma * P->b0 * P->dchi);
@@ -240,6 +244,12 @@ extern "C" int qbold_ctx_set_tissue_mode(qbold_ctx* ctx, int mode) {
 extern "C" int qbold_ctx_set_grad_node0(qbold_ctx* ctx, int on) {
     QB_REQUIRE(ctx, "qbold_ctx_set_grad_node0: null ctx");
     ctx->dev.dF_node0 = on ? ctx->dF_node0_ref : 0.0f;
+    return QBOLD_OK;
+}
+extern "C" int qbold_ctx_set_kernel_selection(qbold_ctx* ctx, int mask) {
+    QB_REQUIRE(ctx, "qbold_ctx_set_kernel_selection: null ctx");
+    QB_REQUIRE((mask & ~QBOLD_KSEL_ALL) == 0, "qbold_ctx_set_kernel_selection: unknown bit");
+    ctx->kernel_sel = mask;
     return QBOLD_OK;
 }
 extern "C" int qbold_ctx_tissue_mode(const qbold_ctx* ctx) {

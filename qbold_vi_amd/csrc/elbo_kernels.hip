@@ -575,7 +575,7 @@ namespace qb {
 // the 64-tau protocol with tau = 0 (up to float32 rounding of the grid) at index 12: see elbo_fwd_launch
 bool elbo_logsigma_path(const qbold_ctx* ctx) {
     return ctx->dev.T == 64 && elbo_fast_path(ctx) && ctx->dev.se_idx == 12 && !ctx->dev.multi_norm &&
-           !(ctx->dev.debug_skip & 4) && std::fabs(std::fmaf(12.0f, ctx->dev.tauh_step, ctx->dev.tauh0)) < 1e-6f;
+           !(ctx->kernel_sel & 4) && std::fabs(std::fmaf(12.0f, ctx->dev.tauh_step, ctx->dev.tauh0)) < 1e-6f;
 }
 }  // namespace qb
 
@@ -752,6 +752,36 @@ extern "C" int qbold_logit_mvn_nlogp(const qbold_ctx* ctx, const float* y, const
     QB_REQUIRE(N > 0 && y && params && out, "qbold_logit_mvn_nlogp: bad argument");
     hipLaunchKernelGGL(nlogp_kernel, dim3(ew_grid(ctx, N, 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float2*>(y), params, out, N);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
+// squared_whitened_residual (model.py:423-441 = logit_mvn.py:20-38): || L^-1 (obs - mean) ||^2 with the Cholesky
+// factor L = [[e^so, 0], [cov, e^sd]] -- a static method of the reference (no distribution object, no context).
+__global__ void swr_kernel(const float2* __restrict__ obs, const float2* __restrict__ mean, const float* __restrict__ so,
+                           const float* __restrict__ sd, const float* __restrict__ cov, float* __restrict__ out,
+                           int64_t N) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const float2 o = obs[i], m = mean[i];
+        const float a = so[i], b = sd[i];
+        const float inv_tl = __expf(-a), inv_br = __expf(-b);
+        const float inv_bl = __expf(-a - b) * cov[i] * -1.0f;            // :431-433
+        const float r0 = o.x - m.x, r1 = o.y - m.y;
+        const float w0 = r0 * inv_tl, w1 = r1 * inv_br + r0 * inv_bl;    // :435-436
+        out[i] = w0 * w0 + w1 * w1;
+    }
+}
+
+extern "C" int qbold_squared_whitened_residual(const float* obs, const float* mean, const float* oef_log_std,
+                                               const float* dbv_log_std, const float* oef_dbv_cov, float* out,
+                                               int64_t N, void* stream) {
+    if (N == 0) return QBOLD_OK;
+    QB_REQUIRE(N > 0 && obs && mean && oef_log_std && dbv_log_std && oef_dbv_cov && out,
+               "qbold_squared_whitened_residual: bad argument");
+    const int64_t nb = (N + 255) / 256;
+    hipLaunchKernelGGL(swr_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float2*>(obs), reinterpret_cast<const float2*>(mean), oef_log_std,
+                       dbv_log_std, oef_dbv_cov, out, N);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }

@@ -19,6 +19,7 @@ struct qbold_ctx {
     std::vector<float> h_tab;       // host copy (4 floats per segment)
     int num_cus = 256;
     float dF_node0_ref = 0.0f;      // TF-gradient slope of Simpson node 0 (see qbold_ctx_set_grad_node0)
+    int kernel_sel = 0;             // qbold_ctx_set_kernel_selection: which of several EQUIVALENT kernels runs
 };
 
 namespace qb {

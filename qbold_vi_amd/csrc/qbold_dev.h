@@ -18,7 +18,9 @@
 struct QbDev {
     int T, se_idx, full_model, include_blood;
     int multi_norm, predict_log, use_student_t, tissue_mode;
-    int debug_skip;  // diagnostics only (env QBOLD_DEBUG_SKIP): 1 = no encoder MFMA, 2 = no sampling
+#ifdef QBOLD_ABLATION
+    int debug_skip;  // timing experiments only (-DQBOLD_ABLATION builds of scripts/): 1 = no encoder MFMA, 2 = no sampling
+#endif
     float dw_coef;   // (4/3) pi gamma b0 dchi hct                      signals.py:144
     float dw_coef_nohct;  // the same without hct (variable_hct)        signals.py:64-70
     float e_te_r2t;  // exp(-te*r2t)                                    signals.py:172
@@ -41,6 +43,17 @@ struct QbDev {
     float taus[QB_MAX_T];
     float blood_B[QB_MAX_T];  // bracket of signals.py:242-247 per tau
 };
+
+// Work-skipping hooks of the timing experiments.  They exist only in builds made with
+// -DQBOLD_ABLATION (scripts/dev/build_ablation.sh); in the library the driver, the tests and bench.py load they are
+// the constant 0 and the guarded code is unconditional.
+#ifdef QBOLD_ABLATION
+#define QB_ABLATE(c, bit) ((c).debug_skip & (bit))
+#define QB_ABLATE_MASK(c) ((c).debug_skip)
+#else
+#define QB_ABLATE(c, bit) 0
+#define QB_ABLATE_MASK(c) 0
+#endif
 
 namespace qb {
 

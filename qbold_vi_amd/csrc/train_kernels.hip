@@ -1828,7 +1828,7 @@ struct Launcher {
         const bool aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (ldx & 3) == 0 && ldx >= 64 &&
                              (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && (ldy & 3) == 0 && ldy >= 64 &&
                              (!mask || ((reinterpret_cast<uintptr_t>(mask) & 15) == 0 && (ld & 3) == 0 && ld >= 64));
-        if (aligned && kdim <= 64 && ndim <= 64 && gather.Z == 0 && !(ctx->dev.debug_skip & 512)) {
+        if (aligned && kdim <= 64 && ndim <= 64 && gather.Z == 0 && !(ctx->kernel_sel & 512)) {
             auto kern = accum ? (mask ? xw64_kernel<true, true> : xw64_kernel<true, false>)
                               : (mask ? xw64_kernel<false, true> : xw64_kernel<false, false>);
             hipLaunchKernelGGL(kern, dim3(grid()), dim3(256), smem, s, X, ldx, kdim, W, ldw, trans, b, Y, ldy, ndim,
@@ -1843,7 +1843,7 @@ struct Launcher {
     // flip = 1 is the adjoint wrt the input (taps mirrored, kernels transposed).
     void conv3x3(const float* X, const float* K9, int U, const float* b, float* Y, int act, int flip,
                  const float* mask, const qbold_geometry& gm) {
-        if (U <= 64 && ld == kLd && !(ctx->dev.debug_skip & 256)) {  // one launch, accumulators in registers
+        if (U <= 64 && ld == kLd && !(ctx->kernel_sel & 256)) {  // one launch, accumulators in registers
             const int64_t nb = (N + 255) / 256;
             const int64_t cap = (int64_t)ctx->num_cus;
             const size_t smem = sizeof(float) * 9 * 64 * kWs;
@@ -1851,7 +1851,7 @@ struct Launcher {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             const bool aligned = ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) |
                                    reinterpret_cast<uintptr_t>(mask)) & 15) == 0;
-            if (aligned && !(ctx->dev.debug_skip & 65536)) {   // split-f16 matrix pipe (bit 65536: the exact-f32 form)
+            if (aligned && !(ctx->kernel_sel & 65536)) {   // split-f16 matrix pipe (bit 65536: the exact-f32 form)
                 const size_t smh = sizeof(float) * (9 * 4096 + 64);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9h_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smh);
@@ -1990,7 +1990,7 @@ static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             const float* wb = w + c.blk0 + l * c.blk_stride;
             float* skip = slot(2 + 5 * l), *t = slot(3 + 5 * l), *r = slot(4 + 5 * l);
             float* gl = slot(5 + 5 * l), *bout = slot(6 + 5 * l);
-            const bool fork = !gm && U <= 64 && ld == kLd && !(ctx->dev.debug_skip & 8192);
+            const bool fork = !gm && U <= 64 && ld == kLd && !(ctx->kernel_sel & 8192);
             if (!fork) k.xw(cur, ld, U, wb + c.Wc, U, 0, wb + c.bc, skip, U, ACT_RELU, 0, nullptr);
             // relu(b) feeds the first residual conv (model.py:151): applied to the rows as they are loaded
             if (gm) {  // 3x3x1 'same' convolutions, model.py:152-157
@@ -2005,7 +2005,7 @@ static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                     k.xw(cur, ld, U, wb + c.Wr1 + ctr, U, 0, wb + c.br1, t, U, ACT_RELU | ACT_RELU_IN, 0, nullptr);
                 k.xw(t, ld, U, wb + c.Wr2 + ctr, U, 0, wb + c.br2, r, U, ACT_NONE, 0, nullptr);
             }
-            const bool fuse_gate = G == U && U <= 64 && ld == kLd && !(ctx->dev.debug_skip & 2048) &&
+            const bool fuse_gate = G == U && U <= 64 && ld == kLd && !(ctx->kernel_sel & 2048) &&
                                    ((reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(gl) |
                                      reinterpret_cast<uintptr_t>(skip) | reinterpret_cast<uintptr_t>(bout)) & 15) == 0;
             if (fuse_gate) {   // gating GEMM with the blend as its epilogue
@@ -2022,7 +2022,7 @@ static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     // heads straight into the caller's [N][5] / [N][T] buffers
     (void)head;
     if (stream_sel == 2 && out_log_sigma && U <= 64 && ld == kLd && 5 + T <= 64 &&
-        (reinterpret_cast<uintptr_t>(cur) & 15) == 0 && !(ctx->dev.debug_skip & 32768)) {
+        (reinterpret_cast<uintptr_t>(cur) & 15) == 0 && !(ctx->kernel_sel & 32768)) {
         hipLaunchKernelGGL(xw64_heads_kernel, dim3(k.grid()), dim3(256), sizeof(float) * 64 * kWs, k.s, cur, ld, U,
                            w + c.Wf, w + c.bf, w + c.Ws, w + c.bs, T, out_q, out_log_sigma, N);
     } else {
@@ -2057,7 +2057,7 @@ extern "C" int qbold_encoder_spatial_fwd(const qbold_ctx* ctx, const qbold_encod
 static bool block_bwd_applies(const qbold_ctx* ctx, const qbold_encoder_shape* s, int64_t N) {
     return ctx && s && s->U >= 1 && s->U <= 64 && s->channelwise_gating && s->L >= 1 && s->L <= 2 && s->T <= 27 &&
            s->T == ctx->dev.T && s->precision == QBOLD_ENC_F32 && N > 0 && N < ((int64_t)1 << 23) &&
-           !(ctx->dev.debug_skip & 131072);
+           !(ctx->kernel_sel & 131072);
 }
 // ... and the one under which the block kernel also accumulates the weight gradients (block_bwd_dw_kernel)
 static int dw_grid(const qbold_ctx* ctx, int64_t N) {
@@ -2065,7 +2065,7 @@ static int dw_grid(const qbold_ctx* ctx, int64_t N) {
     return (int)(nb < ctx->num_cus ? nb : ctx->num_cus);
 }
 static bool block_bwd_dw_applies(const qbold_ctx* ctx, const qbold_encoder_shape* s, int64_t N) {
-    return block_bwd_applies(ctx, s, N) && !(ctx->dev.debug_skip & 262144) &&
+    return block_bwd_applies(ctx, s, N) && !(ctx->kernel_sel & 262144) &&
            4 * (int64_t)dw_grid(ctx, N) * (kDwThreads / 64) <= 8 * (int64_t)kSlabBlocks;
 }
 extern "C" int qbold_encoder_train_bwd_recomputes(const qbold_ctx* ctx, const qbold_encoder_shape* shape, int64_t N) {
@@ -2116,7 +2116,7 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     // the nine-tap kernel runs one 512-thread block per CU (144 accumulator registers per lane)
     const int slabs9 = (int)((N + 511) / 512 < ctx->num_cus ? ((N + 511) / 512 > 0 ? (N + 511) / 512 : 1)
                                                            : (ctx->num_cus < kSlabBlocks ? ctx->num_cus : kSlabBlocks));
-    if (stream_sel == 2 && g_ls && U <= 64 && ld == kLd && 5 + T <= 64 && !(ctx->dev.debug_skip & 16384)) {
+    if (stream_sel == 2 && g_ls && U <= 64 && ld == kLd && 5 + T <= 64 && !(ctx->kernel_sel & 16384)) {
         // both heads at once: one weight-gradient pass over the 5 + T delta columns (slab columns 0-4 -> Wf,
         // 5 .. -> Ws) and one backward-data GEMM with the stacked weights [Wf^T; Ws^T] -- instead of two
         // passes each, one of them over the unaligned column block dA + 5
@@ -2234,7 +2234,7 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                 k.xw(dD, ld, U, wb + c.Wr2 + ctr, U, 1, nullptr, dE, U, ACT_NONE, 0, t);
                 // first residual conv: input relu(b_in): dWr1 = relu(b_in)^T dE; d b_in = (dE Wr1^T) * (b_in > 0)
                 k.xtd(b_in, U, dE, U, partial, slabs, gb + c.Wr1 + ctr, U, gb + c.br1, 0, 1);
-                fused_in = U <= 64 && ld == kLd && !(ctx->dev.debug_skip & 4096);
+                fused_in = U <= 64 && ld == kLd && !(ctx->kernel_sel & 4096);
                 if (!fused_in) k.xw(dE, ld, U, wb + c.Wr1 + ctr, U, 1, nullptr, dB, U, ACT_NONE, 0, b_in);
             }
             // skip conv: dWc = b_in^T dC; d b_in += dC Wc^T

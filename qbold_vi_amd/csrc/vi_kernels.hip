@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
             __builtin_amdgcn_s_setprio(2);
             f32x4 b[4];
             qb::dense_first<T, BF>(lds_w + e.first_A, lds_w + e.first_b, nv, b, lane);
-            if (!(c.debug_skip & 1))
+            if (!QB_ABLATE(c, 1))
 #pragma unroll
                 for (int l = 0; l < NL; ++l) qb::block_stream2<BF>(lds_w + e.blk0 + l * e.blk_stride, b, lane, &amax);
             f32x4 hd[HT];
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
             qb::gather_head<5 + T, HT>(hd, o);
             __builtin_amdgcn_s_setprio(0);
         }
-        if (v < N && !(c.debug_skip & 2)) {
+        if (v < N && !QB_ABLATE(c, 2)) {
             // x is read again (an L1/L2 hit) rather than held in 11 VGPRs across the encoder; the
             // empty asm keeps the compiler from merging the two reads
             const float* xr = x + v * T;
@@ -221,7 +221,7 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     // SEC: the protocol's spin-echo index (tau = 0), folded at compile time when the context agrees
 #define QB_DISPATCH_VI(TT, NL, SEC)                                               \
     do {                                                                          \
-        if (fast && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm && !(ctx->dev.debug_skip & 4)) QB_LAUNCH_VI(TT, NL, SEC, true, false);   \
+        if (fast && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm && !(ctx->kernel_sel & 4)) QB_LAUNCH_VI(TT, NL, SEC, true, false);   \
         else if (fast) QB_LAUNCH_VI(TT, NL, -1, true, false);                     \
         else if (lit && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm) QB_LAUNCH_VI(TT, NL, SEC, false, true);   \
         else if (lit) QB_LAUNCH_VI(TT, NL, -1, false, true);                      \

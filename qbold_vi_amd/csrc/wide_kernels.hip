@@ -493,7 +493,7 @@ extern "C" int qbold_encoder_wide_fwd(const qbold_ctx* ctx, const qbold_encoder_
         a.bias = packed + o.b;
         a.Y = Y; a.ldy = U;
         a.T = T; a.N = N;
-        a.dbg = ctx->dev.debug_skip;
+        a.dbg = QB_ABLATE_MASK(ctx->dev);
         return a;
     };
     float* cur = bufs[0];

@@ -22,13 +22,19 @@ class LogitMVN:
     # logit_mvn.py:20-38: ||L^-1 (obs - mean)||^2 with L = [[e^so, 0], [cov, e^sd]]
     @staticmethod
     def squared_whitened_residual(obs, mean, oef_log_std, dbv_log_std, oef_dbv_cov):
+        from . import _lib
+        from .ops import _f32, _ptr, _stream
         out_shape = mean.shape[:-1]
-        obs, mean = obs.reshape(-1, 2), mean.reshape(-1, 2)
-        so, sd, cov = oef_log_std.reshape(-1), dbv_log_std.reshape(-1), oef_dbv_cov.reshape(-1)
-        r0, r1 = obs[:, 0] - mean[:, 0], obs[:, 1] - mean[:, 1]
-        w0 = r0 * torch.exp(-so)
-        w1 = r1 * torch.exp(-sd) - r0 * torch.exp(-so - sd) * cov
-        return (w0 * w0 + w1 * w1).reshape(out_shape)
+        obs, mean = _f32(obs.reshape(-1, 2), "obs"), _f32(mean.reshape(-1, 2), "mean")
+        n = mean.shape[0]
+        so, sd, cov = (_f32(t.reshape(-1), name) for t, name in ((oef_log_std, "oef_log_std"),
+                                                                  (dbv_log_std, "dbv_log_std"), (oef_dbv_cov, "oef_dbv_cov")))
+        if obs.shape[0] != n or so.numel() != n or sd.numel() != n or cov.numel() != n:
+            raise ValueError("squared_whitened_residual: operands disagree on the number of rows")
+        out = torch.empty(n, dtype=torch.float32, device=mean.device)
+        _lib.check(_lib.load().qbold_squared_whitened_residual(_ptr(obs), _ptr(mean), _ptr(so), _ptr(sd), _ptr(cov),
+                                                               _ptr(out), n, _stream()), "qbold_squared_whitened_residual")
+        return out.reshape(out_shape)
 
     @staticmethod
     def calculate_log_chol_det(oef_log_std, dbv_log_std):  # logit_mvn.py:40-44

@@ -414,6 +414,11 @@ class EncoderTrainer:
     def calculate_log_chol_det(oef_log_std, dbv_log_std):
         return 2.0 * (oef_log_std + dbv_log_std)
 
+    @staticmethod
+    def squared_whitened_residual(obs, mean, oef_log_std, dbv_log_std, oef_dbv_cov):   # model.py:423-441
+        from .logit_mvn import LogitMVN
+        return LogitMVN.squared_whitened_residual(obs, mean, oef_log_std, dbv_log_std, oef_dbv_cov)
+
     def logit_gaussian_log_prob(self, observations, predicted_params):
         """Diagonal family (model.py:406-421): the 5-parameter density with a zero Cholesky term, less
         the log 2 pi that the reference's gaussian_nll (:403-404) does not carry."""

@@ -225,6 +225,11 @@ class Context:
         mode = {"table": 0, "literal": 1}.get(mode, mode)
         _lib.check(self.lib.qbold_ctx_set_tissue_mode(self.handle, int(mode)), "set_tissue_mode")
 
+    def set_kernel_selection(self, mask):
+        """qbold_ctx_set_kernel_selection: dispatch to older EQUIVALENT kernels (QBOLD_KSEL_* of include/qbold_hip.h);
+        0 restores the default, fastest forms.  Used by the tests that hold fused kernels to the layer-wise ones."""
+        _lib.check(self.lib.qbold_ctx_set_kernel_selection(self.handle, int(mask)), "set_kernel_selection")
+
     def set_grad_node0(self, on):
         _lib.check(self.lib.qbold_ctx_set_grad_node0(self.handle, int(bool(on))), "set_grad_node0")
 

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Builds an ABLATION copy of the library: -DQBOLD_ABLATION compiles the work-skipping hooks of the timing
+# experiments in, which then honour QBOLD_DEBUG_SKIP together with
+# QBOLD_ALLOW_ABLATION=1.  Never what the tests, the driver or a user load: the default build has no such hook.
+#   scripts/dev/build_ablation.sh && QBOLD_ALLOW_ABLATION=1 QBOLD_DEBUG_SKIP=2 python3 bench.py --no_variants
+# Rebuild the ordinary library afterwards:  python3 -m qbold_vi_amd.build --force
+set -e
+cd "$(dirname "$0")/../.."
+python3 - <<'PY'
+from qbold_vi_amd.build import build_lib
+print(build_lib(force=True, verbose=False, extra_flags=("-DQBOLD_ABLATION",)))
+PY

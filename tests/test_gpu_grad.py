@@ -525,12 +525,9 @@ def test_one_launch_training_forward_and_block_backward(params, T, L, taps, monk
     g_ls = torch.as_tensor((rng.normal(size=(N, T)) * scale).astype(np.float32), device="cuda")
     out = {}
     for fused in (False, True):
-        if fused:
-            monkeypatch.delenv("QBOLD_DEBUG_SKIP", raising=False)
-        else:   # ablation switch 131072: the layer-wise backward (gate_bwd_kernel + xw64 launches)
-            monkeypatch.setenv("QBOLD_DEBUG_SKIP", "131072")
-            monkeypatch.setenv("QBOLD_ALLOW_ABLATION", "1")
         ctx = Context(p, True, True)
+        # QBOLD_KSEL_LAYERWISE_BWD = 131072: the layer-wise backward (gate_bwd_kernel + xw64 launches)
+        ctx.set_kernel_selection(0 if fused else 131072)
         ew = EncoderWeights(ctx, T, U, L, True, -3.0, spatial_taps=taps).set_from_arrays(w)
         st = TrainState(ctx, ew)
         st.fused_forward = fused
@@ -539,7 +536,6 @@ def test_one_launch_training_forward_and_block_backward(params, T, L, taps, monk
         slots = st.workspace(N)[: (2 + 5 * L) * N * 64].reshape(2 + 5 * L, N, 64).clone()
         grad = st.backward(2, g_q, g_ls).clone()
         out[fused] = (q.clone(), ls.clone(), slots, grad)
-    monkeypatch.delenv("QBOLD_DEBUG_SKIP", raising=False)
     (q0, ls0, s0, g0), (q1, ls1, s1, g1) = out[False], out[True]
     assert torch.isfinite(q1).all() and torch.isfinite(ls1).all() and torch.isfinite(g1).all()
     assert (q1 - q0).abs().max() < 1e-5 * max(1.0, float(q0.abs().max()))      # split-f16 products vs exact f32
@@ -575,19 +571,14 @@ def test_fused_training_kernels_over_widths_and_batch_sizes(params, monkeypatch)
         g_ls = torch.as_tensor((rng.normal(size=(N, 11)) / N).astype(np.float32), device="cuda")
         out = {}
         for fused in (False, True):
-            if fused:
-                monkeypatch.delenv("QBOLD_DEBUG_SKIP", raising=False)
-            else:
-                monkeypatch.setenv("QBOLD_DEBUG_SKIP", "131072")
-                monkeypatch.setenv("QBOLD_ALLOW_ABLATION", "1")
             ctx = Context(params, True, True)
+            ctx.set_kernel_selection(0 if fused else 131072)   # QBOLD_KSEL_LAYERWISE_BWD
             ew = EncoderWeights(ctx, 11, U, L, True, -3.0).set_from_arrays(w)
             st = TrainState(ctx, ew)
             st.fused_forward = fused
             st.workspace(N).fill_(float("nan"))
             q, ls = st.forward(x, 2)
             out[fused] = (q.clone(), ls.clone(), st.backward(2, g_q, g_ls).clone())
-        monkeypatch.delenv("QBOLD_DEBUG_SKIP", raising=False)
         (q0, ls0, g0), (q1, ls1, g1) = out[False], out[True]
         assert torch.isfinite(g1).all(), (U, L, N)
         assert (q1 - q0).abs().max() < 1e-5 * max(1.0, float(q0.abs().max())), (U, L, N)
