@@ -385,7 +385,12 @@ int qbold_smoothness(const qbold_ctx* ctx, const float* q, const float* mask, co
                      float weight, float* g_q, double* tv_sum, void* stream);
 /* g_q [N][5], g_log_sigma [N][T] (stream 2; may be NULL): gradients of the loss with respect to
  * the head outputs.  sums: DEVICE double[3] whose [2] is sum(mask) -- the head gradients are
- * divided by it (NULL: already normalised).  grad: canonical layout, overwritten. */
+ * divided by it (NULL: already normalised).  grad: canonical layout, overwritten.
+ * When qbold_encoder_train_bwd_recomputes(...) is 2 the backward RECOMPUTES each block (skip, t, r, gate logits) with
+ * the split-f16 products of qbold_encoder_train_fwd_fused and takes its relu masks from that recomputation: it is the
+ * adjoint of THAT forward.  After the exact-f32 layer-wise qbold_encoder_train_fwd the masks can differ for
+ * activations within ~1e-6 of zero (where the relu's derivative is a convention anyway); callers that need the adjoint
+ * of the layer-wise forward bit for bit select QBOLD_KSEL_LAYERWISE_BWD. */
 int qbold_encoder_train_bwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* weights,
                             int stream_sel, float* workspace, const float* g_q, const float* g_log_sigma,
                             const double* sums, float* grad, int64_t N, void* stream);

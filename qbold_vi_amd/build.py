@@ -43,8 +43,50 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
+# Translation units whose correctness rests on hand-counted instruction facts the compiler could invalidate: their
+# ISA is checked on EVERY build, and a violation fails the build.  kernel-name substrings -> checks.
+#   ring:   scripts/check_vmcnt_ring.py   -- the weight ring's per-site vmcnt allowances (sync_extras; only the V4
+#           instantiations carry allowances, the others wait with the plain stage count)
+#   hazard: scripts/check_lds_hazards.py  -- no touch of a register between an asm ds_read and the wait covering it
+ISA_CHECKS = {
+    "wide_fused_kernels.hip": {
+        "ring": ("wide_fused_kernelILi4ELi1ELb1", "wide_fused_kernelILi4ELi2ELb1"),
+        "hazard": ("wide_fused_kernelILi1ELi1ELb0", "wide_fused_kernelILi1ELi2ELb0", "wide_fused_kernelILi4ELi1ELb1",
+                   "wide_fused_kernelILi4ELi1ELb0", "wide_fused_kernelILi4ELi2ELb0", "wide_fused_kernelILi4ELi2ELb1"),
+    },
+}
+_TEMP_SUFFIXES = (".bc", ".hipi", ".out", ".resolution.txt", ".s", ".hipfb")
+
+
+def verify_isa(src, asm_path):
+    """Run the static checkers on the device ISA of one translation unit; raise on any violation."""
+    scripts = os.path.join(os.path.dirname(HERE), "scripts")
+    report = []
+    for kind, script in (("ring", "check_vmcnt_ring.py"), ("hazard", "check_lds_hazards.py")):
+        for key in ISA_CHECKS[src].get(kind, ()):
+            r = subprocess.run([sys.executable, os.path.join(scripts, script), asm_path, key], capture_output=True,
+                               text=True)
+            line = (r.stdout.strip().splitlines() or ["(no output)"])
+            summary = line[-1] if kind == "ring" else line[0]
+            report.append(f"{script} {key}: {summary.split(': ', 1)[-1]}")
+            ok = r.returncode == 0 and ((" 0 violations" in r.stdout and " 0 handshakes" not in r.stdout)
+                                        if kind == "ring" else (" 0 hazards" in r.stdout and " 0 LDS reads" not in r.stdout))
+            if not ok:
+                raise RuntimeError(f"ISA check failed for {src} ({script}, {key}):\n{r.stdout[-3000:]}{r.stderr[-1000:]}")
+    return report
+
+
+def _drop_temps(obj_dir, stem):
+    for f in os.listdir(obj_dir):
+        if f.startswith(stem + "-hip-") or f.startswith(stem + "-host-") or f.startswith(stem + ".hip-hip-"):
+            if f.endswith(_TEMP_SUFFIXES) or f.endswith(".o"):
+                os.remove(os.path.join(obj_dir, f))
+
+
 def build_lib(force=False, verbose=False, extra_flags=()):
-    """Compile every .hip translation unit and link libqbold_hip.so.  Returns the library path."""
+    """Compile every .hip translation unit and link libqbold_hip.so.  Returns the library path.
+    Translation units listed in ISA_CHECKS are compiled with -save-temps and their ISA is verified before the
+    object is accepted (a stamp beside the object records the verdict of exactly that object)."""
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
@@ -55,8 +97,14 @@ def build_lib(force=False, verbose=False, extra_flags=()):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
-            jobs.append([hipcc, *FLAGS, *extra_flags, "-c", s, "-o", o])
+        stamp = o + ".isa_ok"
+        stale = force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time)
+        if src in ISA_CHECKS and not stale and not (os.path.exists(stamp) and
+                                                     os.path.getmtime(stamp) >= os.path.getmtime(o)):
+            stale = True     # an object without a verdict is not linked
+        if stale:
+            jobs.append([hipcc, *FLAGS, *extra_flags, *(["-save-temps=obj", "-fverbose-asm"] if src in ISA_CHECKS else []),
+                         "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -66,6 +114,23 @@ def build_lib(force=False, verbose=False, extra_flags=()):
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
         if verbose and r.stderr:
             print(r.stderr, file=sys.stderr)
+        if "-save-temps=obj" in cmd:
+            o = cmd[-1]
+            src = os.path.basename(cmd[-3])
+            stem = src[:-len(".hip")]
+            asm = os.path.join(OBJ, f"{stem}-hip-amdgcn-amd-amdhsa-gfx950.s")
+            try:
+                report = verify_isa(src, asm)
+            except Exception:
+                if os.path.exists(o):
+                    os.remove(o)       # never link an object whose ISA failed the check
+                raise
+            finally:
+                _drop_temps(OBJ, stem)
+            with open(o + ".isa_ok", "w") as fh:
+                fh.write("\n".join(report) + "\n")
+            if verbose:
+                print("\n".join(report), flush=True)
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))

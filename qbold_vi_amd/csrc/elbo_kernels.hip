@@ -607,6 +607,9 @@ int elbo_fwd_launch(const qbold_ctx* ctx, const float* x, const float* mask, con
         return QBOLD_ERR_UNSUPPORTED;
     }
     if (lds64) {
+        // elbo_fwd_lds_kernel reads the x and sigma rows as float4: 256-byte rows, so the bases decide
+        QB_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(sigma) % 16 == 0,
+                   "qbold_elbo_fwd (64-tau protocol): x and sigma must be 16-byte aligned");
         const int64_t gt = (N + kLdsVox - 1) / kLdsVox;
         grid = (int)(gt < qb::elbo_grid(ctx) ? (gt > 0 ? gt : 1) : qb::elbo_grid(ctx));
         if (sigma_is_log)

@@ -62,6 +62,21 @@ def _creation_number(weight_name):
     return int(m.group(1)) if m.group(1) else 0
 
 
+def _split_hyper_prior(named):
+    """A checkpoint saved with infer_inv_gamma=True carries the tfp VariableLayer's single rank-1 variable of four
+    logs (model.py:201-205) in a layer group of its own: taken out before the Conv3D layers are paired."""
+    groups = {}
+    for name, a in named:
+        groups.setdefault(name.rsplit("/", 1)[0], []).append(a)
+    hyper_keys = [k for k, arrs in groups.items() if len(arrs) == 1 and arrs[0].ndim == 1 and arrs[0].shape == (4,)]
+    if len(hyper_keys) > 1:
+        raise ValueError("more than one candidate for the inverse-gamma hyper-prior variable")
+    if not hyper_keys:
+        return named, None
+    key = hyper_keys[0]
+    return [(n, a) for n, a in named if n.rsplit("/", 1)[0] != key], np.asarray(groups[key][0], np.float32)
+
+
 def _pair_layers(named):
     """[(weight name, array)] in file order -> [(kernel, bias)] per layer, in file order."""
     layers, index = [], {}
@@ -107,7 +122,8 @@ def _by_roles(layers):
 def flatten_variables(f):
     """All variables of a Keras weights file (an open h5py.File or anything with the same mapping /
     .attrs interface) as float32 arrays in the reference's layer CREATION order, kernel before bias."""
-    layers = _pair_layers(_named_variables(f))
+    named, hyper = _split_hyper_prior(_named_variables(f))
+    layers = _pair_layers(named)
     numbers = [_creation_number(key + "/kernel:0") for key, _, _ in layers]
     if all(n is not None for n in numbers) and len(set(numbers)) == len(numbers):
         layers = [l for _, l in sorted(zip(numbers, layers), key=lambda t: t[0])]
@@ -116,6 +132,8 @@ def flatten_variables(f):
     out = []
     for _, k, b in layers:
         out += [k, b]
+    if hyper is not None:
+        out.append(hyper)       # trailing rank-1 variable: variables_to_canonical maps it to 'hyper_prior'
     return out
 
 
@@ -135,6 +153,9 @@ def _kernel(a, taps):
 def variables_to_canonical(variables):
     """Flattened Keras variables -> dict of canonical arrays (per-block tensors stacked on axis 0)."""
     v = list(variables)
+    hyper = None
+    if v and np.asarray(v[-1]).ndim == 1 and np.asarray(v[-1]).shape == (4,) and len(v) % 2 == 1:
+        hyper = np.asarray(v.pop(), np.float32)      # the infer_inv_gamma VariableLayer (model.py:201-205)
     if len(v) < 6 or (len(v) - 6) % 8 != 0:
         raise ValueError(f"{len(v)} variables do not fit  W0 b0 | 8 per block | Wf bf | Ws bs")
     L = (len(v) - 6) // 8
@@ -157,6 +178,8 @@ def variables_to_canonical(variables):
     if not ok:
         raise ValueError("variable shapes do not match the reference encoder "
                          f"(T={T}, U={U}, L={L}): " + ", ".join(f"{k}{tuple(a.shape)}" for k, a in w.items()))
+    if hyper is not None:
+        w["hyper_prior"] = hyper
     return w
 
 
@@ -181,6 +204,8 @@ def canonical_to_variables(w):
     out += [(f"conv3d_{n}/kernel:0", k1(w["Wf"])), (f"conv3d_{n}/bias:0", np.asarray(w["bf"], np.float32))]
     n += 1
     out += [(f"conv3d_{n}/kernel:0", k1(w["Ws"])), (f"conv3d_{n}/bias:0", np.asarray(w["bs"], np.float32))]
+    if w.get("hyper_prior") is not None:     # tfp.layers.VariableLayer names its variable 'constant:0'
+        out.append(("variable_layer/constant:0", np.asarray(w["hyper_prior"], np.float32)))
     return out
 
 
@@ -188,7 +213,9 @@ def save_keras_h5(path, w):
     """Write canonical weights in the layout load_keras_h5 reads (outer layers: conv3d, model, sigma conv)."""
     h5py = _h5py()
     var = canonical_to_variables(w)
-    groups = [("conv3d", var[:2]), ("model", var[2:-2]), (var[-2][0].split("/")[0], var[-2:])]
+    hyper = [var.pop()] if var[-1][0].startswith("variable_layer/") else []
+    # the hyper-prior layer is created inside the inner model, after the final layer (model.py:196-205)
+    groups = [("conv3d", var[:2]), ("model", var[2:-2] + hyper), (var[-2][0].split("/")[0], var[-2:])]
     with h5py.File(path, "w") as f:
         f.attrs["layer_names"] = [g.encode("utf8") for g, _ in groups]
         f.attrs["backend"] = b"tensorflow"

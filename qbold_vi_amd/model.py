@@ -441,6 +441,8 @@ class EncoderTrainer:
             y_pred_orig = flat[:, :4]
         q = _pad5(_flat(y_pred_orig, y_pred_orig.shape[-1])[:, :self._nq]).contiguous()
         offset = 0.0 if self._use_mvg else 1.8378770664093453   # logit_gaussian_log_prob, model.py:470
+        if hyper is not None:   # model.py:493-498: with infer_inv_gamma the learned prior is the ONLY one
+            inv_gamma_alpha = inv_gamma_beta = 0.0
         if inv_gamma_alpha * inv_gamma_beta > 0.0:
             lv = self._ctx.synth_loss(y, q, inv_gamma_alpha, inv_gamma_beta)
         else:

@@ -19,14 +19,21 @@ def main():
     # may sit at the bottom, entered by a long jump).  Replayed in layout order -- the blocks besides the body
     # hold no vector-memory instruction but a full drain (s_waitcnt vmcnt(0)) in the header, so layout order
     # differs from execution order only in skipping that drain before the first pass: the stricter replay.
-    ins, loop_blocks, in_loop, cur = [], [], False, None
+    ins, loop_blocks, in_loop, cur, block_start = [], [], False, None, -1
     for l in lines[start + 1:end]:
         code = l.split(";")[0].strip()
         if re.match(r"^(\.LBB[\w$]+):", code) or re.match(r"^; %bb\.\d+:", l):   # a block starts
             in_loop = "Loop" in l
             cur = [len(ins), len(ins)] if in_loop else None
+            block_start = len(ins)
             if cur:
                 loop_blocks.append(cur)
+            continue
+        if not code and "Loop" in l and cur is None and block_start == len(ins):
+            # the loop annotation on its own comment line under the label (-save-temps -fverbose-asm puts the IR
+            # block name on the label's line and the loop membership on the next)
+            in_loop, cur = True, [len(ins), len(ins)]
+            loop_blocks.append(cur)
             continue
         if not code or code.startswith("."):
             continue

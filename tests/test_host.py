@@ -385,6 +385,27 @@ def test_hand_placed_lds_reads_are_not_touched_before_their_wait(tmp_path):
             assert r.returncode == 1 and "still has" in r.stdout, (n, r.stdout[-500:])
 
 
+def test_build_verified_the_isa_of_every_ring_instantiation():
+    """qbold_vi_amd/build.py compiles wide_fused_kernels.hip with -save-temps, runs both static checkers on the ISA
+    of EVERY instantiation and refuses to keep an object that fails: the verdict of the very object linked into
+    libqbold_hip.so is the stamp beside it (both V4 instantiations replayed -- <4, 1, true> too --, no hazards in any
+    of the six kernels)."""
+    from qbold_vi_amd import build
+    obj = os.path.join(build.OBJ, "wide_fused_kernels.o")
+    stamp = obj + ".isa_ok"
+    if not os.path.exists(obj):
+        pytest.skip("library was not built in this tree")
+    assert os.path.exists(stamp) and os.path.getmtime(stamp) >= os.path.getmtime(obj)
+    text = open(stamp).read()
+    for key in build.ISA_CHECKS["wide_fused_kernels.hip"]["ring"]:
+        line = next(l for l in text.splitlines() if "check_vmcnt_ring.py " + key in l)
+        assert " 0 violations" in line and int(line.split(" handshakes replayed")[0].split()[-1]) > 200, line
+    for key in build.ISA_CHECKS["wide_fused_kernels.hip"]["hazard"]:
+        line = next(l for l in text.splitlines() if "check_lds_hazards.py " + key in l)
+        assert " 0 hazards" in line and int(line.split(": ")[1].split()[0]) > 1000, line
+    assert {k[-12:] for k in build.ISA_CHECKS["wide_fused_kernels.hip"]["ring"]} == {"ILi4ELi1ELb1", "ILi4ELi2ELb1"}
+
+
 def test_training_backward_says_when_it_recomputes(params):
     """qbold_encoder_train_bwd_recomputes is the one predicate both sides of the training step use: the one-launch
     forward leaves out exactly what the backward says it will recompute (2: skip, gate logits, t and r)."""
@@ -403,3 +424,44 @@ def test_training_backward_says_when_it_recomputes(params):
                   _lib.EncoderShape(11, 60, 2, 1, -3.0, 1, 1)):   # bf16 encoder mode
         assert lib.qbold_encoder_train_bwd_recomputes(ctx.handle, C.byref(shape), 1 << 20) == 0
     assert lib.qbold_encoder_train_bwd_recomputes(None, C.byref(yes), 1 << 20) == 0
+
+
+def test_keras_h5_carries_the_inverse_gamma_hyper_prior():
+    """A checkpoint saved with infer_inv_gamma=True holds the tfp VariableLayer's one rank-1 variable of four logs
+    (model.py:201-205) in a group of its own: mapped to 'hyper_prior' and back."""
+    from qbold_vi_amd import keras_h5
+    from qbold_vi_amd.init import init_encoder_weights
+    w = init_encoder_weights(T=11, U=12, L=1, channelwise_gating=True, seed=4, spatial_taps=9)
+    w["Wf"], w["bf"] = w["Wf"][:, :4].copy(), w["bf"][:4].copy()          # the diagonal family it runs with
+    w["hyper_prior"] = np.log(np.array([20.0, 2.5, 15.0, 3.0], np.float32))
+    var = keras_h5.canonical_to_variables(w)
+    assert var[-1][0] == "variable_layer/constant:0" and len(var) == 6 + 8 + 1
+    f = _FakeH5Node()
+    groups = [("conv3d", var[:2]), ("model", var[2:-3] + var[-1:]), ("conv3d_6", var[-3:-1])]
+    f.attrs["layer_names"] = [g.encode() for g, _ in groups]
+    for gname, items in groups:
+        g = _FakeH5Node()
+        g.attrs["weight_names"] = [n.encode() for n, _ in items]
+        for n, a in items:
+            node, parts = g, n.split("/")
+            for part in parts[:-1]:
+                node = node.setdefault(part, _FakeH5Node()) if part not in node else dict.__getitem__(node, part)
+            dict.__setitem__(node, parts[-1], a)
+        dict.__setitem__(f, gname, g)
+    back = keras_h5.variables_to_canonical(keras_h5.flatten_variables(f))
+    np.testing.assert_array_equal(back["hyper_prior"], w["hyper_prior"])
+    assert back["Wf"].shape == (12, 4)
+    for k in ("W0", "Wc", "Wr1", "Wg", "Ws", "bs"):
+        np.testing.assert_array_equal(back[k], w[k])
+    # without the variable nothing changes
+    w.pop("hyper_prior")
+    assert "hyper_prior" not in keras_h5.variables_to_canonical([a for _, a in keras_h5.canonical_to_variables(w)])
+
+
+def test_digamma_matches_scipy():
+    from scipy.special import digamma as ref
+    from qbold_vi_amd.training import digamma
+    for x in (1e-3, 0.1, 0.5, 1.0, 2.5, 5.999, 6.0, 20.0, 1e3, 1e6):
+        assert abs(digamma(x) - float(ref(x))) < 1e-12 * max(1.0, abs(float(ref(x)))), x
+    with pytest.raises(ValueError):
+        digamma(0.0)
