@@ -133,6 +133,7 @@ int qbold_ctx_set_grad_node0(qbold_ctx* ctx, int on);
  * the layer-wise ones.  No bit skips work (the work-skipping hooks of the timing experiments exist only in
  * -DQBOLD_ABLATION builds, scripts/dev/build_ablation.sh). */
 #define QBOLD_KSEL_RUNTIME_SE_IDX 4          /* ELBO kernels: run-time instead of compile-time spin-echo index */
+#define QBOLD_KSEL_X_TABLE 8                 /* ELBO kernels: x-indexed F table per (draw, tau) instead of the per-tau OEF-indexed one */
 #define QBOLD_KSEL_CONV_PER_TAP 256          /* 3x3x1 convolution as nine gathered GEMM launches */
 #define QBOLD_KSEL_GENERAL_GEMM 512          /* layer GEMMs on the general xw_kernel */
 #define QBOLD_KSEL_SEPARATE_GATE 2048        /* gate blend as its own launch */
@@ -143,7 +144,7 @@ int qbold_ctx_set_grad_node0(qbold_ctx* ctx, int on);
 #define QBOLD_KSEL_CONV_EXACT_F32 65536      /* 3x3x1 convolution on the f32-input MFMA */
 #define QBOLD_KSEL_LAYERWISE_BWD 131072      /* voxel batches: layer-wise backward instead of the one-launch block kernels */
 #define QBOLD_KSEL_BLOCK_BWD_SPLIT_DW 262144 /* block backward with separate weight-gradient launches */
-#define QBOLD_KSEL_ALL (4 | 256 | 512 | 2048 | 4096 | 8192 | 16384 | 32768 | 65536 | 131072 | 262144)
+#define QBOLD_KSEL_ALL (4 | 8 | 256 | 512 | 2048 | 4096 | 8192 | 16384 | 32768 | 65536 | 131072 | 262144)
 int qbold_ctx_set_kernel_selection(qbold_ctx* ctx, int mask);
 /* Host-side evaluation of the uploaded table (for tests): F(x) and dF/dx, HOST arrays. */
 int qbold_ctx_table_eval(const qbold_ctx* ctx, const float* host_x, float* host_F, float* host_dF,

@@ -193,6 +193,37 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
         ctx->h_tab[4 * i + 3] = (float)(2.0 * (f[i] - f[i + 1]) + g[i] + g[i + 1]);
     }
 
+    // Per-tau OEF-indexed table of the sampling fast path (qbold_dev.h, GtLds): G_j(OEF) = F(|tau_j| dw_coef OEF) on
+    // gtab_segs(T) cubic-Hermite segments over OEF in [0.04, 0.84], j = 1 .. gtab_taus(T, se_idx), built for the
+    // protocols whose spin-echo image sits at tau = 0 exactly (both of the reference's, signals.py:117-121).
+    {
+        const int nseg = qb::gtab_segs(T), se = d.se_idx;
+        const bool proto = (T == 11 && se == 2) || (T == 24 && se == 7);
+        if (nseg > 0 && proto && d.taus[se] == 0.0f && P->full_model) {
+            const int J = qb::gtab_taus(T, se);
+            ctx->h_gtab.resize((size_t)4 * J * nseg);
+            const double hh = (double)QB_GT_OEF_RANGE / nseg;
+            std::vector<double> gf(nseg + 1), gg(nseg + 1);
+            for (int j = 1; j <= J; ++j) {
+                const double tau = fabs((double)(se + j < T ? d.taus[se + j] : d.taus[se - j]));
+                const double k = tau * (double)d.dw_coef;
+                for (int i = 0; i <= nseg; ++i) {
+                    const double oef = (double)QB_GT_OEF_MIN + hh * i;
+                    gf[i] = simpson.F(k * oef);
+                    gg[i] = simpson.dF(k * oef) * k * hh;
+                }
+                float* row = &ctx->h_gtab[(size_t)4 * (j - 1) * nseg];
+                for (int i = 0; i < nseg; ++i) {
+                    row[4 * i + 0] = (float)gf[i];
+                    row[4 * i + 1] = (float)gg[i];
+                    row[4 * i + 2] = (float)(3.0 * (gf[i + 1] - gf[i]) - 2.0 * gg[i] - gg[i + 1]);
+                    row[4 * i + 3] = (float)(2.0 * (gf[i] - gf[i + 1]) + gg[i] + gg[i + 1]);
+                }
+            }
+            ctx->gtab_ok = true;
+        }
+    }
+
     if (device < 0) {
         *out = ctx;
         return QBOLD_OK;
@@ -204,6 +235,11 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
     if (e == hipSuccess)
         e = hipMemcpy(ctx->d_tab, ctx->h_tab.data(), sizeof(float) * 4 * QB_TAB_SEG,
                       hipMemcpyHostToDevice);
+    if (e == hipSuccess && ctx->gtab_ok) {
+        e = hipMalloc((void**)&ctx->d_gtab, sizeof(float) * ctx->h_gtab.size());
+        if (e == hipSuccess)
+            e = hipMemcpy(ctx->d_gtab, ctx->h_gtab.data(), sizeof(float) * ctx->h_gtab.size(), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -212,6 +248,7 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
     if (prev_device >= 0 && prev_device != device) (void)hipSetDevice(prev_device);
     if (e != hipSuccess) {
         if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+        if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
         delete ctx;
         return qb::hip_fail(e, "qbold_ctx_create: device setup");
     }
@@ -222,6 +259,7 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
 extern "C" void qbold_ctx_destroy(qbold_ctx* ctx) {
     if (!ctx) return;
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+    if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
     delete ctx;
 }
 

@@ -18,6 +18,9 @@
 #define QB_LIK_BARRIER 2  // compiler barrier every this many evaluated taus of the likelihood loop (1: 0.517,
                           // 2: 0.509, 3: 0.515, 4: 0.512, 8: 0.512, none: 0.514 ms)
 #endif
+#ifndef QB_GT_DEPTH
+#define QB_GT_DEPTH 2   // table rows requested ahead in the per-tau-table likelihood loop
+#endif
 #ifndef QB_PRIO_KL
 #define QB_PRIO_KL 3
 #endif
@@ -139,6 +142,74 @@ __device__ __forceinline__ float sample_nll(const FwdLds* L, const QbDev& c, con
 
 // Fast path (full model, table mode, Gaussian likelihood on linear data): same arithmetic with the
 // per-draw constants folded (FwdFast) and the residual scored as sum r^2 (0.5 applied once).
+template <class LDS>
+struct IsGtLds { static constexpr bool value = false; };
+template <int T, int SE>
+struct IsGtLds<GtLds<T, SE>> { static constexpr bool value = true; };
+
+// The same with the per-tau OEF-indexed table (GtLds; qbold_dev.h): the host dispatches here only for protocols with
+// tau = 0 at the compile-time spin-echo index and a table built for them (qbold_ctx::gtab_ok).
+template <int T, int SE>
+__device__ __forceinline__ float sample_sq_fast(const GtLds<T, SE>* L, const QbDev& c, const VoxelLik<T>& k,
+                                                float oef, float dbv) {
+    static_assert(SE >= 0 && gtab_segs(T) > 0, "built for compile-time spin-echo protocols");
+    constexpr int NSEG = gtab_segs(T);
+    const FwdFast fv = fwd_fast(c, oef, dbv);
+    float acc = 0.0f;
+    const float s_se = fmaf(fv.tissue_w, 1.0f, fv.blood_w * exp2f_(fv.ng * L->blood_B[SE]));   // F(0) = 0
+    const float inv_np = rcpf_(s_se + 1e-3f);
+    const float lt = log2f_(fv.tissue_w * inv_np), lb = log2f_(fv.blood_w * inv_np);
+    // one coordinate per draw: OEF in [0.04, 0.84] -> segment index and fraction shared by every tau
+    constexpr float kScale = (float)NSEG / QB_GT_OEF_RANGE;
+    const float cg = clampf_(fmaf(oef, kScale, -QB_GT_OEF_MIN * kScale), 0.0f, (float)NSEG - 0.0009765625f);
+    const float f = __builtin_amdgcn_fractf(cg);
+    const float4* row = L->gtab + (int)cg;
+    // The rows of a draw sit at immediate offsets from one address, so nothing orders their reads: left alone the
+    // compiler requests all of them up front (32 live registers: spills under the fused kernel's 128-register
+    // budget).  A ring keeps QB_GT_DEPTH evaluations in flight; sched_barrier pins requests AND arithmetic.
+    struct Stage {
+        float4 kk;
+        float bb;
+    };
+    auto issue = [&](int t) -> Stage {
+        const int j = t > SE ? t - SE : SE - t;
+        Stage st;
+        st.kk = row[(j - 1) * NSEG];
+        st.bb = L->blood_B[t];
+        return st;
+    };
+    auto finish = [&](int t, const Stage& st) {   // normalised prediction at tau index t, scored at t and its mirror
+        const float F = fmaf(fmaf(fmaf(st.kk.w, f, st.kk.z), f, st.kk.y), f, st.kk.x);
+        const float yh = exp2f_(fmaf(fv.nd, F, lt)) + exp2f_(fmaf(fv.ng, st.bb, lb));
+        const float r = fmaf(-yh, k.inv_s[t], k.yt[t]);
+        acc = fmaf(r, r, acc);
+        const int tm = 2 * SE - t;                // the mirrored tau: the signal is even in tau
+        if (t > SE && tm >= 0) {
+            const float r1 = fmaf(-yh, k.inv_s[tm >= 0 ? tm : 0], k.yt[tm >= 0 ? tm : 0]);
+            acc = fmaf(r1, r1, acc);
+        }
+    };
+    {
+        const float r = fmaf(-(s_se * inv_np), k.inv_s[SE], k.yt[SE]);
+        acc = fmaf(r, r, acc);
+    }
+    // evaluation order: SE + 1 .. T - 1, then the taus below the spin echo that have no partner on the grid
+    constexpr int NA = T - 1 - SE, NB = (2 * SE - (T - 1)) > 0 ? 2 * SE - (T - 1) : 0, NE = NA + NB;
+    auto tau_of = [](int e) { return e < NA ? SE + 1 + e : e - NA; };
+    constexpr int D = QB_GT_DEPTH < NE ? QB_GT_DEPTH : NE;
+    Stage ring[D + 1];
+#pragma unroll
+    for (int e = 0; e < D; ++e) ring[e] = issue(tau_of(e));
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        if (e + D < NE) ring[(e + D) % (D + 1)] = issue(tau_of(e + D));
+        __builtin_amdgcn_sched_barrier(0);
+        finish(tau_of(e), ring[e % (D + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
+}
+
 template <int T, int SE>
 __device__ __forceinline__ float sample_sq_fast(const FwdLds* L, const QbDev& c,
                                                 const VoxelLik<T>& k, float oef, float dbv) {
@@ -234,8 +305,8 @@ __device__ __forceinline__ float kl_swr_diff(const LogitMvn& q, const LogitMvn& 
 //   kl_sum  = sum over this half's KL draws of log q(y) - log p(y)          model.py:596-603
 // zs / zk: explicit normals of this voxel ([S][2] / [K][2]) or nullptr for the Philox stream.
 // FAST: requires c.full_model, table mode, !predict_log, !use_student_t (checked on the host).
-template <int T, int SE, bool FAST, bool LITERAL>
-__device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
+template <int T, int SE, bool FAST, bool LITERAL, class LDS>
+__device__ __forceinline__ void voxel_mc_sums(const LDS* L, const QbDev& c,
                                               const VoxelLik<T>& lik, const LogitMvn& q,
                                               const float* __restrict__ prior_row, int S, int K,
                                               const float* __restrict__ zs,
@@ -264,7 +335,7 @@ __device__ __forceinline__ void voxel_mc_sums(const FwdLds* L, const QbDev& c,
             float a, b, oef, dbv;
             reparam_logits(q, d ? z[2] : z[0], d ? z[3] : z[1], a, b);
             forward_transform(a, b, oef, dbv);
-            if (FAST) nll_sum += sample_sq_fast<T, SE>(L, c, lik, oef, dbv);
+            if constexpr (FAST) nll_sum += sample_sq_fast<T, SE>(L, c, lik, oef, dbv);
             else nll_sum += sample_nll<T, SE, LITERAL>(L, c, lik, oef, dbv);
         }
     }

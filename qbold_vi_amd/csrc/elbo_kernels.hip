@@ -15,17 +15,31 @@ namespace {
 constexpr int kBlock = 256;              // 4 waves
 constexpr int kVoxPerBlock = kBlock / QB_LANES_PER_VOXEL;  // 16 voxels per wave, 4 lanes each
 
-template <int T, int SE, bool FAST, bool LITERAL>
+template <int T, int SE, bool GT>
+struct ElboLds { using type = qb::FwdLds; };
+template <int T, int SE>
+struct ElboLds<T, SE, true> { using type = qb::GtLds<T, SE>; };
+
+// GT: per-tau OEF-indexed table (GtLds) instead of the x-indexed one; needs FAST and a compile-time spin echo.
+template <int T, int SE, bool FAST, bool LITERAL, bool GT = false>
 __global__ __launch_bounds__(kBlock) void elbo_fwd_kernel(
     QbDev c, const float4* __restrict__ g_tab, const float* __restrict__ x,
     const float* __restrict__ mask, const float* __restrict__ q, const float* __restrict__ prior,
     const float* __restrict__ sigma, const float* __restrict__ zs, const float* __restrict__ zk,
     int S, int K, uint64_t seed, int64_t voxel0, float2* __restrict__ nll_kl,
     double* __restrict__ partials, int64_t N) {
-    __shared__ qb::FwdLds L;
+    // same choice of sampling table as the fused kernel (vi_kernels.hip), so that the fused and the unfused
+    // evaluation of a voxel run the same arithmetic
+    static_assert(!GT || (FAST && SE >= 0 && qb::gtab_segs(T) > 0), "GT needs the fast path with a compile-time spin echo");
+    using Lds = typename ElboLds<T, SE, GT>::type;
+    __shared__ Lds L;
     __shared__ double red[3 * (kBlock / 64)];
-    qb::fwd_lds_fill(&L, g_tab, true);
-    if (threadIdx.x < QB_MAX_T) L.blood_B[threadIdx.x] = c.blood_B[threadIdx.x];
+    if constexpr (qb::IsGtLds<Lds>::value) {
+        qb::gt_lds_fill(&L, g_tab, c);
+    } else {
+        qb::fwd_lds_fill(&L, g_tab, true);
+        if (threadIdx.x < QB_MAX_T) L.blood_B[threadIdx.x] = c.blood_B[threadIdx.x];
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -223,6 +237,12 @@ __global__ __launch_bounds__(kGenBlock) void elbo_fwd_generic_kernel(
 // pairs evaluated once (52 signal evaluations per draw for 64 taus), per-draw factors in the exponents.
 // A voxel's row is read as four float4 per lane (the four lanes of a voxel own a quarter of the taus each).
 // LOGSIG: `sigma` holds log sigma, the sigma head before its exp (model.py:211-214).
+#ifndef QB_LDS_PIPE
+#define QB_LDS_PIPE 1
+#endif
+#ifndef QB_LDS_DEPTH
+#define QB_LDS_DEPTH 2
+#endif
 constexpr int kLdsBlock = 256;
 constexpr int kLdsVox = kLdsBlock / QB_LANES_PER_VOXEL;
 
@@ -309,6 +329,59 @@ __global__ __launch_bounds__(kLdsBlock) void elbo_fwd_lds_kernel(
                     const float inv_np = qb::rcpf_(s_se + 1e-3f);
                     const float lt = qb::log2f_(fv.tissue_w * inv_np), lb = qb::log2f_(fv.blood_w * inv_np);
                     float acc = 0.0f;
+#if QB_LDS_PIPE
+                    // One-deep software pipeline over the taus: every LDS read an evaluation needs -- its table row (a
+                    // random row per lane: the conflicted, slow read), the blood bracket and the voxel's data pair(s)
+                    // -- is requested one evaluation ahead, so the round trip of the table read (~100+ cycles with its
+                    // bank conflicts) overlaps the previous tau's polynomial, exponentials and residuals instead of
+                    // being waited for right behind its issue (51 exposed round trips per draw before).
+                    struct Stage {
+                        float4 kk;
+                        float f, bb;
+                        float2 d0, d1;
+                    };
+                    auto issue = [&](int t) -> Stage {
+                        Stage st;
+                        const float u = fabsf(fmaf((float)t, fv.ub, fv.ua));
+                        st.kk = L.tab[(int)u];
+                        st.f = __builtin_amdgcn_fractf(u);
+                        st.bb = L.blood_B[t];
+                        st.d0 = my[t * kLdsVox];
+                        st.d1 = 2 * SE - t >= 0 ? my[(2 * SE - t) * kLdsVox] : make_float2(0.0f, 0.0f);
+                        return st;
+                    };
+                    auto finish = [&](int t, const Stage& st) {
+                        const float F = fmaf(fmaf(fmaf(st.kk.w, st.f, st.kk.z), st.f, st.kk.y), st.f, st.kk.x);
+                        const float yh = qb::exp2f_(fmaf(fv.nd, F, lt)) + qb::exp2f_(fmaf(fv.ng, st.bb, lb));
+                        const float r = fmaf(-yh, st.d0.y, st.d0.x);
+                        acc = fmaf(r, r, acc);
+                        if (2 * SE - t >= 0) {
+                            const float r1 = fmaf(-yh, st.d1.y, st.d1.x);
+                            acc = fmaf(r1, r1, acc);
+                        }
+                    };
+                    {
+                        const float2 dd = my[SE * kLdsVox];
+                        const float r = fmaf(-(s_se * inv_np), dd.y, dd.x);
+                        acc = fmaf(r, r, acc);
+                    }
+                    static_assert(2 * SE - (T - 1) <= 0, "the pipelined form covers protocols whose taus below the "
+                                                         "spin echo all have a mirror partner");
+                    // QB_LDS_DEPTH evaluations ahead; sched_barrier pins BOTH the requests and the arithmetic (a memory
+                    // clobber alone lets the compiler sink tau t's arithmetic behind the next requests and wait for a
+                    // table row right behind its issue again)
+                    constexpr int D = QB_LDS_DEPTH;
+                    Stage ring[D + 1];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) ring[k] = issue(SE + 1 + k);
+#pragma unroll
+                    for (int t = SE + 1; t < T; ++t) {
+                        if (t + D < T) ring[(t - SE - 1 + D) % (D + 1)] = issue(t + D);
+                        __builtin_amdgcn_sched_barrier(0);
+                        finish(t, ring[(t - SE - 1) % (D + 1)]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#else
                     auto signal = [&](int t) -> float {
                         const float u = fabsf(fmaf((float)t, fv.ub, fv.ua));
                         const float4 kk = L.tab[(int)u];
@@ -331,6 +404,7 @@ __global__ __launch_bounds__(kLdsBlock) void elbo_fwd_lds_kernel(
                     }
 #pragma unroll
                     for (int t = 0; t < 2 * SE - (T - 1); ++t) residual(t, signal(t));  // no partner on the grid
+#endif
                     nll_sum += acc;
                 }
             }
@@ -595,6 +669,11 @@ int elbo_fwd_launch(const qbold_ctx* ctx, const float* x, const float* mask, con
     hipLaunchKernelGGL((elbo_fwd_kernel<TT, SE, FAST, LIT>), dim3(grid), dim3(kBlock), 0, s,      \
                        ctx->dev, ctx->d_tab, x, mask, q, prior, sigma, zs, zk, S, K, seed, voxel0, \
                        out, partials, N)
+#define QB_LAUNCH_ELBO_GT(TT, SE)                                                                \
+    hipLaunchKernelGGL((elbo_fwd_kernel<TT, SE, true, false, true>), dim3(grid), dim3(kBlock), 0, s, \
+                       ctx->dev, ctx->d_gtab, x, mask, q, prior, sigma, zs, zk, S, K, seed, voxel0, \
+                       out, partials, N)
+    const bool gt = ctx->gtab_ok && !(ctx->kernel_sel & 8);
     const bool fast = qb::elbo_fast_path(ctx);
     // long protocols: compile-time tau count and spin-echo index when tau = 0 there (mirrored pairs).  On the
     // float32 grid start + i step the spin-echo tau of config 3 (-0.015 + 12 * 0.00125) is zero only up to
@@ -620,14 +699,16 @@ int elbo_fwd_launch(const qbold_ctx* ctx, const float* x, const float* mask, con
                                ctx->d_tab, x, mask, q, prior, sigma, zs, zk, S, K, seed, voxel0, out, partials, N);
     } else switch (ctx->dev.T) {
         case 11:
-            if (fast && ctx->dev.se_idx == 2 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(11, 2, true, false);
+            if (fast && ctx->dev.se_idx == 2 && !ctx->dev.multi_norm && gt) QB_LAUNCH_ELBO_GT(11, 2);
+            else if (fast && ctx->dev.se_idx == 2 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(11, 2, true, false);
             else if (fast) QB_LAUNCH_ELBO(11, -1, true, false);
             else if (lit && ctx->dev.se_idx == 2 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(11, 2, false, true);
             else if (lit) QB_LAUNCH_ELBO(11, -1, false, true);
             else QB_LAUNCH_ELBO(11, -1, false, false);
             break;
         case 24:  // the reference's second protocol (signals.py:120-121); se_idx = 7
-            if (fast && ctx->dev.se_idx == 7 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(24, 7, true, false);
+            if (fast && ctx->dev.se_idx == 7 && !ctx->dev.multi_norm && gt) QB_LAUNCH_ELBO_GT(24, 7);
+            else if (fast && ctx->dev.se_idx == 7 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(24, 7, true, false);
             else if (fast) QB_LAUNCH_ELBO(24, -1, true, false);
             else if (lit && ctx->dev.se_idx == 7 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(24, 7, false, true);
             else if (lit) QB_LAUNCH_ELBO(24, -1, false, true);

@@ -54,6 +54,16 @@ struct QbDev {
 #define QB_ABLATE(c, bit) 0
 #define QB_ABLATE_MASK(c) 0
 #endif
+// A wave-uniform condition the compiler cannot fold (always true).  The fused kernel's phases sit behind such
+// branches: as separate basic blocks the encoder's MFMA chains and the sampling loops are scheduled and
+// register-allocated on their own.  Measured: with the phases in one block (the round-2 ablation branches compiled
+// out and nothing in their place) vi_fwd_kernel<11, 2, 2> spills 372 bytes per lane and takes 0.67 instead of
+// 0.51 ms per 1 M voxels.
+__device__ __forceinline__ bool qb_phase_fence() {
+    int one = 1;
+    asm volatile("" : "+s"(one));
+    return one != 0;
+}
 
 namespace qb {
 
@@ -278,6 +288,34 @@ struct FwdLds {
     float blood_B[QB_MAX_T];  // QbDev::blood_B for the fused forward kernel's draw loop (a VGPR operand
                               // instead of an SGPR one: v_fma_f32 issues in 2.9 instead of 5.5 cycles)
 };
+
+// ---- per-tau tissue table of the sampling fast path ------------------------------------------------------------
+// Inside the ELBO kernels every (OEF, DBV) comes from forward_transform, so 0.04 <= OEF <= 0.84, and the protocol's
+// taus are j * |tau_step| about the spin echo (tau = 0 there, compile-time index SE).  F(|tau_j| dw(OEF)) is then
+// tabulated per tau ON ONE OEF GRID: G_j(OEF), cubic-Hermite segments in OEF.  The segment index and the fraction
+// are computed ONCE PER DRAW and serve every tau -- the per-tau coordinate FMA, v_cvt_i32, v_fract and address
+// shift of the x-indexed table are gone (3.5 of ~13 vector instructions per (draw, tau)), and the rows of all taus
+// sit at immediate offsets from one address register.  Accuracy (float64 construction, float32 coefficients): max
+// |G - F| = 4.7e-7 at 138 segments (T = 11), below the x-indexed table's own 9e-7 (whose float32 coordinate
+// arithmetic this form avoids).
+__host__ __device__ constexpr int gtab_taus(int T, int SE) { return SE > T - 1 - SE ? SE : T - 1 - SE; }
+#ifndef QB_GT_SEGS_11
+#define QB_GT_SEGS_11 138
+#endif
+__host__ __device__ constexpr int gtab_segs(int T) { return T == 11 ? QB_GT_SEGS_11 : (T == 24 ? 52 : 0); }
+#define QB_GT_OEF_MIN 0.04f
+#define QB_GT_OEF_RANGE 0.8f
+template <int T, int SE>
+struct GtLds {
+    static constexpr int J = gtab_taus(T, SE), NSEG = gtab_segs(T);
+    float4 gtab[J * NSEG];        // [j - 1][segment]: G_j on segment i as c0 + f (c1 + f (c2 + f c3))
+    float blood_B[(T + 3) & ~3];  // QbDev::blood_B (a VGPR operand instead of an SGPR one)
+};
+template <int T, int SE>
+__device__ __forceinline__ void gt_lds_fill(GtLds<T, SE>* L, const float4* __restrict__ g_gtab, const QbDev& c) {
+    for (int i = threadIdx.x; i < GtLds<T, SE>::J * GtLds<T, SE>::NSEG; i += blockDim.x) L->gtab[i] = g_gtab[i];
+    if (threadIdx.x < T) L->blood_B[threadIdx.x] = c.blood_B[threadIdx.x];
+}
 
 __device__ __forceinline__ void fwd_lds_fill(FwdLds* L, const float4* __restrict__ g_tab,
                                              bool literal) {

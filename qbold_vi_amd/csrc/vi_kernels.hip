@@ -61,7 +61,15 @@ using qb::f32x4;
 constexpr int kBlock = 1024;
 constexpr int kWaves = kBlock / 64;
 
-template <int T, int NL, int SE, bool FAST, bool LITERAL, bool BF>
+template <int T, int SE, bool GT>
+struct ViLds { using type = qb::FwdLds; };
+template <int T, int SE>
+struct ViLds<T, SE, true> { using type = qb::GtLds<T, SE>; };
+constexpr size_t kLdsLimit = 160 * 1024;   // gfx950: LDS per workgroup
+
+// GT: the sampling fast path reads the per-tau OEF-indexed table (GtLds) instead of the x-indexed one (FwdLds);
+// requires FAST and a compile-time spin-echo index.
+template <int T, int NL, int SE, bool FAST, bool LITERAL, bool BF, bool GT = false>
 __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
     QbDev c, const float4* __restrict__ g_tab, const float* __restrict__ packed,
     const float* __restrict__ x, const float* __restrict__ mask, const float* __restrict__ prior,
@@ -69,14 +77,22 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
     float2* __restrict__ nll_kl, double* __restrict__ partials, int64_t N) {
     // compile-time weight-image layout: every LDS offset below folds into an instruction immediate
     constexpr EncLayout e = qb::make_enc_layout(T, 64, NL);
+    // the sampling phase's table: per-tau OEF-indexed rows (GtLds) on the fast path with a compile-time spin-echo
+    // index, the x-indexed table + literal nodes (FwdLds) otherwise; g_tab points at the matching device table
+    static_assert(!GT || (FAST && SE >= 0 && qb::gtab_segs(T) > 0), "GT needs the fast path with a compile-time spin echo");
+    using Lds = typename ViLds<T, SE, GT>::type;
     extern __shared__ __align__(16) unsigned char smem[];
     float* lds_w = reinterpret_cast<float*>(smem);
-    qb::FwdLds* L = reinterpret_cast<qb::FwdLds*>(smem + sizeof(float) * e.total);
-    double* red = reinterpret_cast<double*>(smem + sizeof(float) * e.total + sizeof(qb::FwdLds));
+    Lds* L = reinterpret_cast<Lds*>(smem + sizeof(float) * e.total);
+    double* red = reinterpret_cast<double*>(smem + sizeof(float) * e.total + sizeof(Lds));
     for (int p = threadIdx.x; p < e.total / 4; p += kBlock)
         reinterpret_cast<float4*>(lds_w)[p] = reinterpret_cast<const float4*>(packed)[p];
-    qb::fwd_lds_fill(L, g_tab, true);
-    if (threadIdx.x < QB_MAX_T) L->blood_B[threadIdx.x] = c.blood_B[threadIdx.x];
+    if constexpr (qb::IsGtLds<Lds>::value) {
+        qb::gt_lds_fill(L, g_tab, c);
+    } else {
+        qb::fwd_lds_fill(L, g_tab, true);
+        if (threadIdx.x < QB_MAX_T) L->blood_B[threadIdx.x] = c.blood_B[threadIdx.x];
+    }
     __syncthreads();
 
     constexpr int HT = (5 + T + 15) / 16;
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
             __builtin_amdgcn_s_setprio(2);
             f32x4 b[4];
             qb::dense_first<T, BF>(lds_w + e.first_A, lds_w + e.first_b, nv, b, lane);
-            if (!QB_ABLATE(c, 1))
+            if (!QB_ABLATE(c, 1) && qb_phase_fence())
 #pragma unroll
                 for (int l = 0; l < NL; ++l) qb::block_stream2<BF>(lds_w + e.blk0 + l * e.blk_stride, b, lane, &amax);
             f32x4 hd[HT];
@@ -109,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
             qb::gather_head<5 + T, HT>(hd, o);
             __builtin_amdgcn_s_setprio(0);
         }
-        if (v < N && !QB_ABLATE(c, 2)) {
+        if (v < N && !QB_ABLATE(c, 2) && qb_phase_fence()) {
             // x is read again (an L1/L2 hit) rather than held in 11 VGPRs across the encoder; the
             // empty asm keeps the compiler from merging the two reads
             const float* xr = x + v * T;
@@ -194,8 +210,6 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     QB_REQUIRE(N >= 0 && S >= 1 && K >= 0, "qbold_vi_fwd: need N >= 0, S >= 1, K >= 0");
     QB_REQUIRE(sums && workspace, "qbold_vi_fwd: null sums/workspace");
     QB_REQUIRE(N == 0 || (packed && x && prior), "qbold_vi_fwd: null input buffer");
-    const EncLayout e = qb::make_enc_layout(shape->T, shape->U, shape->L);
-    const size_t smem = sizeof(float) * e.total + sizeof(qb::FwdLds) + sizeof(double) * 3 * kWaves;
     hipStream_t s = (hipStream_t)stream;
     double* partials = reinterpret_cast<double*>(workspace);
     const int64_t ntile = (N + 15) / 16;
@@ -208,20 +222,27 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     // configuration); the literal and generic paths exist to reproduce float32 semantics
     QB_REQUIRE(!bf || qb::elbo_fast_path(ctx),
                "qbold_vi_fwd: QBOLD_ENC_BF16 needs the table-mode Gaussian fast path");
-#define QB_LAUNCH_VI(TT, NL, SE, FAST, LIT)                                                          \
+#define QB_LAUNCH_VI(TT, NL, SE, FAST, LIT) QB_LAUNCH_VI_GT(TT, NL, SE, FAST, LIT, false)
+#define QB_LAUNCH_VI_GT(TT, NL, SE, FAST, LIT, GT)                                                   \
     do {                                                                                          \
-        auto k = vi_fwd_kernel<TT, NL, SE, FAST, LIT, false>;                                      \
-        if constexpr (FAST) { if (bf) k = vi_fwd_kernel<TT, NL, SE, FAST, LIT, true>; }            \
+        using LdsT = typename ViLds<TT, SE, GT>::type;                                             \
+        constexpr size_t smem = sizeof(float) * qb::make_enc_layout(TT, 64, NL).total + sizeof(LdsT) + \
+                                sizeof(double) * 3 * kWaves;                                       \
+        static_assert(smem <= kLdsLimit, "weight image + sampling table exceed the LDS");          \
+        const float4* tab = qb::IsGtLds<LdsT>::value ? ctx->d_gtab : ctx->d_tab;                    \
+        auto k = vi_fwd_kernel<TT, NL, SE, FAST, LIT, false, GT>;                                  \
+        if constexpr (FAST) { if (bf) k = vi_fwd_kernel<TT, NL, SE, FAST, LIT, true, GT>; }        \
         QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                              \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));       \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), smem, s, ctx->dev, ctx->d_tab, packed,    \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), smem, s, ctx->dev, tab, packed,            \
                            x, mask, prior, S, K, seed, voxel0, q_out, out, partials, N);          \
     } while (0)
     const bool fast = qb::elbo_fast_path(ctx);
     // SEC: the protocol's spin-echo index (tau = 0), folded at compile time when the context agrees
 #define QB_DISPATCH_VI(TT, NL, SEC)                                               \
     do {                                                                          \
-        if (fast && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm && !(ctx->kernel_sel & 4)) QB_LAUNCH_VI(TT, NL, SEC, true, false);   \
+        if (fast && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm && !(ctx->kernel_sel & 4) && ctx->gtab_ok && !(ctx->kernel_sel & 8)) QB_LAUNCH_VI_GT(TT, NL, SEC, true, false, true);   \
+        else if (fast && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm && !(ctx->kernel_sel & 4)) QB_LAUNCH_VI(TT, NL, SEC, true, false);   \
         else if (fast) QB_LAUNCH_VI(TT, NL, -1, true, false);                     \
         else if (lit && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm) QB_LAUNCH_VI(TT, NL, SEC, false, true);   \
         else if (lit) QB_LAUNCH_VI(TT, NL, -1, false, true);                      \
@@ -237,6 +258,7 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     }
 #undef QB_DISPATCH_VI
 #undef QB_LAUNCH_VI
+#undef QB_LAUNCH_VI_GT
     QB_HIP(hipGetLastError());
     hipLaunchKernelGGL(qb::reduce_partials_kernel, dim3(1), dim3(192), 0, s, partials, grid, sums);
     QB_HIP(hipGetLastError());

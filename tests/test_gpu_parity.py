@@ -903,3 +903,51 @@ def test_one_launch_wide_encoder_on_partly_filled_tau_tiles(params, T):
         _, q, sg = ctx.encoder_fwd(ew, torch.as_tensor(x, device="cuda"), want=("out2", "sigma"))
         assert np.abs(q.cpu().numpy() - q_want).max() < 5e-5, (T, n)
         assert (np.abs(sg.cpu().numpy() - sg_want) / sg_want).max() < 5e-5, (T, n)
+
+
+def test_per_tau_table_against_the_x_indexed_table(ctx, weights, oracle32, params):
+    """The sampling fast path reads the tissue integral from a per-tau OEF-indexed table (one segment index per DRAW,
+    DESIGN 4.3); QBOLD_KSEL_X_TABLE selects the round-1/2 form with one x-indexed lookup per (draw, tau).  Both against
+    the oracle on the same Philox stream, fused and unfused, 11 and 24 taus."""
+    from oracle.oracle import Oracle, init_weights, synth_inputs
+    from qbold_vi_amd.ops import Context, EncoderWeights
+    w, ew = weights
+    n, S, K, seed = 4096, 32, 70, 13
+    x, _ = synth_inputs(n, seed=21, oracle=oracle32)
+    prior, q_want, sigma = oracle32.encoder_fwd(w, x)
+    mask = (np.random.default_rng(2).uniform(size=n) > 0.2).astype(np.float32)
+    want = oracle32.elbo(x, mask, q_want, prior, sigma, oracle32.philox_normals(seed, 0, 0, n, S),
+                         oracle32.philox_normals(seed, 1, 0, n, K))
+    got = {}
+    try:
+        for sel in (0, 8):
+            ctx.set_kernel_selection(sel)
+            _, _, nk_f = ctx.vi_fwd(ew, dev(x), dev(mask), dev(prior), S, K, seed=seed)
+            _, nk_u = ctx.elbo_fwd(dev(x), dev(mask), dev(q_want), dev(prior), dev(sigma), S, K, seed=seed)
+            got[sel] = (nk_f.cpu().numpy(), nk_u.cpu().numpy())
+    finally:
+        ctx.set_kernel_selection(0)
+    for sel, (nk_f, nk_u) in got.items():
+        for nk in (nk_f, nk_u):
+            assert rel(nk[:, 0], want["nll_v"], 1.0) < 2e-4, sel
+            assert rel(nk[:, 1], want["kl_v"], 1.0) < 2e-4, sel
+    assert not np.array_equal(got[0][0], got[8][0])                    # two different kernels did run
+    assert rel(got[0][0][:, 0], got[8][0][:, 0], 1.0) < 5e-5           # ... and agree far inside the oracle gate
+    assert rel(got[0][1][:, 0], got[8][1][:, 0], 1.0) < 5e-5
+    # 24 taus (52 segments per tau)
+    p24 = dict(params, tau_start="-0.028", tau_end="0.065", tau_step="0.004")
+    o24 = Oracle("f32", p24)
+    c24 = Context(p24, True, True)
+    w24 = init_weights(T=24, U=60, L=2, seed=5)
+    w24["gate_offset"] = -3.0
+    e24 = EncoderWeights(c24, 24, 60, 2, True, -3.0).set_from_arrays(w24)
+    x24 = o24.signal_fwd(np.stack([np.random.default_rng(3).uniform(0.1, 0.7, 1024),
+                                   np.random.default_rng(4).uniform(0.005, 0.1, 1024)], -1).astype(np.float32))
+    x24 = (x24 * (1 + 0.01 * np.random.default_rng(5).standard_normal(x24.shape))).astype(np.float32)
+    p1, q24, s24 = o24.encoder_fwd(w24, x24)
+    want24 = o24.elbo(x24, np.ones(1024, np.float32), q24, p1, s24, o24.philox_normals(seed, 0, 0, 1024, 8),
+                      o24.philox_normals(seed, 1, 0, 1024, 20))
+    for sel in (0, 8):
+        c24.set_kernel_selection(sel)
+        _, _, nk = c24.vi_fwd(e24, dev(x24), None, dev(p1), 8, 20, seed=seed)
+        assert rel(nk.cpu().numpy()[:, 0], want24["nll_v"], 1.0) < 2e-4, sel
