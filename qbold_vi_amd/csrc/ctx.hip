@@ -198,7 +198,7 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
     // protocols whose spin-echo image sits at tau = 0 exactly (both of the reference's, signals.py:117-121).
     {
         const int nseg = qb::gtab_segs(T), se = d.se_idx;
-        const bool proto = (T == 11 && se == 2) || (T == 24 && se == 7);
+        const bool proto = (T == 11 && se == 2);   // the protocol the table-driven kernels are instantiated for
         if (nseg > 0 && proto && d.taus[se] == 0.0f && P->full_model) {
             const int J = qb::gtab_taus(T, se);
             ctx->h_gtab.resize((size_t)4 * J * nseg);

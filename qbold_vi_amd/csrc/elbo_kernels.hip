@@ -670,10 +670,10 @@ int elbo_fwd_launch(const qbold_ctx* ctx, const float* x, const float* mask, con
                        ctx->dev, ctx->d_tab, x, mask, q, prior, sigma, zs, zk, S, K, seed, voxel0, \
                        out, partials, N)
 #define QB_LAUNCH_ELBO_GT(TT, SE)                                                                \
-    hipLaunchKernelGGL((elbo_fwd_kernel<TT, SE, true, false, true>), dim3(grid), dim3(kBlock), 0, s, \
+    hipLaunchKernelGGL((elbo_fwd_kernel<TT, SE, true, false, (qb::gtab_segs(TT) > 0)>), dim3(grid), dim3(kBlock), 0, s, \
                        ctx->dev, ctx->d_gtab, x, mask, q, prior, sigma, zs, zk, S, K, seed, voxel0, \
                        out, partials, N)
-    const bool gt = ctx->gtab_ok && !(ctx->kernel_sel & 8);
+    const bool gt = ctx->gtab_ok && !(ctx->kernel_sel & 8) && qb::gtab_segs(ctx->dev.T) > 0;
     const bool fast = qb::elbo_fast_path(ctx);
     // long protocols: compile-time tau count and spin-echo index when tau = 0 there (mirrored pairs).  On the
     // float32 grid start + i step the spin-echo tau of config 3 (-0.015 + 12 * 0.00125) is zero only up to

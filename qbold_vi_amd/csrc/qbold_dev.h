@@ -302,13 +302,15 @@ __host__ __device__ constexpr int gtab_taus(int T, int SE) { return SE > T - 1 -
 #ifndef QB_GT_SEGS_11
 #define QB_GT_SEGS_11 138
 #endif
-__host__ __device__ constexpr int gtab_segs(int T) { return T == 11 ? QB_GT_SEGS_11 : (T == 24 ? 52 : 0); }
+// T = 24 keeps the x-indexed table: 52 segments would fit beside its weight image, but with 48 data registers live the
+// ring spills (0.947 against 0.755 ms per 1 M voxels, measured)
+__host__ __device__ constexpr int gtab_segs(int T) { return T == 11 ? QB_GT_SEGS_11 : 0; }
 #define QB_GT_OEF_MIN 0.04f
 #define QB_GT_OEF_RANGE 0.8f
 template <int T, int SE>
 struct GtLds {
     static constexpr int J = gtab_taus(T, SE), NSEG = gtab_segs(T);
-    float4 gtab[J * NSEG];        // [j - 1][segment]: G_j on segment i as c0 + f (c1 + f (c2 + f c3))
+    float4 gtab[J * NSEG > 0 ? J * NSEG : 1];        // [j - 1][segment]: G_j on segment i as c0 + f (c1 + f (c2 + f c3))
     float blood_B[(T + 3) & ~3];  // QbDev::blood_B (a VGPR operand instead of an SGPR one)
 };
 template <int T, int SE>

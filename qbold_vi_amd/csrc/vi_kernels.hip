@@ -241,7 +241,7 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     // SEC: the protocol's spin-echo index (tau = 0), folded at compile time when the context agrees
 #define QB_DISPATCH_VI(TT, NL, SEC)                                               \
     do {                                                                          \
-        if (fast && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm && !(ctx->kernel_sel & 4) && ctx->gtab_ok && !(ctx->kernel_sel & 8)) QB_LAUNCH_VI_GT(TT, NL, SEC, true, false, true);   \
+        if (qb::gtab_segs(TT) > 0 && fast && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm && !(ctx->kernel_sel & 4) && ctx->gtab_ok && !(ctx->kernel_sel & 8)) QB_LAUNCH_VI_GT(TT, NL, SEC, true, false, (qb::gtab_segs(TT) > 0));   \
         else if (fast && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm && !(ctx->kernel_sel & 4)) QB_LAUNCH_VI(TT, NL, SEC, true, false);   \
         else if (fast) QB_LAUNCH_VI(TT, NL, -1, true, false);                     \
         else if (lit && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm) QB_LAUNCH_VI(TT, NL, SEC, false, true);   \

@@ -500,7 +500,7 @@ def test_full_size_properties_one_million_voxels(ctx, weights, oracle32, params)
     # sums are the masked checksum of the per-voxel outputs
     nkd, md = nk.double(), mask.double()
     assert abs(float((nkd[:, 0] * md).sum()) / float(sums[0]) - 1) < 1e-9
-    assert abs(float(nkd[:, 1][mask > 0].sum()) / float(sums[1]) - 1) < 1e-9
+    assert abs(float(nkd[:, 1][mask > 0].sum()) / float(sums[1]) - 1) < 1e-8    # float32 lane partials of a cancelling sum
     assert float(sums[2]) == float(md.sum())
     # four shards keyed by their first global voxel == the whole batch
     parts, acc = [], torch.zeros_like(sums)
@@ -782,7 +782,7 @@ def test_config3_full_size_properties(params):
     assert bool(torch.isfinite(nk).all()) and bool(torch.isfinite(sums).all())
     nkd, md = nk.double(), mask.double()
     assert abs(float((nkd[:, 0] * md).sum()) / float(sums[0]) - 1) < 1e-9
-    assert abs(float(nkd[:, 1][mask > 0].sum()) / float(sums[1]) - 1) < 1e-9
+    assert abs(float(nkd[:, 1][mask > 0].sum()) / float(sums[1]) - 1) < 1e-8    # float32 lane partials of a cancelling sum
     assert float(sums[2]) == float(md.sum())
     parts, acc = [], torch.zeros_like(sums)
     for a, b in ((0, 300_001), (300_001, 700_000), (700_000, N)):   # ragged shards: partial passes in the middle
@@ -934,7 +934,7 @@ def test_per_tau_table_against_the_x_indexed_table(ctx, weights, oracle32, param
     assert not np.array_equal(got[0][0], got[8][0])                    # two different kernels did run
     assert rel(got[0][0][:, 0], got[8][0][:, 0], 1.0) < 5e-5           # ... and agree far inside the oracle gate
     assert rel(got[0][1][:, 0], got[8][1][:, 0], 1.0) < 5e-5
-    # 24 taus (52 segments per tau)
+    # 24 taus: the x-indexed table under either selection (the per-tau table is built for the 11-tau protocol)
     p24 = dict(params, tau_start="-0.028", tau_end="0.065", tau_step="0.004")
     o24 = Oracle("f32", p24)
     c24 = Context(p24, True, True)
@@ -951,3 +951,40 @@ def test_per_tau_table_against_the_x_indexed_table(ctx, weights, oracle32, param
         c24.set_kernel_selection(sel)
         _, _, nk = c24.vi_fwd(e24, dev(x24), None, dev(p1), 8, 20, seed=seed)
         assert rel(nk.cpu().numpy()[:, 0], want24["nll_v"], 1.0) < 2e-4, sel
+
+
+def test_whitened_kl_draws_against_the_general_form(ctx, oracle32):
+    """The KL draws on in-kernel normals run in whitened form (|d + M z|^2 - |z|^2, elbo_core.h) while the clip of the
+    logits cannot bind; explicit normals and posteriors wide enough to reach the clip take the general loop.  Same
+    stream, both forms, against each other and the oracle -- including posteriors whose draws ARE clipped."""
+    n, K, seed = 2048, 70, 31
+    rng = np.random.default_rng(17)
+    q = make_q(n, seed=5)
+    prior = make_q(n, seed=6)
+    x = np.abs(rng.normal(0.4, 0.05, (n, 11))).astype(np.float32) + 0.1
+    sigma = np.full((n, 11), 0.05, np.float32)
+    z = oracle32.philox_normals(seed, 1, 0, n, K)
+    assert np.abs(z).max() < 6.7636
+    want = oracle32.kl_samples(q, prior, z)
+    white = ctx.kl_fwd(dev(q), dev(prior), K=K, seed=seed).cpu().numpy()                 # stand-alone KL kernel
+    _, nk_w = ctx.elbo_fwd(dev(x), None, dev(q), dev(prior), dev(sigma), 2, K, seed=seed)            # whitened
+    _, nk_g = ctx.elbo_fwd(dev(x), None, dev(q), dev(prior), dev(sigma), 2, K, seed=seed, zk=dev(z),
+                           zs=dev(oracle32.philox_normals(seed, 0, 0, n, 2)))                          # general
+    for got in (white, nk_w[:, 1].cpu().numpy(), nk_g[:, 1].cpu().numpy()):
+        assert rel(got, want, 1.0) < 1e-4
+    assert rel(nk_w[:, 1].cpu().numpy(), nk_g[:, 1].cpu().numpy(), 1.0) < 2e-5
+    assert torch.equal(nk_w[:, 0], nk_g[:, 0])                                           # same likelihood draws
+    # wide posteriors far from the centre: draws beyond the clip at +-13.8155 (model.py:393-396)
+    qw = q.copy()
+    qw[:, 0] = rng.choice([-11.0, 11.0], n)
+    qw[:, 1] = 3.0            # s_o -> 2: e^s = 7.4
+    qw[::2, 2] = -12.0
+    a = qw[:, 0:1] + z[:, :, 0] * np.exp(3 * np.tanh(qw[:, 1:2]) - 1)
+    assert (np.abs(a) > 13.8155).mean() > 0.2                                            # the clip does bind
+    want_w = oracle32.kl_samples(qw, prior, z)
+    _, nk_c = ctx.elbo_fwd(dev(x), None, dev(qw), dev(prior), dev(sigma), 2, K, seed=seed)
+    assert rel(nk_c[:, 1].cpu().numpy(), want_w, 1.0) < 2e-4
+    # an odd number of KL draws: the untaken second draw of the last pair
+    want_o = oracle32.kl_samples(q, prior, oracle32.philox_normals(seed, 1, 0, n, 7))
+    _, nk_o = ctx.elbo_fwd(dev(x), None, dev(q), dev(prior), dev(sigma), 2, 7, seed=seed)
+    assert rel(nk_o[:, 1].cpu().numpy(), want_o, 1.0) < 1e-4
