@@ -300,6 +300,67 @@ __device__ __forceinline__ float kl_swr_diff(const LogitMvn& q, const LogitMvn& 
     return fmaf(wp0, wp0, wp1 * wp1) - fmaf(wq0, wq0, wq1 * wq1);
 }
 
+// The K KL draws of one voxel restricted to this lane's share, fast path: returns sum over the draws of
+// (swr_p - swr_q); n_kl = draws taken.  zk: explicit normals [K][2] or nullptr for the Philox stream.
+//
+// Whitened form (in-kernel Philox normals).  A draw y = mu_q + L_q z has, under q itself, the whitened residual z
+// exactly, and under the prior  L_p^-1 (mu_q - mu_p) + (L_p^-1 L_q) z = d + M z  with d and the lower-triangular M
+// fixed per voxel: swr_p - swr_q = |d + M z|^2 - |z|^2, seven instructions per draw instead of nineteen, no logits
+// formed (and none of their cancellation: against the float64 oracle this form is at 2e-6 where the general one --
+// the reference's arithmetic -- is at 8e-4 for far-apart q and prior).  Valid while the clip of the logits at
+// +-13.8155 (model.py:393-396) cannot bind: Box-Muller on u >= 2^-33 bounds |z| by 6.7636, so it cannot when
+// |mu| + 6.7636 (|c| + e^s) stays below the clip for both logits.  Decided per wave (any lane over the bound, or
+// explicit normals: the general loop for all).
+__device__ __forceinline__ float kl_draws_fast(const LogitMvn& q, const LogitMvn& prior, int K,
+                                               const float* __restrict__ zk, uint64_t seed, uint64_t vox, int part,
+                                               int& n_kl) {
+    constexpr float kZMax = 6.7636f;
+    const float reach = fmaxf(fabsf(q.mu_o) + kZMax * q.e_so, fabsf(q.mu_d) + kZMax * (fabsf(q.c) + q.e_sd));
+    float kl_sum = 0.0f;
+    if (zk == nullptr && __all(reach < QB_LOGIT_CLIP)) {
+        const float dmu_o = q.mu_o - prior.mu_o, dmu_d = q.mu_d - prior.mu_d;
+        const float d0 = dmu_o * prior.i_so, m00 = q.e_so * prior.i_so;
+        const float d1 = fmaf(dmu_d, prior.i_sd, dmu_o * prior.i_bl);
+        const float m10 = fmaf(q.c, prior.i_sd, q.e_so * prior.i_bl), m11 = q.e_sd * prior.i_sd;
+        float sp = 0.0f, sq = 0.0f, untaken = 0.0f;
+        for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
+            float z[4];
+            const bool two = 2 * j + 1 < K;
+            n_kl += two ? 2 : 1;
+            normals4(seed, vox, (uint32_t)j, STREAM_KL, z);
+            if (!two) {   // an odd K: the pair's second draw is not taken -- with z = 0 it adds |d|^2, removed below
+                z[2] = z[3] = 0.0f;
+                untaken = fmaf(d0, d0, d1 * d1);
+            }
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const float w0 = fmaf(m00, z[2 * d], d0), w1 = fmaf(m11, z[2 * d + 1], fmaf(m10, z[2 * d], d1));
+                sp = fmaf(w0, w0, sp);
+                sp = fmaf(w1, w1, sp);
+                sq = fmaf(z[2 * d], z[2 * d], sq);
+                sq = fmaf(z[2 * d + 1], z[2 * d + 1], sq);
+            }
+        }
+        return (sp - untaken) - sq;
+    }
+    for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
+        float z[4];
+        const bool two = 2 * j + 1 < K;
+        n_kl += two ? 2 : 1;
+        if (zk) {
+            z[0] = zk[4 * j];
+            z[1] = zk[4 * j + 1];
+            z[2] = two ? zk[4 * j + 2] : 0.0f;
+            z[3] = two ? zk[4 * j + 3] : 0.0f;
+        } else {
+            normals4(seed, vox, (uint32_t)j, STREAM_KL, z);
+        }
+        kl_sum += kl_swr_diff(q, prior, z[0], z[1]);
+        if (two) kl_sum += kl_swr_diff(q, prior, z[2], z[3]);
+    }
+    return kl_sum;
+}
+
 // The two Monte-Carlo sums of one voxel restricted to this lane's share of the draws.
 //   nll_sum = sum over this half's likelihood draws of the per-draw NLL
 //   kl_sum  = sum over this half's KL draws of log q(y) - log p(y)          model.py:596-603
@@ -349,62 +410,24 @@ __device__ __forceinline__ void voxel_mc_sums(const LDS* L, const QbDev& c,
     for (int k = 0; k < 5; ++k) pv[k] = prior_row[k];
     const LogitMvn prior = make_mvn(pv);
     __builtin_amdgcn_s_setprio(QB_PRIO_KL);
-    // Whitened form of the KL draws (FAST, in-kernel Philox normals).  A draw y = mu_q + L_q z has, under q itself,
-    // the whitened residual z exactly, and under the prior  L_p^-1 (mu_q - mu_p) + (L_p^-1 L_q) z = d + M z  with d
-    // and the lower-triangular M fixed per voxel: swr_p - swr_q = |d + M z|^2 - |z|^2, seven instructions per draw
-    // instead of nineteen, no logits formed.  Valid while the clip of the logits at +-13.8155 (model.py:393-396)
-    // cannot bind: Box-Muller on u >= 2^-33 bounds |z| by 6.7636, so it cannot when |mu| + 6.7636 (|c| + e^s) stays
-    // below the clip for both logits.  Decided per wave (any lane over the bound: the general loop for all).
-    bool whitened = false;
     if constexpr (FAST) {
-        constexpr float kZMax = 6.7636f;
-        const float reach = fmaxf(fabsf(q.mu_o) + kZMax * q.e_so, fabsf(q.mu_d) + kZMax * (fabsf(q.c) + q.e_sd));
-        whitened = zk == nullptr && __all(reach < QB_LOGIT_CLIP);
-    }
-    if (whitened) {
-        const float dmu_o = q.mu_o - prior.mu_o, dmu_d = q.mu_d - prior.mu_d;
-        const float d0 = dmu_o * prior.i_so, m00 = q.e_so * prior.i_so;
-        const float d1 = fmaf(dmu_d, prior.i_sd, dmu_o * prior.i_bl);
-        const float m10 = fmaf(q.c, prior.i_sd, q.e_so * prior.i_bl), m11 = q.e_sd * prior.i_sd;
-        float sp = 0.0f, sq = 0.0f, untaken = 0.0f;
+        kl_sum = kl_draws_fast(q, prior, K, zk, seed, vox, part, n_kl);
+    } else {
         for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
             float z[4];
             const bool two = 2 * j + 1 < K;
             n_kl += two ? 2 : 1;
-            normals4(seed, vox, (uint32_t)j, STREAM_KL, z);
-            if (!two) {   // an odd K: the pair's second draw is not taken -- with z = 0 it adds |d|^2, removed below
-                z[2] = z[3] = 0.0f;
-                untaken = fmaf(d0, d0, d1 * d1);
+            if (zk) {
+                z[0] = zk[4 * j];
+                z[1] = zk[4 * j + 1];
+                z[2] = two ? zk[4 * j + 2] : 0.0f;
+                z[3] = two ? zk[4 * j + 3] : 0.0f;
+            } else {
+                normals4(seed, vox, (uint32_t)j, STREAM_KL, z);
             }
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
-                const float w0 = fmaf(m00, z[2 * d], d0), w1 = fmaf(m11, z[2 * d + 1], fmaf(m10, z[2 * d], d1));
-                sp = fmaf(w0, w0, sp);
-                sp = fmaf(w1, w1, sp);
-                sq = fmaf(z[2 * d], z[2 * d], sq);
-                sq = fmaf(z[2 * d + 1], z[2 * d + 1], sq);
-            }
-        }
-        kl_sum = (sp - untaken) - sq;
-    } else
-    for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
-        float z[4];
-        const bool two = 2 * j + 1 < K;
-        n_kl += two ? 2 : 1;
-        if (zk) {
-            z[0] = zk[4 * j];
-            z[1] = zk[4 * j + 1];
-            z[2] = two ? zk[4 * j + 2] : 0.0f;
-            z[3] = two ? zk[4 * j + 3] : 0.0f;
-        } else {
-            normals4(seed, vox, (uint32_t)j, STREAM_KL, z);
-        }
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            if (d == 1 && !two) break;
-            if (FAST) {
-                kl_sum += kl_swr_diff(q, prior, z[2 * d], z[2 * d + 1]);
-            } else {
+                if (d == 1 && !two) break;
                 float a, b, oef, dbv;
                 reparam_logits(q, z[2 * d], z[2 * d + 1], a, b);  // create_samples, model.py:318-324
                 forward_transform(a, b, oef, dbv);

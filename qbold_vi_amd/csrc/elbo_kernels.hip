@@ -200,21 +200,7 @@ __global__ __launch_bounds__(kGenBlock) void elbo_fwd_generic_kernel(
 #pragma unroll
             for (int i = 0; i < 5; ++i) pv[i] = prior[v * 5 + i];
             const qb::LogitMvn pm = qb::make_mvn(pv);
-            for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
-                float z[4];
-                const bool two = 2 * j + 1 < K;
-                if (zkv) {
-                    z[0] = zkv[4 * j];
-                    z[1] = zkv[4 * j + 1];
-                    z[2] = two ? zkv[4 * j + 2] : 0.0f;
-                    z[3] = two ? zkv[4 * j + 3] : 0.0f;
-                } else {
-                    qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_KL, z);
-                }
-                n_kl += two ? 2 : 1;
-                kl_sum += qb::kl_swr_diff(qm, pm, z[0], z[1]);
-                if (two) kl_sum += qb::kl_swr_diff(qm, pm, z[2], z[3]);
-            }
+            kl_sum = qb::kl_draws_fast(qm, pm, K, zkv, seed, vox, part, n_kl);
             kl_sum = fmaf(0.5f, kl_sum, (float)n_kl * ((pm.s_o + pm.s_d) - (qm.s_o + qm.s_d)));
             const float nll = qb::voxel_sum(nll_sum) / (float)S;
             const float kl = K > 0 ? qb::voxel_sum(kl_sum) / (float)K : 0.0f;
@@ -414,21 +400,7 @@ __global__ __launch_bounds__(kLdsBlock) void elbo_fwd_lds_kernel(
             for (int i = 0; i < 5; ++i) pv[i] = prior[v * 5 + i];
             const qb::LogitMvn pm = qb::make_mvn(pv);
             __builtin_amdgcn_s_setprio(QB_PRIO_KL);
-            for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
-                float z[4];
-                const bool two = 2 * j + 1 < K;
-                if (zkv) {
-                    z[0] = zkv[4 * j];
-                    z[1] = zkv[4 * j + 1];
-                    z[2] = two ? zkv[4 * j + 2] : 0.0f;
-                    z[3] = two ? zkv[4 * j + 3] : 0.0f;
-                } else {
-                    qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_KL, z);
-                }
-                n_kl += two ? 2 : 1;
-                kl_sum += qb::kl_swr_diff(qm, pm, z[0], z[1]);
-                if (two) kl_sum += qb::kl_swr_diff(qm, pm, z[2], z[3]);
-            }
+            kl_sum = qb::kl_draws_fast(qm, pm, K, zkv, seed, vox, part, n_kl);
             __builtin_amdgcn_s_setprio(QB_PRIO_AFTER);
             kl_sum = fmaf(0.5f, kl_sum, (float)n_kl * ((pm.s_o + pm.s_d) - (qm.s_o + qm.s_d)));
             const float nll = qb::voxel_sum(nll_sum) / (float)S;

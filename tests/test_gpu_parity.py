@@ -988,7 +988,9 @@ def test_whitened_kl_draws_against_the_general_form(ctx, oracle32):
     assert (np.abs(a) > 13.8155).mean() > 0.2                                            # the clip does bind
     want_w = oracle32.kl_samples(qw, prior, z)
     _, nk_c = ctx.elbo_fwd(dev(x), None, dev(qw), dev(prior), dev(sigma), 2, K, seed=seed)
-    assert rel(nk_c[:, 1].cpu().numpy(), want_w, 1.0) < 1e-3          # general form on both sides (see above)
+    # general form on both sides, KL up to ~1.6e4: float32 cancellation of the large logits on either side (the
+    # whitened formula without the clip would be off by O(1) relative here)
+    assert rel(nk_c[:, 1].cpu().numpy(), want_w, 1.0) < 5e-3
     # an odd number of KL draws: the untaken second draw of the last pair
     want_o = Oracle("f64").kl_samples(q, prior, oracle32.philox_normals(seed, 1, 0, n, 7))
     _, nk_o = ctx.elbo_fwd(dev(x), None, dev(q), dev(prior), dev(sigma), 2, 7, seed=seed)
