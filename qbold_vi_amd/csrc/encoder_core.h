@@ -136,6 +136,9 @@ struct ActFrag {
 // NaN into 0).  The kernels therefore track max |activation| over everything they split (amax, one v_max3_f32
 // per pair of values) and poison the voxel's outputs with NaN when it passes the limit: non-finite outputs /
 // sums are the status channel of include/qbold_hip.h.
+#ifndef QB_AMAX_ASM
+#define QB_AMAX_ASM 1
+#endif
 #define QB_SPLIT_MAX 65504.0f
 __device__ __forceinline__ bool split_overflowed(float amax) { return !(amax <= QB_SPLIT_MAX); }
 
@@ -147,8 +150,17 @@ __device__ __forceinline__ ActFrag split_act(const f32x4 (&in)[4], float* amax =
         const float v[8] = {in[2 * s][0], in[2 * s][1], in[2 * s][2], in[2 * s][3],
                             in[2 * s + 1][0], in[2 * s + 1][1], in[2 * s + 1][2], in[2 * s + 1][3]};
         if (!BF && amax) {
+            // one v_max3_f32 with |.| source modifiers per pair.  Written as fmaxf(amax, fmaxf(|a|, |b|)) the compiler
+            // first canonicalises each MFMA result (v_max_f32 x, |a|, |a|): four instructions per pair instead of one
+            // (QB_AMAX_ASM=0 restores that form)
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) *amax = fmaxf(*amax, fmaxf(fabsf(v[j]), fabsf(v[j + 1])));  // v_max3_f32
+            for (int j = 0; j < 8; j += 2) {
+#if QB_AMAX_ASM
+                asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(*amax) : "v"(v[j]), "v"(v[j + 1]));
+#else
+                *amax = fmaxf(*amax, fmaxf(fabsf(v[j]), fabsf(v[j + 1])));
+#endif
+            }
         }
         split8<BF>(v, f.hi[s], f.lo[s]);
     }
