@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define QBOLD_MAX_T 64
-#define QBOLD_ABI_VERSION 3
+#define QBOLD_ABI_VERSION 4
 
 typedef enum {
     QBOLD_OK = 0,
@@ -86,6 +86,11 @@ typedef enum {
                            "bf16 forward / fp32 ELBO accum"); sampling and ELBO stay float32 */
 } qbold_encoder_precision;
 
+typedef enum {
+    QBOLD_ACT_RELU = 0, /* 'relu': both of the reference's configuration files */
+    QBOLD_ACT_GELU = 1  /* 'gelu' (Keras: exact, 0.5 x (1 + erf(x / sqrt 2))): the class default of EncoderTrainer */
+} qbold_activation;
+
 /* Voxel-wise encoder geometry (model.py:122-223; 3x3x1 convolutions act through their centre
  * tap on (N,1,1,1,T) voxel batches). */
 typedef struct {
@@ -98,6 +103,10 @@ typedef struct {
                                    9: full 3x3x1 kernels [3][3][U][U] in Keras order (model.py:152-157) */
     int32_t precision;          /* qbold_encoder_precision; the packed image (qbold_encoder_pack) and the
                                    kernels that read it must be given the same value */
+    int32_t activation;         /* qbold_activation: EncoderTrainer's activation_type (model.py:60, 115-120, 151, 155).
+                                   QBOLD_ACT_GELU runs FORWARD ONLY, on the layer-wise entry points
+                                   (qbold_encoder_train_fwd / _spatial_fwd); every other entry point that takes a shape
+                                   returns QBOLD_ERR_UNSUPPORTED for it (ABI v4) */
 } qbold_encoder_shape;
 
 /* Image-crop geometry of a [B][X][Y][Z][C] batch (train.py:17-72): voxel v = ((b X + x) Y + y) Z + z.

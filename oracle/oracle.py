@@ -158,6 +158,11 @@ class Oracle:
         """Process-global test hook: bf16-rounded operands in the voxel-wise encoder's products."""
         self.lib.qbo_set_encoder_bf16(int(bool(on)))
 
+    def set_activation(self, name):
+        """Process-global test hook: 'relu' (default) or 'gelu' in the encoder restatements."""
+        assert name in ("relu", "gelu")
+        self.lib.qbo_set_activation_gelu(int(name == "gelu"))
+
     def set_threads(self, n):
         self.lib.qbo_set_threads(int(n))
 

@@ -433,13 +433,26 @@ static inline real bf16_round(real v) {
     return (real)f;
 }
 
+/* activation_type of EncoderTrainer (model.py:60, 115-120, 151, 155): 'relu', or Keras' 'gelu' =
+ * tf.keras.activations.gelu(x, approximate=False) = 0.5 x (1 + erf(x / sqrt 2)).  Process-global test hook. */
+static int g_gelu = 0;
+void qbo_set_activation_gelu(int on) { g_gelu = on; }
+static real activate(real v) {
+    if (!g_gelu) return v > 0 ? v : 0;
+#ifdef QBO_DOUBLE
+    return R(0.5) * v * (R(1.0) + erf(v * R(0.70710678118654752440)));
+#else
+    return R(0.5) * v * (R(1.0) + erff(v * R(0.70710678118654752440)));
+#endif
+}
+
 static void dense(const real *x, const real *W, const real *b, real *y, int nin, int nout,
                   int relu) {
     for (int o = 0; o < nout; ++o) {
         real acc = 0;
         for (int i = 0; i < nin; ++i) acc += bf16_round(x[i]) * bf16_round(W[(int64_t)i * nout + o]);
         acc += b[o];
-        y[o] = relu ? (acc > 0 ? acc : 0) : acc;
+        y[o] = relu ? activate(acc) : acc;
     }
 }
 
@@ -461,7 +474,7 @@ void qbo_encoder_fwd(const qbo_weights *W, const qbo_loss_cfg *C, const real *x,
             dense(a, Wc, bc, tmp, U, U, 1); /* stream 1, model.py:145 */
             memcpy(a, tmp, sizeof(real) * U);
             dense(b, Wc, bc, skip, U, U, 1); /* shared conv as skip, model.py:148 */
-            for (int i = 0; i < U; ++i) tmp[i] = b[i] > 0 ? b[i] : 0; /* model.py:151 */
+            for (int i = 0; i < U; ++i) tmp[i] = activate(b[i]); /* model.py:151 */
             /* a (N,1,1,1,T) batch sees only the centre tap of a 'same'-padded 3x3x1 kernel */
             const int64_t ts = (int64_t)(W->taps == 9 ? 9 : 1) * U * U, tc = W->taps == 9 ? 4 * U * U : 0;
             dense(tmp, W->Wr1 + l * ts + tc, W->br1 + l * U, t1, U, U, 1); /* :152,155 */
@@ -516,7 +529,7 @@ static void conv3x3(const real *in, const real *K /*[3][3][U][U]*/, const real *
                         }
                     for (int c = 0; c < U; ++c) {
                         o[c] += b[c];
-                        if (relu_out && o[c] < 0) o[c] = 0;
+                        if (relu_out) o[c] = activate(o[c]);
                     }
                 }
 }
@@ -537,7 +550,7 @@ void qbo_encoder_fwd_spatial(const qbo_weights *W, const qbo_loss_cfg *C, const 
     for (int l = 0; l < L; ++l) {
         const real *Wc = W->Wc + (int64_t)l * U * U, *bc = W->bc + l * U;
         for (int64_t v = 0; v < V; ++v) dense(b + v * U, Wc, bc, skip + v * U, U, U, 1); /* :148 */
-        for (int64_t e = 0; e < V * U; ++e) r[e] = b[e] > 0 ? b[e] : 0;                  /* :151 */
+        for (int64_t e = 0; e < V * U; ++e) r[e] = activate(b[e]);                       /* :151 */
         conv3x3(r, W->Wr1 + (int64_t)l * 9 * U * U, W->br1 + l * U, t1, B, X, Y, Z, U, 1); /* :152,155 */
         conv3x3(t1, W->Wr2 + (int64_t)l * 9 * U * U, W->br2 + l * U, r, B, X, Y, Z, U, 0); /* :156 */
         for (int64_t v = 0; v < V; ++v) {

@@ -75,6 +75,8 @@ void qbo_set_node0_zero(int on);
 
 /* test hook: round both operands of every encoder dense product to bfloat16 (voxel-wise encoder). */
 void qbo_set_encoder_bf16(int on);
+/* test hook: 'gelu' (Keras exact form) instead of 'relu' in the encoder restatements (model.py:60, 115-120) */
+void qbo_set_activation_gelu(int on);
 
 /* tf.math.special.bessel_j0 for float32 = Eigen generic_j0<float> = Cephes j0f. */
 real qbo_j0(real x);

@@ -34,7 +34,7 @@ class LossCfg(C.Structure):
 class EncoderShape(C.Structure):
     _fields_ = [("T", C.c_int32), ("U", C.c_int32), ("L", C.c_int32),
                 ("channelwise_gating", C.c_int32), ("gate_offset", C.c_float),
-                ("spatial_taps", C.c_int32), ("precision", C.c_int32)]
+                ("spatial_taps", C.c_int32), ("precision", C.c_int32), ("activation", C.c_int32)]
 
 
 class Geometry(C.Structure):

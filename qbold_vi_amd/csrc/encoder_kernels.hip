@@ -351,6 +351,7 @@ extern "C" int qbold_encoder_fwd(const qbold_ctx* ctx, const qbold_encoder_shape
                                  const float* packed, const float* x, float* out1, float* out2,
                                  float* sigma, int64_t N, void* stream) {
     QB_NEED_DEVICE(ctx);
+    QB_RELU_ONLY(shape, "qbold_encoder_fwd");
     int rc = qb::check_encoder_shape(ctx, shape);
     if (rc) return rc;
     QB_REQUIRE(N >= 0, "qbold_encoder_fwd: negative N");
@@ -387,6 +388,7 @@ extern "C" int qbold_encoder_train_fwd_fused(const qbold_ctx* ctx, const qbold_e
                                              const float* packed, const float* x, int save_all, float* ws,
                                              float* out_q, float* out_log_sigma, int64_t N, void* stream) {
     QB_NEED_DEVICE(ctx);
+    QB_RELU_ONLY(shape, "qbold_encoder_train_fwd_fused");
     int rc = qb::check_encoder_shape(ctx, shape);
     if (rc) return rc;
     if (!shape->channelwise_gating || shape->precision != QBOLD_ENC_F32) {

@@ -44,6 +44,16 @@ int hip_fail(hipError_t e, const char* what);
         }                                                                     \
     } while (0)
 
+// entry points whose kernels implement relu only (gelu: the layer-wise forward, include/qbold_hip.h)
+#define QB_RELU_ONLY(shape, what)                                                                      \
+    do {                                                                                               \
+        if ((shape) && (shape)->activation != QBOLD_ACT_RELU) {                                        \
+            qb::set_error(what ": activation 'gelu' runs forward only, through qbold_encoder_train_fwd / " \
+                               "qbold_encoder_spatial_fwd");                                           \
+            return QBOLD_ERR_UNSUPPORTED;                                                              \
+        }                                                                                              \
+    } while (0)
+
 #define QB_REQUIRE(cond, msg)              \
     do {                                   \
         if (!(cond)) {                     \

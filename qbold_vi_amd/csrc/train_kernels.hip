@@ -30,7 +30,21 @@ constexpr int kWs = 65;        // LDS row stride of a staged weight matrix
 
 // bit 0: relu on the output; bit 1: relu on the INPUT rows as they are loaded (the reference's Activation
 // layer in front of a convolution, model.py:151 -- no materialised relu(b) tensor)
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU_IN = 2 };
+// bits 2 / 3: the same with Keras' 'gelu' (exact: 0.5 x (1 + erf(x / sqrt 2)); activation_type of the reference's
+// EncoderTrainer, model.py:60, 115-120) -- forward only, on the general kernels (xw_kernel, conv9_kernel)
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU_IN = 2, ACT_GELU = 4, ACT_GELU_IN = 8 };
+__device__ __forceinline__ float gelu_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// activation of an output value / of an input value as it is loaded
+__device__ __forceinline__ float act_out(float y, int act) {
+    if (act & ACT_RELU) return fmaxf(y, 0.0f);
+    if (act & ACT_GELU) return gelu_(y);
+    return y;
+}
+__device__ __forceinline__ float act_in(float a, int act) {
+    if (act & ACT_RELU_IN) return fmaxf(a, 0.0f);
+    if (act & ACT_GELU_IN) return gelu_(a);
+    return a;
+}
 
 // Row gather of one 3x3x1 tap on a [B][X][Y][Z] crop batch: row v reads its (dx, dy) neighbour, or
 // zeros outside the crop ('same' padding).  Z == 0 disables the gather.
@@ -134,9 +148,9 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
                 const int k0 = 16 * q + 4 * g;
                 float ac[4] = {rowok && k0 + 0 < kdim ? cur[q].x : 0.0f, rowok && k0 + 1 < kdim ? cur[q].y : 0.0f,
                                rowok && k0 + 2 < kdim ? cur[q].z : 0.0f, rowok && k0 + 3 < kdim ? cur[q].w : 0.0f};
-                if (act & ACT_RELU_IN) {
+                if (act & (ACT_RELU_IN | ACT_GELU_IN)) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) ac[c] = fmaxf(ac[c], 0.0f);
+                    for (int c = 0; c < 4; ++c) ac[c] = act_in(ac[c], act);
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -156,9 +170,9 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
                 if (va >= 0 && k0 < kdim) a = *reinterpret_cast<const float4*>(xr + k0);
                 float ac[4] = {k0 + 0 < kdim ? a.x : 0.0f, k0 + 1 < kdim ? a.y : 0.0f,
                                k0 + 2 < kdim ? a.z : 0.0f, k0 + 3 < kdim ? a.w : 0.0f};
-                if (act & ACT_RELU_IN) {
+                if (act & (ACT_RELU_IN | ACT_GELU_IN)) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) ac[c] = fmaxf(ac[c], 0.0f);
+                    for (int c = 0; c < 4; ++c) ac[c] = act_in(ac[c], act);
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -171,7 +185,7 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
             for (int s = 0; s < ksteps; ++s) {
                 const int k = 4 * s + g;
                 float a = (k < kdim && va >= 0) ? xr[k] : 0.0f;
-                if (act & ACT_RELU_IN) a = fmaxf(a, 0.0f);
+                a = act_in(a, act);
                 const float* wr = Wl + k * kWs + i;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(a, wr[16 * m], acc[m]);
@@ -196,9 +210,9 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
                             const float4 o = *yp;
                             y[0] += o.x; y[1] += o.y; y[2] += o.z; y[3] += o.w;
                         }
-                        if ((act & ACT_RELU)) {
+                        if (act & (ACT_RELU | ACT_GELU)) {
 #pragma unroll
-                            for (int m = 0; m < 4; ++m) y[m] = fmaxf(y[m], 0.0f);
+                            for (int m = 0; m < 4; ++m) y[m] = act_out(y[m], act);
                         }
                         if (mask) {
                             const float4 mk = *reinterpret_cast<const float4*>(mask + v * ldm + j);
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
                         for (int m = 0; m < 4 && j + m < ndim; ++m) {
                             float t = y[m];
                             if (accum) t += Y[v * ldy + j + m];
-                            if ((act & ACT_RELU)) t = fmaxf(t, 0.0f);
+                            t = act_out(t, act);
                             if (mask) t = mask[v * ldm + j + m] > 0.0f ? t : 0.0f;
                             Y[v * ldy + j + m] = t;
                         }
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
                     if (v >= N) continue;
                     float y = acc[m][r] + bj;
                     if (accum) y += Y[v * ldy + j];
-                    if ((act & ACT_RELU)) y = fmaxf(y, 0.0f);
+                    y = act_out(y, act);
                     if (mask) y = mask[v * ldm + j] > 0.0f ? y : 0.0f;
                     Y[v * ldy + j] = y;
                 }
@@ -738,9 +752,9 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
                 const int k0 = 16 * q + 4 * g;
                 float ac[4] = {k0 + 0 < U ? a.x : 0.0f, k0 + 1 < U ? a.y : 0.0f,
                                k0 + 2 < U ? a.z : 0.0f, k0 + 3 < U ? a.w : 0.0f};
-                if (act & ACT_RELU_IN) {
+                if (act & (ACT_RELU_IN | ACT_GELU_IN)) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) ac[c] = fmaxf(ac[c], 0.0f);
+                    for (int c = 0; c < 4; ++c) ac[c] = act_in(ac[c], act);
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -764,7 +778,7 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
                         y[m] = acc[m][r] + bj[m];
-                        if ((act & ACT_RELU)) y[m] = fmaxf(y[m], 0.0f);
+                        y[m] = act_out(y[m], act);
                     }
                     if (j + 3 < U) {
                         if (mask) {
@@ -790,7 +804,7 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
                     const int64_t v = v0 + 4 * g + r;
                     if (v >= N) continue;
                     float y = acc[m][r] + bj;
-                    if ((act & ACT_RELU)) y = fmaxf(y, 0.0f);
+                    y = act_out(y, act);
                     if (mask) y = mask[v * ldm + j] > 0.0f ? y : 0.0f;
                     Y[v * ldy + j] = y;
                 }
@@ -1828,7 +1842,8 @@ struct Launcher {
         const bool aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (ldx & 3) == 0 && ldx >= 64 &&
                              (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && (ldy & 3) == 0 && ldy >= 64 &&
                              (!mask || ((reinterpret_cast<uintptr_t>(mask) & 15) == 0 && (ld & 3) == 0 && ld >= 64));
-        if (aligned && kdim <= 64 && ndim <= 64 && gather.Z == 0 && !(ctx->kernel_sel & 512)) {
+        if (aligned && kdim <= 64 && ndim <= 64 && gather.Z == 0 && !(ctx->kernel_sel & 512) &&
+            !(act & (ACT_GELU | ACT_GELU_IN))) {   // gelu: the general kernel
             auto kern = accum ? (mask ? xw64_kernel<true, true> : xw64_kernel<true, false>)
                               : (mask ? xw64_kernel<false, true> : xw64_kernel<false, false>);
             hipLaunchKernelGGL(kern, dim3(grid()), dim3(256), smem, s, X, ldx, kdim, W, ldw, trans, b, Y, ldy, ndim,
@@ -1851,7 +1866,7 @@ struct Launcher {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             const bool aligned = ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) |
                                    reinterpret_cast<uintptr_t>(mask)) & 15) == 0;
-            if (aligned && !(ctx->kernel_sel & 65536)) {   // split-f16 matrix pipe (bit 65536: the exact-f32 form)
+            if (aligned && !(ctx->kernel_sel & 65536) && !(act & (ACT_GELU | ACT_GELU_IN))) {   // split-f16 matrix pipe (bit 65536 / gelu: the exact-f32 form)
                 const size_t smh = sizeof(float) * (9 * 4096 + 64);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9h_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smh);
@@ -1869,7 +1884,7 @@ struct Launcher {
             const int dx = tap / 3 - 1, dy = tap % 3 - 1;
             gather = make_gather(gm.X, gm.Y, gm.Z, flip ? -dx : dx, flip ? -dy : dy);
             (void)xw_ld(X, ld, U, K9 + (int64_t)tap * U * U, U, flip, tap == 0 ? b : nullptr, Y, ld, U,
-                        (tap == 8 ? (act & ACT_RELU) : ACT_NONE) | (act & ACT_RELU_IN), tap != 0,
+                        (tap == 8 ? (act & (ACT_RELU | ACT_GELU)) : ACT_NONE) | (act & (ACT_RELU_IN | ACT_GELU_IN)), tap != 0,
                         tap == 8 ? mask : nullptr);
         }
         gather = make_gather(0, 0, 0, 0, 0);
@@ -1938,6 +1953,10 @@ int check_layerwise_shape(const qbold_ctx* ctx, const qbold_encoder_shape* s) {
         qb::set_error("layer-wise encoder path: need 1 <= U <= 256, 1 <= L <= 8");
         return QBOLD_ERR_UNSUPPORTED;
     }
+    if (s->activation != QBOLD_ACT_RELU && s->activation != QBOLD_ACT_GELU) {
+        qb::set_error("encoder shape: activation must be QBOLD_ACT_RELU or QBOLD_ACT_GELU");
+        return QBOLD_ERR_INVALID;
+    }
     return QBOLD_OK;
 }
 
@@ -1976,13 +1995,16 @@ static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     auto slot = [&](int i) { return ws + (int64_t)i * N * ld; };
     // slot 0 holds the normalised input with its own row stride (T may exceed ld only if T > 64: not allowed)
     hipLaunchKernelGGL(normalise64_kernel, dim3(k.ew()), dim3(256), 0, k.s, ctx->dev, x, slot(0), ld, N);
-    k.xw(slot(0), ld, T, w + c.W0, U, 0, w + c.b0, slot(1), U, ACT_RELU, 0, nullptr);
+    // activation_type (model.py:60, 115-120): relu, or Keras' exact gelu on the general kernels (forward only)
+    const bool gelu = shape->activation == QBOLD_ACT_GELU;
+    const int A_OUT = gelu ? ACT_GELU : ACT_RELU, A_IN = gelu ? ACT_GELU_IN : ACT_RELU_IN;
+    k.xw(slot(0), ld, T, w + c.W0, U, 0, w + c.b0, slot(1), U, A_OUT, 0, nullptr);
     const float* cur = slot(1);
     float* head = slot(2 + 5 * L);  // scratch slot for the head output
     if (stream_sel == 1) {
         for (int l = 0; l < L; ++l) {
             const float* wb = w + c.blk0 + l * c.blk_stride;
-            k.xw(cur, ld, U, wb + c.Wc, U, 0, wb + c.bc, slot(2 + l), U, ACT_RELU, 0, nullptr);
+            k.xw(cur, ld, U, wb + c.Wc, U, 0, wb + c.bc, slot(2 + l), U, A_OUT, 0, nullptr);
             cur = slot(2 + l);
         }
     } else {
@@ -1990,11 +2012,11 @@ static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             const float* wb = w + c.blk0 + l * c.blk_stride;
             float* skip = slot(2 + 5 * l), *t = slot(3 + 5 * l), *r = slot(4 + 5 * l);
             float* gl = slot(5 + 5 * l), *bout = slot(6 + 5 * l);
-            const bool fork = !gm && U <= 64 && ld == kLd && !(ctx->kernel_sel & 8192);
-            if (!fork) k.xw(cur, ld, U, wb + c.Wc, U, 0, wb + c.bc, skip, U, ACT_RELU, 0, nullptr);
+            const bool fork = !gm && U <= 64 && ld == kLd && !(ctx->kernel_sel & 8192) && !gelu;
+            if (!fork) k.xw(cur, ld, U, wb + c.Wc, U, 0, wb + c.bc, skip, U, A_OUT, 0, nullptr);
             // relu(b) feeds the first residual conv (model.py:151): applied to the rows as they are loaded
             if (gm) {  // 3x3x1 'same' convolutions, model.py:152-157
-                k.conv3x3(cur, wb + c.Wr1, U, wb + c.br1, t, ACT_RELU | ACT_RELU_IN, 0, nullptr, *gm);
+                k.conv3x3(cur, wb + c.Wr1, U, wb + c.br1, t, A_OUT | A_IN, 0, nullptr, *gm);
                 k.conv3x3(t, wb + c.Wr2, U, wb + c.br2, r, ACT_NONE, 0, nullptr, *gm);
             } else {   // voxel batch: centre tap only
                 const int ctr = c.taps == 9 ? 4 * U * U : 0;
@@ -2002,7 +2024,7 @@ static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                     hipLaunchKernelGGL(xw64_fork_kernel, dim3(k.grid()), dim3(256), sizeof(float) * 2 * 64 * kWs, k.s,
                                        cur, ld, U, U, wb + c.Wc, wb + c.bc, skip, wb + c.Wr1 + ctr, wb + c.br1, t, U, N);
                 else
-                    k.xw(cur, ld, U, wb + c.Wr1 + ctr, U, 0, wb + c.br1, t, U, ACT_RELU | ACT_RELU_IN, 0, nullptr);
+                    k.xw(cur, ld, U, wb + c.Wr1 + ctr, U, 0, wb + c.br1, t, U, A_OUT | A_IN, 0, nullptr);
                 k.xw(t, ld, U, wb + c.Wr2 + ctr, U, 0, wb + c.br2, r, U, ACT_NONE, 0, nullptr);
             }
             const bool fuse_gate = G == U && U <= 64 && ld == kLd && !(ctx->kernel_sel & 2048) &&
@@ -2055,7 +2077,7 @@ extern "C" int qbold_encoder_spatial_fwd(const qbold_ctx* ctx, const qbold_encod
 // the condition under which a stream-2 voxel-batch backward runs block_bwd_kernel (one definition: the forward
 // leaves out what that kernel recomputes only if this says so)
 static bool block_bwd_applies(const qbold_ctx* ctx, const qbold_encoder_shape* s, int64_t N) {
-    return ctx && s && s->U >= 1 && s->U <= 64 && s->channelwise_gating && s->L >= 1 && s->L <= 2 && s->T <= 27 &&
+    return ctx && s && s->activation == QBOLD_ACT_RELU && s->U >= 1 && s->U <= 64 && s->channelwise_gating && s->L >= 1 && s->L <= 2 && s->T <= 27 &&
            s->T == ctx->dev.T && s->precision == QBOLD_ENC_F32 && N > 0 && N < ((int64_t)1 << 23) &&
            !(ctx->kernel_sel & 131072);
 }
@@ -2079,6 +2101,7 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                           const double* sums, float* grad, int64_t N, void* stream,
                           const qbold_geometry* gm) {
     QB_NEED_DEVICE(ctx);
+    QB_RELU_ONLY(shape, "qbold_encoder_train_bwd");
     int rc = check_layerwise_shape(ctx, shape);
     if (rc) return rc;
     if (gm && shape->U > 64) {

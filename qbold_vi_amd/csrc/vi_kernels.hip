@@ -187,6 +187,7 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
                             float* q_out, float* nll_kl, double* sums, void* workspace, int64_t N,
                             void* stream) {
     QB_NEED_DEVICE(ctx);
+    QB_RELU_ONLY(shape, "qbold_vi_fwd");
     if (wide_vi_path(ctx, shape)) {
         QB_REQUIRE(N >= 0 && S >= 1 && K >= 0, "qbold_vi_fwd: need N >= 0, S >= 1, K >= 0");
         QB_REQUIRE(sums && workspace, "qbold_vi_fwd: null sums/workspace");

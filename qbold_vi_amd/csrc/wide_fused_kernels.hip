@@ -961,6 +961,7 @@ extern "C" int qbold_encoder_fused_pack(const qbold_ctx* ctx, const qbold_encode
 extern "C" int qbold_encoder_fused_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* packed,
                                        const float* x, float* out_q, float* out_log_sigma, int64_t N, void* stream) {
     QB_NEED_DEVICE(ctx);
+    QB_RELU_ONLY(shape, "qbold_encoder_fused_fwd");
     if (!fused_supported(shape)) {
         qb::set_error("qbold_encoder_fused_fwd: shape outside the one-launch wide encoder (see qbold_encoder_fused_pack)");
         return QBOLD_ERR_UNSUPPORTED;

@@ -464,6 +464,7 @@ extern "C" int qbold_encoder_wide_fwd(const qbold_ctx* ctx, const qbold_encoder_
                                       float* workspace, float* out_q, float* out_log_sigma, int64_t N,
                                       void* stream) {
     QB_NEED_DEVICE(ctx);
+    QB_RELU_ONLY(shape, "qbold_encoder_wide_fwd");
     int rc = check_wide(ctx, shape, "qbold_encoder_wide_fwd");
     if (rc) return rc;
     QB_REQUIRE(N >= 0, "qbold_encoder_wide_fwd: negative N");

@@ -279,8 +279,8 @@ class EncoderTrainer:
         unsupported = []
         if use_layer_norm or dropout_rate > 0.0:
             unsupported.append("use_layer_norm / dropout_rate (model.py:133-140)")
-        if activation_type != 'relu':
-            unsupported.append(f"activation_type={activation_type!r} (kernels implement 'relu')")
+        if activation_type not in ('relu', 'gelu'):
+            unsupported.append(f"activation_type={activation_type!r} (kernels implement 'relu' and, forward only, 'gelu')")
         if infer_inv_gamma and use_mvg:
             # the reference itself cannot run this pair: synthetic_data_loss splits the 9-channel first output
             # (5 + 4) in two (tf.split(y_pred_orig, 2, axis=-1), model.py:455)
@@ -338,7 +338,8 @@ class EncoderTrainer:
             w["Wf"][:, 4] = 0.0
             w["bf"][4] = 0.0
         ew = EncoderWeights(self._ctx, no_ip_images, self._no_units, self._no_intermediate_layers,
-                            self._channelwise_gating, gate_offset, spatial_taps=9).set_from_arrays(w)
+                            self._channelwise_gating, gate_offset, spatial_taps=9,
+                            activation=self._activation_type).set_from_arrays(w)
         return EncoderModel(self, ew), _InnerModel()
 
     def build_fine_tuner(self, encoder_model, signal_generation_layer, input_im=None, input_mask=None):

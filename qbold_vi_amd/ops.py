@@ -55,13 +55,16 @@ class EncoderWeights:
     NAMES = ("W0", "b0", "Wc", "bc", "Wr1", "br1", "Wr2", "br2", "Wg", "bg", "Wf", "bf", "Ws", "bs")
 
     PRECISIONS = {"f32": 0, "bf16": 1}   # qbold_encoder_precision
+    ACTIVATIONS = {"relu": 0, "gelu": 1}  # qbold_activation
 
     def __init__(self, ctx, T, U, L, channelwise_gating=True, gate_offset=0.0, spatial_taps=1,
-                 precision="f32"):
+                 precision="f32", activation="relu"):
         self.ctx = ctx
+        if activation not in self.ACTIVATIONS:
+            raise ValueError(f"activation {activation!r}: the kernels implement 'relu' and (forward only) 'gelu'")
         self.shape = EncoderShape(int(T), int(U), int(L), int(bool(channelwise_gating)),
                                   float(gate_offset), 9 if spatial_taps == 9 else 1,
-                                  self.PRECISIONS[precision])
+                                  self.PRECISIONS[precision], self.ACTIVATIONS[activation])
         if precision != "f32" and not Context.fits_fused(self.shape):
             raise ValueError("precision='bf16' exists for the fused voxel kernels (U <= 64, L <= 2, T in {11, 24})")
         lib = _lib.load()
@@ -72,7 +75,8 @@ class EncoderWeights:
         self._dirty = {"packed", "wide", "fused"}   # device images to rebuild from the canonical blob
         # weight-streaming image for widths beyond the LDS-resident kernels (U = 128 / 256)
         n_wide = int(lib.qbold_encoder_wide_packed_floats(C.byref(self.shape)))
-        self.wide = n_wide > 0 and not Context.fits_fused(self.shape)
+        # gelu runs on the general layer-wise kernels only (include/qbold_hip.h, qbold_activation)
+        self.wide = n_wide > 0 and not Context.fits_fused(self.shape) and self.shape.activation == 0
         self.wide_packed = (torch.zeros(n_wide, dtype=torch.float32, device=ctx.device)
                             if self.wide else None)
         self._wide_ws = None
@@ -294,7 +298,7 @@ class Context:
     def fits_fused(shape):
         """The LDS-resident fused kernels cover U <= 64, L <= 2, T in {11, 24}; anything else (e.g.
         BASELINE config 3: U = 256, T = 64) takes the layer-wise GEMM path."""
-        return shape.U <= 64 and shape.L <= 2 and shape.T in (11, 24)
+        return shape.U <= 64 and shape.L <= 2 and shape.T in (11, 24) and shape.activation == 0   # gelu: layer-wise
 
     def encoder_fwd(self, weights, x, want=("out1", "out2", "sigma")):
         x = _f32(x, "x", self.T)
@@ -725,6 +729,9 @@ class TrainState:
     def backward(self, stream_sel, g_q, g_ls=None, sums=None):
         """Fills self.grad (canonical layout) from the head gradients of the last forward()."""
         ctx = self.ctx
+        if self.weights.shape.activation != 0:
+            raise NotImplementedError("activation_type='gelu' runs forward only (prediction, ELBO evaluation): its "
+                                      "backward needs the pre-activations, which the training kernels do not keep")
         _lib.check(ctx.lib.qbold_encoder_train_bwd(ctx.handle, C.byref(self.weights.shape),
                                                    _ptr(self.weights.flat), int(stream_sel),
                                                    _ptr(self._ws), _ptr(g_q), _ptr(g_ls), _ptr(sums),

@@ -303,3 +303,31 @@ def test_homoscedastic_fine_tuner(params):
     sg = torch.full((n, 11), s0, device="cuda")
     sums, _ = tr.context.elbo_fwd(dev(data), None, q.reshape(n, 5).contiguous(), prior, sg, 64, 8, seed=3)
     assert torch.equal(e["sums"], sums)
+
+
+def test_gelu_encoder(params):
+    """activation_type='gelu' (model.py:60, 115-120, 151, 155): forward on voxel batches and crops; training raises."""
+    tr, model = encoder_of(params, "encoder_gelu", activation_type="gelu")
+    x, o1, o2, sg = g("encoder_gelu/voxels", "x", "out1", "out2", "sigma")
+    g1, g2, gs = model(dev(x.reshape(-1, 1, 1, 1, 11)))
+    close(g1.reshape(o1.shape), o1, rtol=2e-5, atol=2e-5)
+    close(g2.reshape(o2.shape), o2, rtol=2e-5, atol=2e-5)
+    close(gs.reshape(sg.shape), sg, rtol=5e-5)
+    xc, c1, c2, cs = g("encoder_gelu/crops", "x", "out1", "out2", "sigma")
+    s1, s2, ssg = model(dev(xc))
+    close(s1, c1, rtol=2e-5, atol=2e-5)
+    close(s2, c2, rtol=2e-5, atol=2e-5)
+    close(ssg, cs, rtol=5e-5)
+    # the ELBO evaluation composes the same forward with the sampling kernel
+    from qbold_vi_amd.signals import SignalGenerationLayer
+    full = tr.build_fine_tuner(model, SignalGenerationLayer(dict(params, simulate_noise="False"), True, True))
+    n = len(x)
+    e = full.elbo(dev(x), None, g1.reshape(n, 5), kl_samples=16, seed=2)
+    sums, _ = tr.context.elbo_fwd(dev(x), None, g2.reshape(n, 5).contiguous(), g1.reshape(n, 5).contiguous(),
+                                  gs.reshape(n, 11).contiguous(), 1, 16, seed=2)
+    assert torch.equal(e["sums"], sums)
+    from qbold_vi_amd.ops import TrainState
+    st = TrainState(tr.context, model.weights)
+    q, ls = st.forward(dev(x), 2)
+    with pytest.raises(NotImplementedError, match="forward only"):
+        st.backward(2, torch.zeros_like(q), torch.zeros_like(ls))

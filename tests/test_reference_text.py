@@ -283,3 +283,25 @@ def test_homoscedastic_fine_tuner(params, oracle32):
     close(pred, imgs[:, :11], rtol=3e-5)
     nll = oracle32.nll(data, np.ones(64, np.float32), pred, np.full_like(pred, s0))
     close(nll.astype(np.float64).mean(), g("fine_tuner_homoscedastic", "nll"), rtol=2e-5)
+
+
+def test_gelu_encoder(oracle32):
+    """activation_type='gelu' (the class default of EncoderTrainer, model.py:60; Keras' exact erf form) everywhere the
+    reference applies its activation: the 1x1x1 layers (:119-120) and the two Activation layers of a block (:151, :155)
+    -- where the second stream's input is activated AGAIN (gelu is not idempotent as relu is)."""
+    w = weights_of("encoder_gelu")
+    oracle32.set_activation("gelu")
+    try:
+        x, o1, o2, sg = g("encoder_gelu/voxels", "x", "out1", "out2", "sigma")
+        g1, g2, gs = oracle32.encoder_fwd(centre_taps(w), x)
+        close(g1, o1, rtol=2e-5, atol=2e-5)
+        close(g2, o2, rtol=2e-5, atol=2e-5)
+        close(gs, sg, rtol=5e-5)
+        xc, c2, cs = g("encoder_gelu/crops", "x", "out2", "sigma")
+        s2, ssg = oracle32.encoder_fwd_spatial(w, xc)
+        close(s2, c2, rtol=2e-5, atol=2e-5)
+        close(ssg, cs, rtol=5e-5)
+    finally:
+        oracle32.set_activation("relu")
+    r1, _, _ = oracle32.encoder_fwd(centre_taps(w), x)
+    assert np.abs(r1 - o1).max() > 1e-3          # relu on the same weights is a different network
