@@ -95,6 +95,20 @@ def test_committed_bench_line_keeps_the_contract():
     assert d3["roofline"]["kernel_ms"] < d3["roofline"]["step"]["kernel_ms"]
 
 
+def test_committed_round3_line_carries_the_variants():
+    """profiles/r03_bench.json: the default N = 1 run of this round -- headline keys as the contract has them, plus one
+    timed entry per configuration the summaries quote."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    check_line(d, expect_cpu_baseline=True)
+    assert "variants" in d and d["n_gpus"] == 1 and d["config"]["global_voxels"] == 1 << 20 and d["dtype"] == "f32"
+    assert d["roofline"]["kernel"] == "vi_fwd_kernel" and d["roofline"]["bound"] == "valu-issue"
+    assert d["value"] > 2.0e9                                   # round 2's driver-witnessed headline: 2.04e9
+    assert 0.015 < d["roofline"]["hbm"]["frac"] < 0.05          # the metric's HBM roofline: ~2 - 3 % by arithmetic
+    d3 = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_config3.json")))
+    check_line(d3, expect_cpu_baseline=False)
+    assert d3["roofline"]["bound"] == "mfma" and d3["ms_per_step"] < 4.0
+
+
 def test_bench_refuses_to_run_without_a_gpu():
     torch = pytest.importorskip("torch")
     if torch.cuda.device_count() > 0:
