@@ -104,9 +104,9 @@ typedef struct {
     int32_t precision;          /* qbold_encoder_precision; the packed image (qbold_encoder_pack) and the
                                    kernels that read it must be given the same value */
     int32_t activation;         /* qbold_activation: EncoderTrainer's activation_type (model.py:60, 115-120, 151, 155).
-                                   QBOLD_ACT_GELU runs FORWARD ONLY, on the layer-wise entry points
-                                   (qbold_encoder_train_fwd / _spatial_fwd); every other entry point that takes a shape
-                                   returns QBOLD_ERR_UNSUPPORTED for it (ABI v4) */
+                                   QBOLD_ACT_GELU runs on the layer-wise entry points (qbold_encoder_train_fwd / _bwd,
+                                   qbold_encoder_spatial_fwd / _bwd: general kernels, pre-activations recomputed in the
+                                   backward); the fused / wide entry points return QBOLD_ERR_UNSUPPORTED for it (ABI v4) */
 } qbold_encoder_shape;
 
 /* Image-crop geometry of a [B][X][Y][Z][C] batch (train.py:17-72): voxel v = ((b X + x) Y + y) Z + z.

@@ -13,6 +13,9 @@
 // Same lane mapping and Philox stream as the forward kernels, so loss values are identical.
 #include "elbo_core.h"
 #include "qbold_ctx.h"
+#ifndef QB_BWD_WHITENED
+#define QB_BWD_WHITENED 1
+#endif
 
 namespace qb {
 bool elbo_fast_path(const qbold_ctx* ctx);
@@ -177,6 +180,54 @@ __global__ __launch_bounds__(kBlock) void elbo_bwd_kernel(
 
             // ---- KL draws ------------------------------------------------------------------
             float k_mu_o = 0.0f, k_so = 0.0f, k_mu_d = 0.0f, k_sd = 0.0f, k_c = 0.0f;
+            // Whitened form (elbo_core.h, kl_draws_fast): under q the whitened residual of a draw is z itself, under
+            // the prior it is w = d + M z with d, M fixed per voxel.  Both the value, sum |w|^2 - |z|^2, and the
+            // gradient through the sample (q stop-gradient inside log q, model.py:596) --
+            //   g_l = L_p^-T w - L_q^-T z,  d/d mu += g_l,  d/d s_o += g_a z0 e^so,  d/d c += g_b z0,  d/d s_d += g_b z1 e^sd
+            // -- are then linear / quadratic in (1, z0, z1): the loop only gathers the draws' five second moments (five
+            // instructions per draw besides Philox, instead of thirty-five) and the sums are assembled once per voxel.
+            // Valid while the logit clip cannot bind (the same per-wave bound as the forward kernels).
+            constexpr float kZMax = 6.7636f;
+            const float reach = fmaxf(fabsf(qm.mu_o) + kZMax * qm.e_so, fabsf(qm.mu_d) + kZMax * (fabsf(qm.c) + qm.e_sd));
+            if (QB_BWD_WHITENED && __all(reach < QB_LOGIT_CLIP)) {
+                float s0 = 0.0f, s1 = 0.0f, s00 = 0.0f, s11 = 0.0f, s01 = 0.0f;
+                for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
+                    float z[4];
+                    const bool two = 2 * j + 1 < K;
+                    qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_KL, z);
+                    n_kl += two ? 2 : 1;
+                    if (!two) z[2] = z[3] = 0.0f;     // an untaken draw adds nothing to any moment
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const float z0 = z[2 * d], z1 = z[2 * d + 1];
+                        s0 += z0;
+                        s1 += z1;
+                        s00 = fmaf(z0, z0, s00);
+                        s11 = fmaf(z1, z1, s11);
+                        s01 = fmaf(z0, z1, s01);
+                    }
+                }
+                const float nk = (float)n_kl;
+                const float dmu_o = qm.mu_o - pm.mu_o, dmu_d = qm.mu_d - pm.mu_d;
+                const float d0 = dmu_o * pm.i_so, m00 = qm.e_so * pm.i_so;
+                const float d1 = fmaf(dmu_d, pm.i_sd, dmu_o * pm.i_bl);
+                const float m10 = fmaf(qm.c, pm.i_sd, qm.e_so * pm.i_bl), m11 = qm.e_sd * pm.i_sd;
+                // sum |w|^2 with w0 = d0 + m00 z0, w1 = d1 + m10 z0 + m11 z1
+                const float sw0 = nk * d0 * d0 + 2.0f * d0 * m00 * s0 + m00 * m00 * s00;
+                const float sw1 = nk * d1 * d1 + 2.0f * d1 * (m10 * s0 + m11 * s1) + m10 * m10 * s00 +
+                                  2.0f * m10 * m11 * s01 + m11 * m11 * s11;
+                kl_sum = (sw0 + sw1) - (s00 + s11);
+                // g_a = A0 + A1 z0 + A2 z1,  g_b = B0 + B1 z0 + B2 z1
+                const float A0 = d0 * pm.i_so + d1 * pm.i_bl;
+                const float A1 = m00 * pm.i_so + m10 * pm.i_bl - qm.i_so;
+                const float A2 = m11 * pm.i_bl - qm.i_bl;
+                const float B0 = d1 * pm.i_sd, B1 = m10 * pm.i_sd, B2 = m11 * pm.i_sd - qm.i_sd;
+                k_mu_o = A0 * nk + A1 * s0 + A2 * s1;
+                k_so = (A0 * s0 + A1 * s00 + A2 * s01) * qm.e_so;
+                k_mu_d = B0 * nk + B1 * s0 + B2 * s1;
+                k_c = B0 * s0 + B1 * s00 + B2 * s01;
+                k_sd = (B0 * s1 + B1 * s01 + B2 * s11) * qm.e_sd;
+            } else
             for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
                 float z[4];
                 const bool two = 2 * j + 1 < K;

@@ -48,8 +48,8 @@ int hip_fail(hipError_t e, const char* what);
 #define QB_RELU_ONLY(shape, what)                                                                      \
     do {                                                                                               \
         if ((shape) && (shape)->activation != QBOLD_ACT_RELU) {                                        \
-            qb::set_error(what ": activation 'gelu' runs forward only, through qbold_encoder_train_fwd / " \
-                               "qbold_encoder_spatial_fwd");                                           \
+            qb::set_error(what ": activation 'gelu' runs through the layer-wise entry points "        \
+                               "(qbold_encoder_train_fwd / _bwd, qbold_encoder_spatial_fwd / _bwd)");   \
             return QBOLD_ERR_UNSUPPORTED;                                                              \
         }                                                                                              \
     } while (0)

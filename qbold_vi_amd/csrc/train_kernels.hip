@@ -1288,11 +1288,13 @@ __global__ void gate_fwd_kernel(float* __restrict__ gl, const float* __restrict_
         bout[e] = o;
     }
 }
-// gate backward: d_b in/out -> d_skip_pre (masked by skip > 0), d_r, d_gl (channelwise or summed)
+// gate backward: d_b in/out -> d_skip_pre (masked by skip > 0; relu_mask = 0: d skip itself, the gelu path applies
+// its own derivative), d_r, d_gl (channelwise or summed)
 __global__ void gate_bwd_kernel(const float* __restrict__ d_b, const float* __restrict__ gl,
                                 const float* __restrict__ skip, const float* __restrict__ r,
                                 float* __restrict__ d_skip_pre, float* __restrict__ d_r,
-                                float* __restrict__ d_gl, float offset, int U, int G, int ld, int64_t N) {
+                                float* __restrict__ d_gl, float offset, int U, int G, int ld, int64_t N,
+                                int relu_mask = 1) {
     for (int64_t v = blockIdx.x * (int64_t)(blockDim.x / 64) + (threadIdx.x >> 6); v < N;
          v += (int64_t)gridDim.x * (blockDim.x / 64)) {
         float shared_sum = 0.0f;
@@ -1302,7 +1304,7 @@ __global__ void gate_bwd_kernel(const float* __restrict__ d_b, const float* __re
             if (j < U) {
                 const float gate = 1.0f / (1.0f + expf(-(gl[v * ld + (G == 1 ? 0 : j)] + offset)));
                 const float db = d_b[e];
-                ds = skip[e] > 0.0f ? db * (1.0f - gate) : 0.0f;
+                ds = (!relu_mask || skip[e] > 0.0f) ? db * (1.0f - gate) : 0.0f;
                 dr = db * gate;
                 dgl = db * (r[e] - skip[e]) * gate * (1.0f - gate);
             }
@@ -1702,6 +1704,21 @@ __global__ void mask_mul_kernel(const float* __restrict__ in, const float* __res
 // Optional inverse-gamma prior on the two marginal variances (model.py:492-507, use_mvg branch):
 // loss -= log IG(exp(s_o)^2; a, b) + log IG(exp(s_d)^2 + q[4]^2; a, b) -- the RAW fifth parameter, as
 // the reference writes it (:499).  ig_a = 0 switches it off; ig_c0 = lgamma(a) - a log b.
+// out = gelu(in);  out = d * gelu'(z), gelu'(z) = Phi(z) + z phi(z)  -- the gelu backward works on pre-activations it
+// recomputes (train_bwd_gelu below)
+__global__ void gelu_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        out[e] = gelu_(in[e]);
+}
+__global__ void gelu_bwd_mul_kernel(const float* __restrict__ d, const float* __restrict__ z,
+                                    float* __restrict__ out, int64_t n) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float v = z[e];
+        const float dg = 0.5f * (1.0f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
+        out[e] = d[e] * dg;
+    }
+}
+
 __global__ void nlogp_bwd_kernel(const float* __restrict__ y_true, int ldy, const float* __restrict__ q,
                                  float* __restrict__ g_q, int ldg, float* __restrict__ loss, float scale,
                                  float ig_a, float ig_b, float ig_c0, int64_t N) {
@@ -2094,6 +2111,105 @@ extern "C" int qbold_encoder_train_bwd_recomputes(const qbold_ctx* ctx, const qb
     return block_bwd_dw_applies(ctx, shape, N) ? 2 : (block_bwd_applies(ctx, shape, N) ? 1 : 0);
 }
 
+// The backward of the layer-wise forward with activation_type = 'gelu' (model.py:60, 115-120, 151, 155).  gelu is not
+// invertible, so its derivative needs the PRE-activation, which the forward (shared with relu: post-activation tensors
+// in the workspace slots) does not keep: each pre-activation is recomputed by the GEMM / convolution that produced
+// it, without bias-free shortcuts, right where its derivative is needed, and the delta is multiplied by gelu'(z).  All
+// on the general kernels (xw_kernel, conv9_kernel, xtd_kernel, xtd9_kernel); scratch: the head-delta slot once the
+// heads are done, and the block's `skip` slot once gate_bwd_kernel has read it.
+static int train_bwd_gelu(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* w, int stream_sel,
+                          float* ws, const float* g_q, const float* g_ls, const double* sums, float* grad, int64_t N,
+                          void* stream, const qbold_geometry* gm) {
+    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating, shape->spatial_taps);
+    const int T = c.T, U = c.U, L = c.L, G = c.G;
+    const int ld = train_ld(shape->U);
+    Launcher k{ctx, (hipStream_t)stream, N, ld};
+    auto slot = [&](int i) { return ws + (int64_t)i * N * ld; };
+    const int base = 2 + 5 * L;
+    float* dA = slot(base), *dB = slot(base + 1), *dC = slot(base + 2), *dD = slot(base + 3), *dE = slot(base + 4);
+    float* partial = ws + (int64_t)(base + 5) * N * ld;
+    QB_HIP(hipMemsetAsync(grad, 0, sizeof(float) * c.total, k.s));
+    hipLaunchKernelGGL(head_delta_kernel, dim3(k.ew()), dim3(256), 0, k.s, g_q, stream_sel == 2 ? g_ls : nullptr, T,
+                       sums, dA, ld, N);
+    const float* last = stream_sel == 1 ? slot(2 + L - 1) : slot(6 + 5 * (L - 1));
+    int64_t nb = N / (16 * 16 * 4);
+    const int64_t cap = ctx->num_cus < kSlabBlocks ? ctx->num_cus : kSlabBlocks;
+    const int slabs = (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
+    const int slabs9 = (int)((N + 511) / 512 < ctx->num_cus ? ((N + 511) / 512 > 0 ? (N + 511) / 512 : 1)
+                                                           : (ctx->num_cus < kSlabBlocks ? ctx->num_cus : kSlabBlocks));
+    const int64_t ne = N * (int64_t)ld;
+    auto gelu_of = [&](const float* in, float* out) {
+        hipLaunchKernelGGL(gelu_kernel, dim3(k.ew()), dim3(256), 0, k.s, in, out, ne);
+    };
+    auto times_dgelu = [&](float* d, const float* z) {   // d *= gelu'(z)
+        hipLaunchKernelGGL(gelu_bwd_mul_kernel, dim3(k.ew()), dim3(256), 0, k.s, d, z, d, ne);
+    };
+    // heads: dWf, dbf (and dWs, dbs); dB = g_q Wf^T (+ g_ls Ws^T)
+    k.xtd(last, U, dA, 5, partial, slabs, grad + c.Wf, 5, grad + c.bf, 0);
+    k.xw(dA, ld, 5, w + c.Wf, 5, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
+    if (stream_sel == 2 && g_ls) {
+        k.xtd(last, U, dA + 5, T, partial, slabs, grad + c.Ws, T, grad + c.bs, 0);
+        k.xw(dA + 5, ld, T, w + c.Ws, T, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
+    }
+    float* Z = dA;   // the head delta has been consumed: scratch for recomputed pre-activations
+    if (stream_sel == 1) {
+        for (int l = L - 1; l >= 0; --l) {
+            const float* wb = w + c.blk0 + l * c.blk_stride;
+            float* gb = grad + c.blk0 + l * c.blk_stride;
+            const float* a_in = l == 0 ? slot(1) : slot(2 + l - 1);
+            k.xw(a_in, ld, U, wb + c.Wc, U, 0, wb + c.bc, Z, U, ACT_NONE, 0, nullptr);   // z_l, model.py:145
+            times_dgelu(dB, Z);
+            k.xtd(a_in, U, dB, U, partial, slabs, gb + c.Wc, U, gb + c.bc, 0);
+            k.xw(dB, ld, U, wb + c.Wc, U, 1, nullptr, dC, U, ACT_NONE, 0, nullptr);
+            float* tmp = dB; dB = dC; dC = tmp;
+        }
+    } else {
+        for (int l = L - 1; l >= 0; --l) {
+            const float* wb = w + c.blk0 + l * c.blk_stride;
+            float* gb = grad + c.blk0 + l * c.blk_stride;
+            float* skip = slot(2 + 5 * l);
+            const float* t = slot(3 + 5 * l), *r = slot(4 + 5 * l), *gl = slot(5 + 5 * l);
+            const float* b_in = l == 0 ? slot(1) : slot(6 + 5 * (l - 1));
+            const int ctr = (!gm && c.taps == 9) ? 4 * U * U : 0;
+            // dB = d b_out  ->  dC = d skip (post-activation), dD = d r, dE = d gate logits
+            hipLaunchKernelGGL(gate_bwd_kernel, dim3(k.grid()), dim3(256), 0, k.s, dB, gl, skip, r, dC, dD, dE,
+                               shape->gate_offset, U, G, ld, N, 0);
+            k.xtd(r, U, dE, G, partial, slabs, gb + c.Wg, G, gb + c.bg, 0);
+            k.xw(dE, ld, G, wb + c.Wg, G, 1, nullptr, dD, U, ACT_NONE, 1, nullptr);       // d r += d gl Wg^T
+            float* Gb = skip;                                                             // gelu(b_in), model.py:151
+            gelu_of(b_in, Gb);
+            if (gm) {
+                k.xtd9(t, U, dD, partial, slabs9, gb + c.Wr2, gb + c.br2, *gm);
+                k.conv3x3(dD, wb + c.Wr2, U, nullptr, dE, ACT_NONE, 1, nullptr, *gm);     // d t (post-activation)
+                k.conv3x3(Gb, wb + c.Wr1, U, wb + c.br1, Z, ACT_NONE, 0, nullptr, *gm);   // z_t, model.py:152
+            } else {
+                k.xtd(t, U, dD, U, partial, slabs, gb + c.Wr2 + ctr, U, gb + c.br2, 0);
+                k.xw(dD, ld, U, wb + c.Wr2 + ctr, U, 1, nullptr, dE, U, ACT_NONE, 0, nullptr);
+                k.xw(Gb, ld, U, wb + c.Wr1 + ctr, U, 0, wb + c.br1, Z, U, ACT_NONE, 0, nullptr);
+            }
+            times_dgelu(dE, Z);                                                           // d z_t
+            if (gm) {
+                k.xtd9(Gb, U, dE, partial, slabs9, gb + c.Wr1, gb + c.br1, *gm, 0);
+                k.conv3x3(dE, wb + c.Wr1, U, nullptr, dB, ACT_NONE, 1, nullptr, *gm);     // d gelu(b_in)
+            } else {
+                k.xtd(Gb, U, dE, U, partial, slabs, gb + c.Wr1 + ctr, U, gb + c.br1, 0, 0);
+                k.xw(dE, ld, U, wb + c.Wr1 + ctr, U, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
+            }
+            times_dgelu(dB, b_in);                                                        // through Activation(b_in)
+            k.xw(b_in, ld, U, wb + c.Wc, U, 0, wb + c.bc, Z, U, ACT_NONE, 0, nullptr);    // z_skip, model.py:148
+            times_dgelu(dC, Z);
+            k.xtd(b_in, U, dC, U, partial, slabs, gb + c.Wc, U, gb + c.bc, 0);
+            k.xw(dC, ld, U, wb + c.Wc, U, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);       // d b_in += d z_skip Wc^T
+        }
+    }
+    // first layer: z_0 = n W0 + b0; dW0 = n^T (dB gelu'(z_0))
+    k.xw(slot(0), ld, T, w + c.W0, U, 0, w + c.b0, Z, U, ACT_NONE, 0, nullptr);
+    times_dgelu(dB, Z);
+    k.xtd(slot(0), T, dB, U, partial, slabs, grad + c.W0, U, grad + c.b0, 0);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
 // g_head_q [N][5], g_head_ls [N][T] (stream 2 only; may be NULL), sums: device double[3] whose
 // third entry is sum(mask) (NULL = gradients already normalised).  grad: canonical layout, overwritten.
 static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* w,
@@ -2101,7 +2217,7 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                           const double* sums, float* grad, int64_t N, void* stream,
                           const qbold_geometry* gm) {
     QB_NEED_DEVICE(ctx);
-    QB_RELU_ONLY(shape, "qbold_encoder_train_bwd");
+
     int rc = check_layerwise_shape(ctx, shape);
     if (rc) return rc;
     if (gm && shape->U > 64) {
@@ -2114,6 +2230,8 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     const int T = c.T, U = c.U, L = c.L, G = c.G;
     const int ld = train_ld(shape->U);
     QB_REQUIRE(5 + shape->T <= ld, "qbold_encoder_train_bwd: the head delta (5 + T columns) exceeds the row stride");
+    if (shape->activation == QBOLD_ACT_GELU)
+        return train_bwd_gelu(ctx, shape, w, stream_sel, ws, g_q, g_ls, sums, grad, N, stream, gm);
     Launcher k{ctx, (hipStream_t)stream, N, ld};
     auto slot = [&](int i) { return ws + (int64_t)i * N * ld; };
     const int base = 2 + 5 * L;

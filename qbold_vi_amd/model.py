@@ -280,7 +280,7 @@ class EncoderTrainer:
         if use_layer_norm or dropout_rate > 0.0:
             unsupported.append("use_layer_norm / dropout_rate (model.py:133-140)")
         if activation_type not in ('relu', 'gelu'):
-            unsupported.append(f"activation_type={activation_type!r} (kernels implement 'relu' and, forward only, 'gelu')")
+            unsupported.append(f"activation_type={activation_type!r} (kernels implement 'relu' and 'gelu')")
         if infer_inv_gamma and use_mvg:
             # the reference itself cannot run this pair: synthetic_data_loss splits the 9-channel first output
             # (5 + 4) in two (tf.split(y_pred_orig, 2, axis=-1), model.py:455)

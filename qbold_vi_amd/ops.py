@@ -61,7 +61,7 @@ class EncoderWeights:
                  precision="f32", activation="relu"):
         self.ctx = ctx
         if activation not in self.ACTIVATIONS:
-            raise ValueError(f"activation {activation!r}: the kernels implement 'relu' and (forward only) 'gelu'")
+            raise ValueError(f"activation {activation!r}: the kernels implement 'relu' and 'gelu'")
         self.shape = EncoderShape(int(T), int(U), int(L), int(bool(channelwise_gating)),
                                   float(gate_offset), 9 if spatial_taps == 9 else 1,
                                   self.PRECISIONS[precision], self.ACTIVATIONS[activation])
@@ -729,9 +729,6 @@ class TrainState:
     def backward(self, stream_sel, g_q, g_ls=None, sums=None):
         """Fills self.grad (canonical layout) from the head gradients of the last forward()."""
         ctx = self.ctx
-        if self.weights.shape.activation != 0:
-            raise NotImplementedError("activation_type='gelu' runs forward only (prediction, ELBO evaluation): its "
-                                      "backward needs the pre-activations, which the training kernels do not keep")
         _lib.check(ctx.lib.qbold_encoder_train_bwd(ctx.handle, C.byref(self.weights.shape),
                                                    _ptr(self.weights.flat), int(stream_sel),
                                                    _ptr(self._ws), _ptr(g_q), _ptr(g_ls), _ptr(sums),

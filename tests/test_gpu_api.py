@@ -211,7 +211,7 @@ def test_disabled_branches_fail_loudly(params):
         EncoderTrainer(params, use_population_prior=False, activation_type='selu')
     with pytest.raises(NotImplementedError, match="dropout"):
         EncoderTrainer(params, use_population_prior=False, activation_type='relu', dropout_rate=0.1)
-    # built since round 3: gelu (forward), the homoscedastic sigma, the population prior with the diagonal family
+    # built since round 3: gelu, the homoscedastic sigma, the population prior with the diagonal family
     EncoderTrainer(params, use_population_prior=False, activation_type='gelu')
     EncoderTrainer(params, use_population_prior=False, activation_type='relu', heteroscedastic_noise=False)
     EncoderTrainer(params, use_population_prior=True, use_mvg=False, mog_components=1, activation_type='relu')
