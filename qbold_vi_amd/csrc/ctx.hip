@@ -212,12 +212,30 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
                     gf[i] = simpson.F(k * oef);
                     gg[i] = simpson.dF(k * oef) * k * hh;
                 }
-                float* row = &ctx->h_gtab[(size_t)4 * (j - 1) * nseg];
+                const double* cf[4] = {nullptr, nullptr, nullptr, nullptr};
+                std::vector<double> c0(nseg), c1(nseg), c2(nseg), c3(nseg);
                 for (int i = 0; i < nseg; ++i) {
-                    row[4 * i + 0] = (float)gf[i];
-                    row[4 * i + 1] = (float)gg[i];
-                    row[4 * i + 2] = (float)(3.0 * (gf[i + 1] - gf[i]) - 2.0 * gg[i] - gg[i + 1]);
-                    row[4 * i + 3] = (float)(2.0 * (gf[i] - gf[i + 1]) + gg[i] + gg[i + 1]);
+                    c0[i] = gf[i];
+                    c1[i] = gg[i];
+                    c2[i] = 3.0 * (gf[i + 1] - gf[i]) - 2.0 * gg[i] - gg[i + 1];
+                    c3[i] = 2.0 * (gf[i] - gf[i + 1]) + gg[i] + gg[i + 1];
+                }
+                cf[0] = c0.data(); cf[1] = c1.data(); cf[2] = c2.data(); cf[3] = c3.data();
+                if (qb::gtab_paired(T, se)) {
+                    // tau j is member m = (j - 1) & 1 of pair p = (j - 1) / 2: rows 2p (c0, c1) and 2p + 1 (c2, c3)
+                    const int p = (j - 1) / 2, m = (j - 1) & 1;
+                    float* rowA = &ctx->h_gtab[(size_t)4 * (2 * p) * nseg];
+                    float* rowB = &ctx->h_gtab[(size_t)4 * (2 * p + 1) * nseg];
+                    for (int i = 0; i < nseg; ++i) {
+                        rowA[4 * i + 0 + m] = (float)cf[0][i];
+                        rowA[4 * i + 2 + m] = (float)cf[1][i];
+                        rowB[4 * i + 0 + m] = (float)cf[2][i];
+                        rowB[4 * i + 2 + m] = (float)cf[3][i];
+                    }
+                } else {
+                    float* row = &ctx->h_gtab[(size_t)4 * (j - 1) * nseg];
+                    for (int i = 0; i < nseg; ++i)
+                        for (int q = 0; q < 4; ++q) row[4 * i + q] = (float)cf[q][i];
                 }
             }
             ctx->gtab_ok = true;

@@ -165,50 +165,92 @@ __device__ __forceinline__ float sample_sq_fast(const GtLds<T, SE>* L, const QbD
     const float cg = clampf_(fmaf(oef, kScale, -QB_GT_OEF_MIN * kScale), 0.0f, (float)NSEG - 0.0009765625f);
     const float f = __builtin_amdgcn_fractf(cg);
     const float4* row = L->gtab + (int)cg;
-    // The rows of a draw sit at immediate offsets from one address, so nothing orders their reads: left alone the
-    // compiler requests all of them up front (32 live registers: spills under the fused kernel's 128-register
-    // budget).  A ring keeps QB_GT_DEPTH evaluations in flight; sched_barrier pins requests AND arithmetic.
-    struct Stage {
-        float4 kk;
-        float bb;
-    };
-    auto issue = [&](int t) -> Stage {
-        const int j = t > SE ? t - SE : SE - t;
-        Stage st;
-        st.kk = row[(j - 1) * NSEG];
-        st.bb = L->blood_B[t];
-        return st;
-    };
-    auto finish = [&](int t, const Stage& st) {   // normalised prediction at tau index t, scored at t and its mirror
-        const float F = fmaf(fmaf(fmaf(st.kk.w, f, st.kk.z), f, st.kk.y), f, st.kk.x);
-        const float yh = exp2f_(fmaf(fv.nd, F, lt)) + exp2f_(fmaf(fv.ng, st.bb, lb));
-        const float r = fmaf(-yh, k.inv_s[t], k.yt[t]);
-        acc = fmaf(r, r, acc);
-        const int tm = 2 * SE - t;                // the mirrored tau: the signal is even in tau
-        if (t > SE && tm >= 0) {
-            const float r1 = fmaf(-yh, k.inv_s[tm >= 0 ? tm : 0], k.yt[tm >= 0 ? tm : 0]);
-            acc = fmaf(r1, r1, acc);
-        }
-    };
     {
         const float r = fmaf(-(s_se * inv_np), k.inv_s[SE], k.yt[SE]);
         acc = fmaf(r, r, acc);
     }
     // evaluation order: SE + 1 .. T - 1, then the taus below the spin echo that have no partner on the grid
     constexpr int NA = T - 1 - SE, NB = (2 * SE - (T - 1)) > 0 ? 2 * SE - (T - 1) : 0, NE = NA + NB;
-    auto tau_of = [](int e) { return e < NA ? SE + 1 + e : e - NA; };
-    constexpr int D = QB_GT_DEPTH < NE ? QB_GT_DEPTH : NE;
-    Stage ring[D + 1];
+    auto score = [&](int t, float yh) {   // the normalised prediction at tau index t, scored at t and its mirror
+        const float r = fmaf(-yh, k.inv_s[t], k.yt[t]);
+        acc = fmaf(r, r, acc);
+        const int tm = 2 * SE - t;        // the mirrored tau: the signal is even in tau
+        if (t > SE && tm >= 0) {
+            const float r1 = fmaf(-yh, k.inv_s[tm >= 0 ? tm : 0], k.yt[tm >= 0 ? tm : 0]);
+            acc = fmaf(r1, r1, acc);
+        }
+    };
+    // The rows of a draw sit at immediate offsets from one address, so nothing orders their reads: left alone the
+    // compiler requests all of them up front and spills under the fused kernel's 128-register budget.  A ring keeps
+    // QB_GT_DEPTH evaluations in flight; sched_barrier pins requests AND arithmetic.
+    if constexpr (gtab_paired(T, SE)) {
+        // Two taus per step on packed float32 pairs (v_pk_fma_f32: 4.6 cycles for two FMAs against 2 x 2.9): the table
+        // interleaves the coefficients of taus 2p + 1 and 2p + 2 so that a row read delivers aligned pairs -- cubic,
+        // both exponent FMAs and the blood bracket run packed, no register moves to build the pairs.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        static_assert(NB == 0 && NA % 2 == 0, "paired table: every evaluated tau above the spin echo, in pairs");
+        struct Stage {
+            float4 A, B;   // (c0a, c0b, c1a, c1b), (c2a, c2b, c3a, c3b)
+            f32x2 bb;
+        };
+        auto issue = [&](int p) -> Stage {
+            Stage st;
+            st.A = row[(2 * p) * NSEG];
+            st.B = row[(2 * p + 1) * NSEG];
+            st.bb = f32x2{L->blood_B[SE + 1 + 2 * p], L->blood_B[SE + 2 + 2 * p]};
+            return st;
+        };
+        const f32x2 ff{f, f}, nd2{fv.nd, fv.nd}, ng2{fv.ng, fv.ng}, lt2{lt, lt}, lb2{lb, lb};
+        auto finish = [&](int p, const Stage& st) {
+            const f32x2 c0{st.A.x, st.A.y}, c1{st.A.z, st.A.w}, c2{st.B.x, st.B.y}, c3{st.B.z, st.B.w};
+            const f32x2 F = __builtin_elementwise_fma(__builtin_elementwise_fma(__builtin_elementwise_fma(c3, ff, c2), ff, c1), ff, c0);
+            const f32x2 e1 = __builtin_elementwise_fma(nd2, F, lt2), e2 = __builtin_elementwise_fma(ng2, st.bb, lb2);
+            score(SE + 1 + 2 * p, exp2f_(e1.x) + exp2f_(e2.x));
+            score(SE + 2 + 2 * p, exp2f_(e1.y) + exp2f_(e2.y));
+        };
+        constexpr int NP = NA / 2;
+        constexpr int D = (QB_GT_DEPTH + 1) / 2 < NP ? (QB_GT_DEPTH + 1) / 2 : NP;
+        Stage ring[D + 1];
 #pragma unroll
-    for (int e = 0; e < D; ++e) ring[e] = issue(tau_of(e));
+        for (int e = 0; e < D; ++e) ring[e] = issue(e);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        if (e + D < NE) ring[(e + D) % (D + 1)] = issue(tau_of(e + D));
-        __builtin_amdgcn_sched_barrier(0);
-        finish(tau_of(e), ring[e % (D + 1)]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int e = 0; e < NP; ++e) {
+            if (e + D < NP) ring[(e + D) % (D + 1)] = issue(e + D);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(e, ring[e % (D + 1)]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return acc;
+    } else {
+        struct Stage {
+            float4 kk;
+            float bb;
+        };
+        auto issue = [&](int t) -> Stage {
+            const int j = t > SE ? t - SE : SE - t;
+            Stage st;
+            st.kk = row[(j - 1) * NSEG];
+            st.bb = L->blood_B[t];
+            return st;
+        };
+        auto finish = [&](int t, const Stage& st) {
+            const float F = fmaf(fmaf(fmaf(st.kk.w, f, st.kk.z), f, st.kk.y), f, st.kk.x);
+            score(t, exp2f_(fmaf(fv.nd, F, lt)) + exp2f_(fmaf(fv.ng, st.bb, lb)));
+        };
+        auto tau_of = [](int e) { return e < NA ? SE + 1 + e : e - NA; };
+        constexpr int D = QB_GT_DEPTH < NE ? QB_GT_DEPTH : NE;
+        Stage ring[D + 1];
+#pragma unroll
+        for (int e = 0; e < D; ++e) ring[e] = issue(tau_of(e));
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (e + D < NE) ring[(e + D) % (D + 1)] = issue(tau_of(e + D));
+            __builtin_amdgcn_sched_barrier(0);
+            finish(tau_of(e), ring[e % (D + 1)]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return acc;
     }
-    return acc;
 }
 
 template <int T, int SE>

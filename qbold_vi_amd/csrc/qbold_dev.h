@@ -305,6 +305,17 @@ __host__ __device__ constexpr int gtab_taus(int T, int SE) { return SE > T - 1 -
 // T = 24 keeps the x-indexed table: 52 segments would fit beside its weight image, but with 48 data registers live the
 // ring spills (0.947 against 0.755 ms per 1 M voxels, measured)
 __host__ __device__ constexpr int gtab_segs(int T) { return T == 11 ? QB_GT_SEGS_11 : 0; }
+// Pair-interleaved rows (QB_GT_PAIRS): when every evaluated tau lies above the spin echo and they come in pairs, rows
+// 2p and 2p + 1 of the table hold (c0a, c0b, c1a, c1b) and (c2a, c2b, c3a, c3b) of taus j = 2p + 1 (a) and 2p + 2 (b),
+// so that a row read delivers aligned float32 pairs for v_pk_fma_f32 (elbo_core.h).  Measured and NOT adopted: 137
+// instead of 157 instructions per draw, but 0.474 against 0.459 ms per 1 M voxels on the split-f16 kernel (the packed
+// forms issue slower than they save, as round 1 found for hand-built pairs); kept as a build option.
+#ifndef QB_GT_PAIRS
+#define QB_GT_PAIRS 0
+#endif
+__host__ __device__ constexpr bool gtab_paired(int T, int SE) {
+    return QB_GT_PAIRS && gtab_segs(T) > 0 && 2 * SE - (T - 1) <= 0 && (T - 1 - SE) % 2 == 0 && gtab_taus(T, SE) == T - 1 - SE;
+}
 #define QB_GT_OEF_MIN 0.04f
 #define QB_GT_OEF_RANGE 0.8f
 template <int T, int SE>
