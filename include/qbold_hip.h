@@ -229,6 +229,11 @@ int qbold_reparam(const qbold_ctx* ctx, const float* q, const float* z, float* o
  * y [N][2] under params [N][5] -> out [N]. */
 int qbold_logit_mvn_nlogp(const qbold_ctx* ctx, const float* y, const float* params, float* out,
                           int64_t N, void* stream);
+/* kl_loss against a mixture-of-Gaussians population prior (use_mvg = False, use_population_prior = True,
+ * mog_components = M > 1; model.py:666-685): q [N][5] (columns 0-3), comps DEVICE [M][4] raw parameters (M <= 16),
+ * z = explicit normals [N][2] (OEF draw, DBV draw) or NULL for the in-kernel Philox stream -> kl [N] (unmasked). */
+int qbold_kl_mog(const qbold_ctx* ctx, const float* q, const float* comps, int M, const float* z, uint64_t seed,
+                 int64_t voxel0, float* kl, int64_t N, void* stream);
 /* EncoderTrainer.squared_whitened_residual (model.py:423-441) = LogitMVN.squared_whitened_residual
  * (logit_mvn.py:20-38), a static method there and context-free here: obs, mean [N][2]; oef_log_std, dbv_log_std,
  * oef_dbv_cov [N] (already transformed) -> out [N] = || L^-1 (obs - mean) ||^2. */

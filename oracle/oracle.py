@@ -295,6 +295,16 @@ class Oracle:
         self.lib.qbo_population_prior_cost.restype = C.c_double
         return self.lib.qbo_population_prior_cost(self._p(p), C.c_int(int(batch)))
 
+    def kl_mog(self, q, comps, z):
+        """model.py:666-685: one-draw KL estimate against a mixture-of-Gaussians population prior, comps [M, 4]."""
+        q = self._a(q, (-1, 5))
+        comps = self._a(comps, (-1, 4))
+        z = self._a(z, (q.shape[0], 2))
+        out = np.empty(q.shape[0], self.dtype)
+        self.lib.qbo_kl_mog(self._p(q), self._p(comps), C.c_int(comps.shape[0]), self._p(z), self._p(out),
+                            C.c_int64(q.shape[0]))
+        return out
+
     def logit_gaussian_nlogp(self, y, p):
         y = self._a(y, (-1, 2))
         p = self._a(p, (-1, 5))

@@ -825,6 +825,29 @@ double qbo_population_prior_cost(const real *prior4 /*[4]*/, int batch) {
     return cost * (double)batch;
 }
 
+/* kl_loss, mixture-of-Gaussians population prior (use_mvg = False, use_population_prior = True, mog_components = M > 1)
+ * -- model.py:666-685.  Per voxel, with ONE reparameterised draw per dimension (z[0] for OEF, z[1] for DBV, :672-675):
+ *   entropy = s_o + s_d;  sample = mu + z exp(s);
+ *   kl = -entropy + (1 / M) sum_i [ nll(oef_sample; comp_i[0], comp_i[1]) + nll(dbv_sample; comp_i[2], comp_i[3]) ],
+ *   nll(x; m, raw) = transform_std(raw) + 0.5 ((x - m) / exp(transform_std(raw)))^2                       (:677-678)
+ * q rows 5 wide (columns 0-3 used), comps [M][4] raw parameters. */
+void qbo_kl_mog(const real *q, const real *comps, int M, const real *z /*[N][2]*/, real *kl, int64_t N) {
+    for (int64_t i = 0; i < N; ++i) {
+        const real *qq = q + 5 * i;
+        const real so = transform_std(qq[1]), sd = transform_std(qq[3]);
+        const real xo = qq[0] + z[2 * i] * r_exp(so), xd = qq[2] + z[2 * i + 1] * r_exp(sd);
+        real acc = -(so + sd);
+        for (int c = 0; c < M; ++c) {
+            const real *p = comps + 4 * c;
+            const real po = transform_std(p[1]), pd = transform_std(p[3]);
+            const real ro = (xo - p[0]) / r_exp(po), rd = (xd - p[2]) / r_exp(pd);
+            acc += (po + R(0.5) * ro * ro) / (real)M;
+            acc += (pd + R(0.5) * rd * rd) / (real)M;
+        }
+        kl[i] = acc;
+    }
+}
+
 /* logit_gaussian_log_prob (diagonal family, model.py:406-421): NEGATIVE log-density up to the
  * reference's own constant -- gaussian_nll (:403-404) carries no log sqrt(2 pi).  p rows 5 wide. */
 void qbo_logit_gaussian_nlogp(const real *y, const real *p, real *out, int64_t N) {

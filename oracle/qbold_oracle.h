@@ -145,6 +145,7 @@ void qbo_kl_closed(const real *q, const real *prior, real *kl /*[N]*/, int64_t N
  * logit_gaussian_log_prob (:406-421); rows 5 wide, columns 0-3 used. */
 void qbo_kl_diag(const real *q, const real *prior, real *kl, int64_t N);
 double qbo_population_prior_cost(const real *prior4 /*[4]*/, int batch);
+void qbo_kl_mog(const real *q /*[N][5]*/, const real *comps /*[M][4]*/, int M, const real *z /*[N][2]*/, real *kl, int64_t N);
 void qbo_logit_gaussian_nlogp(const real *y /*[N][2]*/, const real *p /*[N][5]*/, real *out, int64_t N);
 /* calculate_means(include_r2p=True, return_stds=True) with explicit z [N][n][2] --
  * model.py:318-343.  means/vars [N][3] = (OEF, DBV, R2'). */

@@ -103,6 +103,7 @@ SIGNATURES = {
     "qbold_encoder_fused_fwd": (C.c_int, [_P, C.POINTER(EncoderShape), _P, _P, _P, _P, C.c_int64, _P]),
     "qbold_vi_workspace_bytes": (C.c_int64, [_P, C.POINTER(EncoderShape), C.c_int64]),
     "qbold_signal_fwd_ex": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "qbold_kl_mog": (C.c_int, [_P, _P, _P, C.c_int, _P, _U64, _I64, _P, _I64, _P]),
     "qbold_kl_diag": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "qbold_wls_fit": (C.c_int, [_P, _P, C.c_double, _P, C.c_int64, _P]),
     "qbold_smoothness": (C.c_int, [_P, _P, _P, C.POINTER(Geometry), C.c_float, _P, _P, _P]),

@@ -790,6 +790,59 @@ extern "C" int qbold_kl_diag(const qbold_ctx* ctx, const float* q, const float* 
     return QBOLD_OK;
 }
 
+// kl_loss against a mixture-of-Gaussians population prior (use_mvg = False, mog_components = M > 1; model.py:666-685):
+// one reparameterised draw per dimension, minus the entropy of q, plus the MEAN of the components' Gaussian NLLs.
+// comps: device [M][4] raw parameters; z: explicit normals [N][2] (OEF, DBV) or NULL for the Philox stream
+// (stream 4, one pair per voxel).
+constexpr int kMaxMog = 16;
+__global__ __launch_bounds__(256) void kl_mog_kernel(const float* __restrict__ q, const float* __restrict__ comps, int M,
+                                                     const float* __restrict__ z, uint64_t seed, int64_t voxel0,
+                                                     float* __restrict__ kl_v, int64_t N) {
+    __shared__ float cm[kMaxMog][4];   // mean_o, exp(-s_o), mean_d, exp(-s_d)
+    __shared__ float cs[kMaxMog];      // s_o + s_d
+    if (threadIdx.x < M) {
+        const float so = qb::transform_std(comps[4 * threadIdx.x + 1]), sd = qb::transform_std(comps[4 * threadIdx.x + 3]);
+        cm[threadIdx.x][0] = comps[4 * threadIdx.x + 0];
+        cm[threadIdx.x][1] = __expf(-so);
+        cm[threadIdx.x][2] = comps[4 * threadIdx.x + 2];
+        cm[threadIdx.x][3] = __expf(-sd);
+        cs[threadIdx.x] = so + sd;
+    }
+    __syncthreads();
+    const float inv_m = 1.0f / (float)M;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < N; v += (int64_t)gridDim.x * blockDim.x) {
+        float z0, z1;
+        if (z) {
+            z0 = z[2 * v];
+            z1 = z[2 * v + 1];
+        } else {
+            float zz[4];
+            qb::normals4(seed, (uint64_t)(voxel0 + v), 0u, 4u, zz);
+            z0 = zz[0];
+            z1 = zz[1];
+        }
+        const float so = qb::transform_std(q[v * 5 + 1]), sd = qb::transform_std(q[v * 5 + 3]);
+        const float xo = fmaf(z0, __expf(so), q[v * 5 + 0]), xd = fmaf(z1, __expf(sd), q[v * 5 + 2]);   // :672-675
+        float acc = 0.0f;
+        for (int c = 0; c < M; ++c) {
+            const float ro = (xo - cm[c][0]) * cm[c][1], rd = (xd - cm[c][2]) * cm[c][3];
+            acc += cs[c] + 0.5f * fmaf(ro, ro, rd * rd);
+        }
+        kl_v[v] = fmaf(acc, inv_m, -(so + sd));                                                         // :679-684
+    }
+}
+
+extern "C" int qbold_kl_mog(const qbold_ctx* ctx, const float* q, const float* comps, int M, const float* z,
+                            uint64_t seed, int64_t voxel0, float* kl_v, int64_t N, void* stream) {
+    QB_NEED_DEVICE(ctx);
+    if (N == 0) return QBOLD_OK;
+    QB_REQUIRE(N > 0 && q && comps && kl_v && M >= 1 && M <= kMaxMog, "qbold_kl_mog: bad argument (1 <= M <= 16)");
+    hipLaunchKernelGGL(kl_mog_kernel, dim3(ew_grid(ctx, N, 256)), dim3(256), 0, (hipStream_t)stream, q, comps, M, z, seed,
+                       voxel0, kl_v, N);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
 extern "C" int qbold_reparam(const qbold_ctx* ctx, const float* q, const float* z, float* oef_dbv,
                              int64_t N, void* stream) {
     QB_NEED_DEVICE(ctx);

@@ -161,8 +161,12 @@ class FineTuner:
         self.log_sigma = None if trainer._heteroscedastic_noise else math.log(float(trainer._initial_im_sigma))
         # use_population_prior with the diagonal family (model.py:262-271): a 4-vector variable of the fine-tuner,
         # [mu_oef, raw_s_oef, mu_dbv, raw_s_dbv], appended to 'predictions' as constant channels
-        self.pop_prior = (np.array([-0.97, 0.4, -1.14, 0.6], np.float32)
-                          if trainer._use_population_prior else None)
+        # (mog_components > 1: 4 M values, random-normal initialised, model.py:262-266)
+        M = int(trainer._mog_components)
+        self.pop_prior = None
+        if trainer._use_population_prior:
+            self.pop_prior = (np.array([-0.97, 0.4, -1.14, 0.6], np.float32) if M <= 1 else
+                              np.random.default_rng(trainer._seed).standard_normal(4 * M).astype(np.float32))
 
     def __call__(self, inputs):
         return self.predict(inputs)
@@ -177,7 +181,7 @@ class FineTuner:
         sampled = self._rpl((qs, mask))     # model.py:248
         if self.pop_prior is not None:      # model.py:268-270
             pp = torch.as_tensor(self.pop_prior, device=qs.device)
-            qs = torch.cat([qs, pp.expand(qs.shape[:-1] + (4,))], -1)
+            qs = torch.cat([qs, pp.expand(qs.shape[:-1] + (pp.numel(),))], -1)
         output = self.signal_generation_layer(sampled)  # model.py:273
         if self.log_sigma is not None:      # model.py:277-281: one channel holding the scalar sigma
             sig = torch.full(output.shape[:-1] + (1,), math.exp(self.log_sigma), dtype=output.dtype,
@@ -202,7 +206,8 @@ class FineTuner:
         m = None if mask is None else mask.reshape(-1)
         p5 = _pad5(_flat(prior, prior.shape[-1])).contiguous()
         K = kl_samples if tr._use_mvg else 0   # diagonal family: closed-form KL below (model.py:686-716)
-        if self.pop_prior is not None:   # the per-voxel prior is ignored (model.py:687-690): one population prior
+        mog = self.pop_prior is not None and self.pop_prior.size > 4
+        if self.pop_prior is not None and not mog:   # the per-voxel prior is ignored (model.py:687-690): one population prior
             p5 = _pad5(torch.as_tensor(self.pop_prior, device=x.device).expand(x.shape[0], 4)).contiguous()
         if tr._is_spatial(data) or self.log_sigma is not None:
             _, q5, sg5 = self.encoder_model.predict(data, want=("out2", "sigma"))
@@ -216,7 +221,14 @@ class FineTuner:
             # recomputed on the exact-float32 layer-wise path (ops.Context.vi_fwd)
             sums, q, nll_kl = tr._ctx.vi_fwd(self.encoder_model.weights, x, m, p5, S, K, seed=seed, voxel0=voxel0,
                                              range_check=True)
-        if not tr._use_mvg:
+        if not tr._use_mvg and mog:   # model.py:666-685: one draw per dimension against the mixture (no prior cost)
+            kl_v = tr._ctx.kl_mog(q, torch.as_tensor(self.pop_prior, device=x.device).reshape(-1, 4), seed=seed,
+                                  voxel0=voxel0)
+            live = kl_v if m is None else torch.where(m > 0, kl_v, torch.zeros_like(kl_v))
+            sums[1] = live.sum(dtype=torch.float64)
+            nll_kl[:, 1] = kl_v
+            q = q[:, :4].contiguous()
+        elif not tr._use_mvg:
             ksums, kl_v = tr._ctx.kl_diag(q, p5, m)
             sums[1] = ksums[1]
             nll_kl[:, 1] = kl_v
@@ -291,8 +303,8 @@ class EncoderTrainer:
             # logit_gaussian_mvg_log_prob, which reshapes them to (-1, 5) and so doubles the rows (model.py:596, 378)
             unsupported.append("use_population_prior with use_mvg=True (a shape error in the reference, model.py:596; "
                                "the population prior runs with the diagonal family, use_mvg=False)")
-        if use_population_prior and mog_components > 1:
-            unsupported.append("mog_components > 1 (model.py:666-685)")
+        if use_population_prior and not use_mvg and mog_components > 16:
+            unsupported.append("mog_components > 16")
         if unsupported:
             raise NotImplementedError("configuration outside the accelerated path (disabled by "
                                       "configurations/optimal.yaml): " + "; ".join(unsupported))
@@ -504,6 +516,16 @@ class EncoderTrainer:
             pr = _flat(true, 5)   # [p_oef_mean, p_oef_log_std, p_dbv_mean, p_dbv_log_std, mask]
             pred = _flat(predicted, predicted.shape[-1])
             prior_cost = 0.0
+            if self._use_population_prior and self._mog_components > 1:   # model.py:666-685
+                M = int(self._mog_components)
+                if pred.shape[-1] != 4 + 4 * M:
+                    raise ValueError("mog_components: predictions must carry 4 + 4 M channels (model.py:262-270)")
+                kl = self._ctx.kl_mog(_pad5(pred[:, :4]).contiguous(), pred[0, 4:].reshape(M, 4).contiguous(),
+                                      seed=self._seed if seed is None else seed)
+                kl_op = kl.reshape(predicted.shape[:-1] + (1,))
+                mask = true[..., 4:5]
+                kl_op = torch.where(mask > 0, kl_op, torch.zeros_like(kl_op))
+                return kl_op.sum() / mask.sum() if return_mean else kl_op
             if self._use_population_prior:   # 'predictions' = [q4 | population prior 4]; `true` gives the mask only
                 if pred.shape[-1] != 8:
                     raise ValueError("use_population_prior: predictions must carry 4 + 4 channels (model.py:268-270)")

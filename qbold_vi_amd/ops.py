@@ -581,6 +581,22 @@ def kl_diag(self, q, prior, mask=None, g_q=None, per_voxel=True):
 
 
 @_ctx_method
+def kl_mog(self, q, comps, z=None, seed=1, voxel0=0):
+    """kl_loss against a mixture-of-Gaussians population prior (model.py:666-685): q [N,5] (columns 0-3 used), comps
+    [M,4] raw parameters; one draw per dimension from z [N,2] or the Philox stream.  Returns kl [N] (unmasked)."""
+    q = _f32(q, "q", 5)
+    comps = _f32(comps, "comps", 4)
+    N = q.numel() // 5
+    z = _f32(z, "z", 2) if z is not None else None
+    if z is not None and z.numel() != 2 * N:
+        raise ValueError("z must be [N, 2]")
+    out = torch.empty(N, dtype=torch.float32, device=q.device)
+    _lib.check(self.lib.qbold_kl_mog(self.handle, _ptr(q), _ptr(comps), comps.numel() // 4, _ptr(z), int(seed), int(voxel0),
+                                     _ptr(out), N, _stream()), "qbold_kl_mog")
+    return out
+
+
+@_ctx_method
 def wls_fit(self, signals, tau_min=0.016):
     """loglinear.fit_wls per voxel: signals [N,T] -> [N,3] = (OEF, DBV, R2'), clipped."""
     x = _f32(signals, "signals", self.T)

@@ -191,7 +191,7 @@ class ScalarAdamW:
 
 def _fine_tuner_guards(trainer, full_model):
     if getattr(full_model, "pop_prior", None) is not None:
-        # train.py:318-320 always adds smoothness_loss, which splits the 8-channel 'predictions' of the population
+        # train.py:318-320 always adds smoothness_loss, which splits the 8- (or 4 + 4 M-) channel 'predictions' of the population
         # prior into 4 groups and fails on the range division (model.py:729-739): the reference cannot fine-tune
         # with it; the evaluation side (kl_loss, FineTuner.elbo) is built
         raise NotImplementedError("fine-tuning with use_population_prior: the reference's own smoothness_loss "

@@ -240,6 +240,20 @@ pred8 = np.concatenate([q[:, :4], np.broadcast_to(pop, (N, 4))], -1).reshape(N, 
 put("kl/population_diag", pop_prior=pop, mean=et_pop.kl_loss(T_(true5), T_(pred8)),
     per_voxel=et_pop.kl_loss(T_(true5), T_(pred8), return_mean=False).a.reshape(N))
 
+# mixture-of-Gaussians population prior (model.py:666-685): predictions = [q4 | M x prior4]; one reparameterised draw
+# per voxel (OEF normal first, then DBV), minus the entropy of q, plus the MEAN of the components' Gaussian NLLs
+M = 3
+et_mog = ref_model.EncoderTrainer(P, use_mvg=False, use_population_prior=True, mog_components=M)
+comps = np.stack([rng.normal(-0.8, 0.6, M), rng.normal(0.2, 0.5, M), rng.normal(-1.2, 0.6, M), rng.normal(0.3, 0.5, M)],
+                 -1).astype(np.float32)                                          # [M][4]
+pred_mog = np.concatenate([q[:, :4], np.broadcast_to(comps.reshape(-1), (N, 4 * M))], -1).reshape(N, 1, 1, 1, 4 + 4 * M)
+tf.random.set_seed(33)
+mog_mean = et_mog.kl_loss(T_(true5), T_(pred_mog))
+z_mog = np.stack([d.reshape(N) for d in draws("normal")], -1)                  # [N][2]: (z_oef, z_dbv)
+tf.random.set_seed(33)
+mog_map = et_mog.kl_loss(T_(true5), T_(pred_mog), return_mean=False)
+put("kl/mog", components=comps, z=z_mog, mean=mog_mean, per_voxel=mog_map.a.reshape(N))
+
 # smoothness_loss (model.py:726-754) on crops
 B, X, Y, Z = 2, 6, 5, 3
 qc = q_params(B * X * Y * Z).reshape(B, X, Y, Z, 5)

@@ -205,8 +205,6 @@ def test_disabled_branches_fail_loudly(params):
         EncoderTrainer(params, use_population_prior=True, use_mvg=True, activation_type='relu')
     with pytest.raises(NotImplementedError, match="shape error in the reference"):
         EncoderTrainer(params, use_population_prior=False, use_mvg=True, infer_inv_gamma=True, activation_type='relu')
-    with pytest.raises(NotImplementedError, match="mog_components"):
-        EncoderTrainer(params, use_population_prior=True, use_mvg=False, mog_components=3, activation_type='relu')
     with pytest.raises(NotImplementedError, match="activation_type"):
         EncoderTrainer(params, use_population_prior=False, activation_type='selu')
     with pytest.raises(NotImplementedError, match="dropout"):
@@ -215,6 +213,7 @@ def test_disabled_branches_fail_loudly(params):
     EncoderTrainer(params, use_population_prior=False, activation_type='gelu')
     EncoderTrainer(params, use_population_prior=False, activation_type='relu', heteroscedastic_noise=False)
     EncoderTrainer(params, use_population_prior=True, use_mvg=False, mog_components=1, activation_type='relu')
+    EncoderTrainer(params, use_population_prior=True, use_mvg=False, mog_components=3, activation_type='relu')
     # misalignment / variable_hct are built (test_signal_variable_hct_and_misalignment); their
     # gradient is not -- they only occur in synthetic-data generation (signals.py:251-300)
     layer = SignalGenerationLayer(dict(params, simulate_noise='False'), True, True, misaligned_prob=0.1)

@@ -327,3 +327,29 @@ def test_gelu_encoder(params):
                                   gs.reshape(n, 11).contiguous(), 1, 16, seed=2)
     assert torch.equal(e["sums"], sums)
     # (its training gradients: tests/test_gpu_branches.py::test_gelu_training_gradients_*)
+
+
+def test_mixture_of_gaussians_kl(params):
+    """kl_loss with mog_components = 3 (model.py:666-685) on the reference's own draws, and through the host mirror."""
+    q, prior, mask = g("kl/sampled", "q", "prior", "mask")
+    comps, z = g("kl/mog", "components", "z")
+    n = len(q)
+    tm = trainer(params, use_mvg=False, use_population_prior=True, mog_components=3)
+    kl = tm.context.kl_mog(dev(q), dev(comps), z=dev(z)) * dev((mask > 0).astype(np.float32))
+    close(kl, g("kl/mog", "per_voxel"), rtol=1e-4, atol=1e-5)
+    close(kl.double().sum() / float(mask.sum()), g("kl/mog", "mean"), rtol=1e-4)
+    # the reference-shaped call draws its own normals: same expectation
+    true5 = dev(np.concatenate([prior[:, :4], mask[:, None]], -1).reshape(n, 1, 1, 1, 5))
+    pred = dev(np.concatenate([q[:, :4], np.broadcast_to(comps.reshape(-1), (n, 12))], -1).reshape(n, 1, 1, 1, 16))
+    vals = [float(tm.kl_loss(true5, pred, seed=s)) for s in range(1, 9)]
+    assert abs(np.mean(vals) / float(g("kl/mog", "mean")) - 1) < 0.25 and np.std(vals) > 0
+    assert tuple(tm.kl_loss(true5, pred, return_mean=False).shape) == (n, 1, 1, 1, 1)
+    # the fine-tuner appends the 4 M prior values to 'predictions' and evaluates the ELBO with this KL
+    from qbold_vi_amd.signals import SignalGenerationLayer
+    model, _ = tm.create_encoder(gate_offset=-3.0, resid_init_std=0.05, no_ip_images=11)
+    full = tm.build_fine_tuner(model, SignalGenerationLayer(dict(params, simulate_noise="False"), True, True))
+    x = g("nll/inputs", "data")[:64]
+    out = full([dev(x.reshape(64, 1, 1, 1, 11)), None])
+    assert tuple(out["predictions"].shape) == (64, 1, 1, 1, 16)
+    e = full.elbo(dev(x), None, dev(prior[:64]), seed=4)
+    assert np.isfinite(float(e["kl"])) and np.isfinite(float(e["nll"]))

@@ -305,3 +305,14 @@ def test_gelu_encoder(oracle32):
         oracle32.set_activation("relu")
     r1, _, _ = oracle32.encoder_fwd(centre_taps(w), x)
     assert np.abs(r1 - o1).max() > 1e-3          # relu on the same weights is a different network
+
+
+def test_mixture_of_gaussians_kl(oracle32):
+    """kl_loss with mog_components = 3 (model.py:666-685): -entropy + the MEAN of the components' Gaussian NLLs at one
+    reparameterised draw per dimension."""
+    q, mask = g("kl/sampled", "q", "mask")
+    comps, z = g("kl/mog", "components", "z")
+    assert comps.shape == (3, 4) and z.shape == (len(q), 2)
+    kl = oracle32.kl_mog(q, comps, z) * (mask > 0)
+    close(kl, g("kl/mog", "per_voxel"), rtol=1e-4, atol=1e-5)
+    close(kl.astype(np.float64).sum() / mask.sum(), g("kl/mog", "mean"), rtol=1e-4)
