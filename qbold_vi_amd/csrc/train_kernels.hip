@@ -10,6 +10,7 @@
 // training steps are 190-256 k voxels in the reference (train.py:68,103), ~1 GB of activations,
 // and HBM-bound at a few ms per step -- off the voxel-ELBO headline path, correctness first.
 #include <cmath>
+#include <type_traits>
 
 #include "canon_layout.h"
 #include "encoder_core.h"
@@ -77,6 +78,21 @@ __device__ __forceinline__ int64_t gather_row(const Gather& gt, int64_t v) {
     const int xx = x + gt.dx, yy = y + gt.dy;
     if (xx < 0 || xx >= gt.X || yy < 0 || yy >= gt.Y) return -1;
     return v + ((int64_t)gt.dx * gt.Y + gt.dy) * gt.Z;
+}
+
+// Row tensors read through a buffer resource of N x 256 bytes: an offset at or beyond kOutside is outside any of
+// them (N < 2^23) and the hardware returns zeros for it -- padding without a select behind the load.
+constexpr uint32_t kOutside = 0x80000000u;
+// one v_max_f32 (fmaxf would quiet a signalling NaN first: two instructions per value)
+__device__ __forceinline__ float max_1op(float x, float floor) {
+    float y;
+    asm("v_max_f32 %0, %1, %2" : "=v"(y) : "s"(floor), "v"(x));
+    return y;
+}
+__device__ __forceinline__ float relu_1op(float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
 }
 
 // Y[N][ldy] (cols < ndim) = act(X[N][ldx] (cols < kdim) . W + b), W given as Wl[k][j]:
@@ -826,21 +842,45 @@ __global__ __launch_bounds__(1024) void conv9h_kernel(const float* __restrict__ 
                                                       int ldm, int64_t N, Gather g0) {
     extern __shared__ __align__(16) float img[];  // [9][s 2][m 4][hi, lo][lane 64][8 halves], then bias[64]
     float* bias = img + 9 * 4096;
-    for (int e = threadIdx.x; e < 9 * 8192; e += 1024) {
-        const int tap = e >> 13, ee = e & 8191;
-        const int j8 = ee & 7, ln = (ee >> 3) & 63, part = (ee >> 9) & 1, m = (ee >> 10) & 3, st = ee >> 12;
-        const int k = 16 * (2 * st + (j8 >> 2)) + 4 * (ln >> 4) + (j8 & 3), j = 16 * m + (ln & 15);
-        const float* W = K9 + (int64_t)tap * U * U;
-        float w = 0.0f;
-        if (k < U && j < U) w = flip ? W[j * U + k] : W[k * U + j];
-        const _Float16 hi = (_Float16)w;
-        reinterpret_cast<_Float16*>(img)[e] = part == 0 ? hi : (_Float16)((w - (float)hi) * QB_LO_SCALE);
+    // the nine tap kernels into the weight image: thread (a, b) of a 16 x 64 patch reads W[tap][a][b] (rows of U
+    // floats, coalesced; 36 independent loads per thread, all in flight at once -- walking the IMAGE in order
+    // instead made 72 dependent scattered reads per thread, half of the launch) and scatters its two halves
+    {
+        const int tb = threadIdx.x & 63, ta = threadIdx.x >> 6;
+        const float bv = b && threadIdx.x < 64 && (int)threadIdx.x < U ? b[threadIdx.x] : 0.0f;   // in flight with the weights
+        float wv[9][4];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                const int ra = 16 * a4 + ta;
+                wv[tap][a4] = ra < U && tb < U ? K9[(int64_t)tap * U * U + ra * U + tb] : 0.0f;
+            }
+        _Float16* ih = reinterpret_cast<_Float16*>(img);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                const int ra = 16 * a4 + ta;
+                const int k = flip ? tb : ra, j = flip ? ra : tb;   // the image holds Wl[k][j] = flip ? W[j][k] : W[k][j]
+                const int e = tap * 8192 + (k >> 5) * 4096 + (j >> 4) * 1024 + (((k >> 2) & 3) * 16 + (j & 15)) * 8 +
+                              ((k >> 4) & 1) * 4 + (k & 3);
+                const float w = wv[tap][a4];
+                const _Float16 hi = (_Float16)w;
+                ih[e] = hi;
+                ih[e + 512] = (_Float16)((w - (float)hi) * QB_LO_SCALE);
+            }
+        if (threadIdx.x < 64) bias[threadIdx.x] = bv;
     }
-    if (threadIdx.x < 64) bias[threadIdx.x] = (b && (int)threadIdx.x < U) ? b[threadIdx.x] : 0.0f;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
     const int64_t ntile = (N + 15) / 16;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (uint32_t)(N * 256), 0x00020000);
+    uint32_t col[4];   // byte offset of this lane's quarter q of a row (units 16 q + 4 g ..), outside for padding units
+#pragma unroll
+    for (int q = 0; q < 4; ++q) col[q] = 16 * q + 4 * g < U ? 4u * (16 * q + 4 * g) : kOutside;
+    const float in_floor = act & ACT_RELU_IN ? 0.0f : -INFINITY;   // relu on the rows as they arrive, or nothing
     for (int64_t tile = (int64_t)blockIdx.x * 16 + wave; tile < ntile; tile += (int64_t)gridDim.x * 16) {
         const int64_t v = tile * 16 + i;
         const bool ok = v < N;
@@ -858,26 +898,36 @@ __global__ __launch_bounds__(1024) void conv9h_kernel(const float* __restrict__ 
             out[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             cross[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
-        for (int tap = 0; tap < 9; ++tap) {
+        // Rows come through a buffer resource of N x 256 bytes: a padded tap, a voxel beyond the batch or a
+        // padding column reads at an offset outside it and the hardware returns zeros -- no selects behind the
+        // loads.  The nine taps are unrolled with the next tap's four row quarters in flight during this tap's
+        // 24 MFMAs (two register sets in rotation: a copy out of an in-flight load would wait for it).
+        const uint32_t rowoff = ok ? (uint32_t)v * 256u : kOutside;
+        float4 rows[2][4];
+        bool some[2];
+        auto load_tap = [&](int tap, float4 (&w)[4], bool& any) {
             const int dx = flip ? 1 - tap / 3 : tap / 3 - 1, dy = flip ? 1 - tap % 3 : tap % 3 - 1;
             const int xx = x + dx, yy = y + dy;
-            const bool in = xx >= 0 && xx < g0.X && yy >= 0 && yy < g0.Y;
-            if (__builtin_amdgcn_ballot_w64(in) == 0) continue;  // the whole tile reads padding
-            const float* xr = X + (in ? vc + ((int64_t)dx * g0.Y + dy) * g0.Z : vc) * ldx + 4 * g;
-            float4 rows[4];
+            const bool in = ok && xx >= 0 && xx < g0.X && yy >= 0 && yy < g0.Y;
+            any = __builtin_amdgcn_ballot_w64(in) != 0;
+            const uint32_t o = in ? rowoff + (uint32_t)((dx * g0.Y + dy) * g0.Z * 256) : kOutside;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rows[q] = *reinterpret_cast<const float4*>(xr + 16 * q);
+            for (int q = 0; q < 4; ++q)   // o (a multiple of 256) | col[q] (< 256): their sum, or outside if either is
+                w[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, o | col[q], 0, 0));
+        };
+        load_tap(0, rows[0], some[0]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) load_tap(tap + 1, rows[(tap + 1) & 1], some[(tap + 1) & 1]);
+            if (!some[tap & 1]) continue;  // the whole tile reads padding
+            const float4(&rw)[4] = rows[tap & 1];
             qb::f16x8 bhi[2], blo[2];
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                float x8[8] = {rows[2 * st].x, rows[2 * st].y, rows[2 * st].z, rows[2 * st].w,
-                               rows[2 * st + 1].x, rows[2 * st + 1].y, rows[2 * st + 1].z, rows[2 * st + 1].w};
+                float x8[8] = {rw[2 * st].x, rw[2 * st].y, rw[2 * st].z, rw[2 * st].w,
+                               rw[2 * st + 1].x, rw[2 * st + 1].y, rw[2 * st + 1].z, rw[2 * st + 1].w};
 #pragma unroll
-                for (int j8 = 0; j8 < 8; ++j8) {
-                    const int k = 16 * (2 * st + (j8 >> 2)) + 4 * g + (j8 & 3);
-                    x8[j8] = in && k < U ? x8[j8] : 0.0f;
-                    if (act & ACT_RELU_IN) x8[j8] = fmaxf(x8[j8], 0.0f);
-                }
+                for (int j8 = 0; j8 < 8; ++j8) x8[j8] = max_1op(x8[j8], in_floor);
                 qb::split8<false>(x8, bhi[st], blo[st]);
             }
             const float* A = img + tap * 4096;
@@ -1067,6 +1117,52 @@ __global__ __launch_bounds__(1024) void xtd_kernel(const float* __restrict__ X, 
     }
 }
 
+// The eight waves of an xtd9 workgroup (2 row groups x 4 output quadrants) put their nine tap gradients into the
+// slabs: per tap, row group 0 writes its quadrants, row group 1 adds (fixed order), all threads store the slab.
+__device__ __forceinline__ void xtd9_store(float* __restrict__ red, float* __restrict__ partial,
+                                           const f32x4 (&acc)[9][2][2], const float (&dbsum)[2], int lane, int wave) {
+    const int g = lane >> 4, i = lane & 15;
+    const int rg = wave >> 2, qa = (wave >> 1) & 1, qc = wave & 1;
+    const int cd = 32 * qc + 2 * i;
+    float sm[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        sm[m] = dbsum[m];
+        sm[m] += __shfl_xor(sm[m], 16, 64);
+        sm[m] += __shfl_xor(sm[m], 32, 64);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            if (rg == ph) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* p = red + (32 * qa + 2 * (4 * g + r) + a) * 64 + 32 * qc + 2 * i + c;
+                            *p = ph == 0 ? acc[t][a][c][r] : *p + acc[t][a][c][r];
+                        }
+                if (qa == 0 && g == 0) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        float* p = red + 64 * 64 + cd + m;
+                        const float val = t == 0 ? sm[m] : 0.0f;
+                        *p = ph == 0 ? val : *p + val;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        float* out = partial + ((int64_t)t * gridDim.x + blockIdx.x) * (64 * 64 + 64);
+        for (int e = threadIdx.x; e < 64 * 64 + 64; e += 512) out[e] = red[e];
+        __syncthreads();
+    }
+}
+
+
 // All nine tap gradients of a 3x3x1 kernel in one pass over the rows: dK[tap] = X[nbr(., tap)]^T D.
 // A wave splits a 4-voxel step's flat index into crop coordinates once, reads its D half-row once and the
 // nine neighbour half-rows of X, and issues 36 MFMAs -- the per-step address arithmetic, which bounds the
@@ -1161,35 +1257,207 @@ __global__ __launch_bounds__(512) void xtd9_kernel(const float* __restrict__ X, 
         load(st + 2 * stride, b0);
         compute(b1);
     }
-    float sm[2];
+    xtd9_store(red, partial, acc, dbsum, lane, wave);
+}
+
+// ---- weight gradients on the bf16 matrix pipe: a float32 as three bfloat16 pieces ------------------------------
+// x = p0 + p1 + p2 EXACTLY: p0 is x with its low 16 bits cleared (8 significant bits), p1 the same of what is
+// left, p2 the rest (24 bits in all; the two subtractions are exact).  bfloat16 keeps float32's exponent, so
+// deltas that carry the loss's 1 / sum(mask) (1e-6 and below) need no scaling -- the reason this product cannot
+// use the forward's two-half f16 split, whose per-voxel scale does not factor out of a sum over voxels.  Of the
+// nine piece products the six of order <= 2 are kept:  x d ~ x0 d0 + x1 d0 + x0 d1 + x1 d1 + x0 d2 + x2 d0
+// (dropped: x1 d2 + x2 d1 + x2 d2 <= 2^-23 |x d|), accumulated in float32 by v_mfma_f32_16x16x32_bf16.  A wave's
+// MFMA takes K = 32: a lane group holds FOUR voxels x TWO pieces in its eight k slots, so three MFMAs
+//   [x0 | x0] . [d1 | d0],   [x1 | x1] . [d1 | d0],   [x2 | x0] . [d0 | d2]
+// add all six products of 16 voxels -- 48 matrix-pipe cycles where v_mfma_f32_16x16x4_f32 spends 128 on the
+// vector pipe.
+typedef uint32_t u32x4b __attribute__((ext_vector_type(4)));
+struct Bf3 {
+    uint32_t p0[2], p1[2], p2[2];   // piece p of k slots (0, 1) and (2, 3), two bfloat16 per register
+};
+__device__ __forceinline__ uint32_t bf_pack(float lo, float hi) {   // the upper halves of two float32
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+__device__ __forceinline__ void bf3_split(const float (&x)[4], Bf3& o) {
+    float r[4], c[4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        sm[m] = dbsum[m];
-        sm[m] += __shfl_xor(sm[m], 16, 64);
-        sm[m] += __shfl_xor(sm[m], 32, 64);
+    for (int j = 0; j < 4; ++j) {
+        r[j] = x[j] - __uint_as_float(__float_as_uint(x[j]) & 0xffff0000u);
+        c[j] = r[j] - __uint_as_float(__float_as_uint(r[j]) & 0xffff0000u);
     }
-    // per tap: row group 0 writes its quadrants, row group 1 adds (fixed order), all threads store the slab
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        o.p0[h] = bf_pack(x[2 * h], x[2 * h + 1]);
+        o.p1[h] = bf_pack(r[2 * h], r[2 * h + 1]);
+        o.p2[h] = bf_pack(c[2 * h], c[2 * h + 1]);
+    }
+}
+// acc += X^T D over the 16 voxels whose pieces the wave holds (x: the row operand's tile, d: the column operand's).
+// The repeated pieces sit on the row operand: the column operand's two forms are windows of six registers.
+struct Bf3Cols {
+    uint32_t q[6];   // d1 | d0 | d2
+};
+__device__ __forceinline__ void bf3_cols(const float (&d)[4], Bf3Cols& o) {
+    Bf3 t;
+    bf3_split(d, t);
+    o.q[0] = t.p1[0]; o.q[1] = t.p1[1]; o.q[2] = t.p0[0]; o.q[3] = t.p0[1]; o.q[4] = t.p2[0]; o.q[5] = t.p2[1];
+}
+__device__ __forceinline__ f32x4 bf3_mfma(const Bf3& x, const Bf3Cols& d, f32x4 acc) {
+    const qb::bf16x8 a00 = __builtin_bit_cast(qb::bf16x8, u32x4b{x.p0[0], x.p0[1], x.p0[0], x.p0[1]});
+    const qb::bf16x8 a11 = __builtin_bit_cast(qb::bf16x8, u32x4b{x.p1[0], x.p1[1], x.p1[0], x.p1[1]});
+    const qb::bf16x8 a20 = __builtin_bit_cast(qb::bf16x8, u32x4b{x.p2[0], x.p2[1], x.p0[0], x.p0[1]});
+    const qb::bf16x8 b10 = __builtin_bit_cast(qb::bf16x8, u32x4b{d.q[0], d.q[1], d.q[2], d.q[3]});
+    const qb::bf16x8 b02 = __builtin_bit_cast(qb::bf16x8, u32x4b{d.q[2], d.q[3], d.q[4], d.q[5]});
+    acc = QB_MFMA_BF16(a00, b10, acc);    // x0 d1 + x0 d0
+    acc = QB_MFMA_BF16(a11, b10, acc);    // x1 d1 + x1 d0
+    return QB_MFMA_BF16(a20, b02, acc);   // x2 d0 + x0 d2
+}
+
+// xtd9_kernel on the bf16 matrix pipe, 16 voxels per step, for layers of U <= 64, U % 4 == 0 units.  A lane group takes FOUR
+// CONSECUTIVE voxels: with Z % 4 == 0 they are one z run of one (x, y) column, so a step splits one flat index
+// (32-bit multiply-high divisions), tests one neighbourhood and reads every tap's four rows off one offset
+// (256-byte strides).  Rows come through a buffer resource of N x 256 bytes: a padded tap or a step beyond the
+// batch reads at an offset outside it and the hardware returns zeros -- no selects behind the loads.
+// 512 threads = 8 waves = 2 row groups x 4 ROW tiles of the gradient: a wave owns 16 input units (lane i: unit
+// 16 qa + i, one float per tap row) against all 64 output units (lane i: units 4 i .. 4 i + 3, one float4 of
+// the delta row; column tile c = unit 4 i + c), so every tap row is split into its pieces once per workgroup and
+// the delta row once per wave and step: 52 values per step where 2 x 2 quadrants split 80.  144 accumulator
+// registers per lane.  The taps are walked with the next tap's rows (at tap 8: the next step's tap 0) in
+// flight.  Same slabs, same fixed-order reduction as xtd9_kernel.
+struct Xtd9Pos {
+    uint32_t row;   // byte offset of the four voxels' first row, or kOutside
+    unsigned in;    // bit t: tap t inside the crop
+};
+// n = q d + r for n < 2^32 / d:  m = floor(2^32 / d) + 1 overestimates the quotient by at most one
+// (d = 1: m does not fit 32 bits and magic32 returns 0, for which the quotient is n itself)
+__device__ __forceinline__ uint32_t magic32(int d) { return d > 1 ? (uint32_t)(0x100000000ull / (uint32_t)d) + 1u : 0u; }
+__device__ __forceinline__ void divmod32(uint32_t n, uint32_t d, uint32_t m, uint32_t& q, uint32_t& r) {
+    q = m ? __umulhi(n, m) : n;
+    uint32_t p = q * d;
+    if (p > n) { --q; p -= d; }
+    r = n - p;
+}
+template <bool RELU_X>
+__global__ __launch_bounds__(512) void xtd9b_kernel(const float* __restrict__ X, const float* __restrict__ D,
+                                                    float* __restrict__ partial, int64_t N, Gather gt, int U) {
+    __shared__ __align__(16) float red[64 * 64 + 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int rg = wave >> 2, qa = wave & 3;
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float dbsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // byte offsets inside a row; units beyond U (a multiple of 4) are padding nobody wrote: read outside instead
+    const bool xcol = 16 * qa + i < U;
+    const uint32_t cx = 4u * (16 * qa + i), cd = 4 * i < U ? 16u * i : kOutside;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (uint32_t)(N * 256), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(D), 0, (uint32_t)(N * 256), 0x00020000);
+    const uint32_t nvox = (uint32_t)N;
+    const uint32_t nstep = (nvox + 15u) / 16u;
+    const uint32_t stride = gridDim.x * 2u;
+    const uint32_t mZ = magic32(gt.Z), mY = magic32(gt.Y), mX = magic32(gt.X);
+    auto locate = [&](uint32_t st, Xtd9Pos& p) {
+        const uint32_t v0 = st * 16u + 4u * g;
+        const bool ok = st < nstep && v0 < nvox;   // N is a multiple of Z, Z of 4: four voxels or none
+        uint32_t q2, q3, q4, z, y, x;
+        divmod32(ok ? v0 : 0u, (uint32_t)gt.Z, mZ, q2, z);
+        divmod32(q2, (uint32_t)gt.Y, mY, q3, y);
+        divmod32(q3, (uint32_t)gt.X, mX, q4, x);
+        (void)z;
+        (void)q4;
+        const bool okx[3] = {ok && x > 0, ok, ok && (int)x + 1 < gt.X};
+        const bool oky[3] = {y > 0, true, (int)y + 1 < gt.Y};
+        p.in = 0u;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) p.in |= okx[t / 3] && oky[t % 3] ? 1u << t : 0u;
+        p.row = ok ? v0 * 256u : kOutside;
+    };
+    auto load_tap = [&](const Xtd9Pos& p, int t, float (&w)[4]) {
+        const int32_t off = ((t / 3 - 1) * gt.Y + (t % 3 - 1)) * gt.Z * 256;   // wave-uniform
+        const uint32_t o = ((p.in >> t) & 1u) && xcol ? p.row + (uint32_t)off + cx : kOutside;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, o + 256u * j, 0, 0));
+    };
+    auto load_d = [&](const Xtd9Pos& p, f32x4 (&w)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)   // row (a multiple of 1024) | cd (< 256): their sum, or outside if either is
+            w[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, (p.row | cd) + 256u * j, 0, 0));
+    };
+    // one 16-voxel step; P = which of the two tap buffers holds tap 0 (nine taps: the parity flips per step)
+    float xb[2][4];
+    f32x4 dw[4];
+    auto step = [&](auto parity, const Xtd9Pos& cur, const Xtd9Pos& nxt) {
+        constexpr int P = decltype(parity)::value;
+        Bf3Cols dp[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float dd[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dd[j] = dw[j][c];
+                dbsum[c] += dd[j];
+            }
+            bf3_cols(dd, dp[c]);
+        }
+        load_d(nxt, dw);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t < 8) load_tap(cur, t + 1, xb[(P + t + 1) & 1]);
+            else load_tap(nxt, 0, xb[(P + 9) & 1]);
+            float xa[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xa[j] = RELU_X ? relu_1op(xb[(P + t) & 1][j]) : xb[(P + t) & 1][j];
+            Bf3 xp;
+            bf3_split(xa, xp);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[t][c] = bf3_mfma(xp, dp[c], acc[t][c]);
+        }
+    };
+    Xtd9Pos p0, p1;
+    uint32_t st = blockIdx.x * 2u + rg;
+    locate(st, p0);
+    load_d(p0, dw);
+    load_tap(p0, 0, xb[0]);
+    for (; st < nstep; st += 2 * stride) {
+        locate(st + stride, p1);
+        step(std::integral_constant<int, 0>{}, p0, p1);
+        locate(st + 2 * stride, p0);
+        step(std::integral_constant<int, 1>{}, p1, p0);
+    }
+    // acc[t][c][r] of lane (g, i): input unit 16 qa + 4 g + r, output unit 4 i + c
+    float sm[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        sm[c] = dbsum[c];
+        sm[c] += __shfl_xor(sm[c], 16, 64);
+        sm[c] += __shfl_xor(sm[c], 32, 64);
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             if (rg == ph) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float* p = red + (32 * qa + 2 * (4 * g + r) + a) * 64 + 32 * qc + 2 * i + c;
-                            *p = ph == 0 ? acc[t][a][c][r] : *p + acc[t][a][c][r];
-                        }
-                if (qa == 0 && g == 0) {
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        float* p = red + 64 * 64 + cd + m;
-                        const float val = t == 0 ? sm[m] : 0.0f;
-                        *p = ph == 0 ? val : *p + val;
+                for (int r = 0; r < 4; ++r) {
+                    float4* p = reinterpret_cast<float4*>(red + (16 * qa + 4 * g + r) * 64 + 4 * i);
+                    float4 o = make_float4(acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]);
+                    if (ph == 1) {
+                        const float4 q = *p;
+                        o = make_float4(q.x + o.x, q.y + o.y, q.z + o.z, q.w + o.w);
                     }
+                    *p = o;
+                }
+                if (qa == 0 && g == 0) {
+                    float4* p = reinterpret_cast<float4*>(red + 64 * 64 + 4 * i);
+                    float4 o = t == 0 ? make_float4(sm[0], sm[1], sm[2], sm[3]) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (ph == 1) {
+                        const float4 q = *p;
+                        o = make_float4(q.x + o.x, q.y + o.y, q.z + o.z, q.w + o.w);
+                    }
+                    *p = o;
                 }
             }
             __syncthreads();
@@ -1593,7 +1861,10 @@ __global__ __launch_bounds__(kDwThreads) void block_bwd_dw_kernel(
         }
     const int64_t ntile = (N + 15) / 16;
     // (Requesting the next tile's block input two products ahead was measured and lost, 3.18 against 3.11 ms per
-    // step: with every register taken it adds spills, and the loads' latency is not what bounds this kernel.)
+    // step: with every register taken it adds spills, and the loads' latency is not what bounds this kernel.  So
+    // was moving the four weight-gradient products to the bf16 matrix pipe with xtd9b_kernel's three-piece operands,
+    // 3.03 against 2.69 ms per step: 192 MFMAs of 16 cycles replace 256 of 32, but the pieces cost 770 more vector
+    // instructions per tile and 250 bytes of scratch per lane, on a wave that has nothing to overlap them with.)
     for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntile; tile += (int64_t)gridDim.x * NW) {
         const int64_t v = tile * 16 + i;
         const bool live = v < N;
@@ -1883,7 +2154,7 @@ struct Launcher {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             const bool aligned = ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) |
                                    reinterpret_cast<uintptr_t>(mask)) & 15) == 0;
-            if (aligned && !(ctx->kernel_sel & 65536) && !(act & (ACT_GELU | ACT_GELU_IN))) {   // split-f16 matrix pipe (bit 65536 / gelu: the exact-f32 form)
+            if (aligned && U % 4 == 0 && N < (1 << 23) && !(ctx->kernel_sel & 65536) && !(act & (ACT_GELU | ACT_GELU_IN))) {   // split-f16 matrix pipe (bit 65536 / gelu / odd widths: the exact-f32 form)
                 const size_t smh = sizeof(float) * (9 * 4096 + 64);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9h_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smh);
@@ -1948,8 +2219,17 @@ struct Launcher {
     // all nine taps of a 3x3x1 kernel gradient in two launches: dK[tap] = X[nbr(., tap)]^T D, db = sum D
     void xtd9(const float* X, int U, const float* D, float* partial, int nblk, float* dK9, float* db,
               const qbold_geometry& gm, int relu_x = 0) const {
-        hipLaunchKernelGGL(xtd9_kernel, dim3(nblk), dim3(512), 0, s, X, kLd, U, D, kLd, U, partial, N,
-                           make_gather(gm.X, gm.Y, gm.Z, 0, 0), relu_x);
+        // bf16 matrix pipe (three-piece operands): crops whose lane groups' four voxels are one z run
+        // (bit 524288 of the kernel selection: the exact-f32 kernel)
+        const bool pieces = U <= 64 && U % 4 == 0 && gm.Z % 4 == 0 && N % 4 == 0 && N >= 4 && N < (1 << 23) &&
+                            gm.X <= 512 && gm.Y <= 512 && gm.Z <= 512 && !(ctx->kernel_sel & 524288) &&
+                            ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D)) & 7) == 0;
+        if (pieces)
+            hipLaunchKernelGGL(relu_x ? xtd9b_kernel<true> : xtd9b_kernel<false>, dim3(nblk), dim3(512), 0, s, X, D,
+                               partial, N, make_gather(gm.X, gm.Y, gm.Z, 0, 0), U);
+        else
+            hipLaunchKernelGGL(xtd9_kernel, dim3(nblk), dim3(512), 0, s, X, kLd, U, D, kLd, U, partial, N,
+                               make_gather(gm.X, gm.Y, gm.Z, 0, 0), relu_x);
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64, 9), dim3(1024), 0, s, partial,
                            nblk, dK9, U, U, U, db, 0, 0);
     }

@@ -24,10 +24,13 @@ def main():
     ap.add_argument("--K", type=int, default=70)
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--only", choices=["voxel", "crop"], default=None)
+    ap.add_argument("--ksel", type=int, default=0, help="qbold_ctx_set_kernel_selection mask (QBOLD_KSEL_* of include/qbold_hip.h)")
     a = ap.parse_args()
     os.chdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     params = get_params("config")
     ctx = Context(params, True, True)
+    if a.ksel:
+        ctx.set_kernel_selection(a.ksel)
     w = init_encoder_weights(T=ctx.T, U=60, L=2, channelwise_gating=True, resid_init_std=0.05,
                              im_loss_sigma=0.05, seed=1, spatial_taps=9)
     ew = EncoderWeights(ctx, ctx.T, 60, 2, True, -3.0, spatial_taps=9).set_from_arrays(w)

@@ -589,3 +589,4 @@ def test_fused_training_kernels_over_widths_and_batch_sizes(params, monkeypatch)
                 a, b = g0[off:off + cnt], g1[off:off + cnt]
                 assert (a - b).abs().max() <= 3e-4 * float(a.abs().max()) + 1e-30, \
                     (U, L, N, name, l, float((a - b).abs().max()), float(a.abs().max()))
+
