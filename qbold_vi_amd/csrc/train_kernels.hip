@@ -1322,8 +1322,8 @@ __device__ __forceinline__ f32x4 bf3_mfma(const Bf3& x, const Bf3Cols& d, f32x4 
 // 16 qa + i, one float per tap row) against all 64 output units (lane i: units 4 i .. 4 i + 3, one float4 of
 // the delta row; column tile c = unit 4 i + c), so every tap row is split into its pieces once per workgroup and
 // the delta row once per wave and step: 52 values per step where 2 x 2 quadrants split 80.  144 accumulator
-// registers per lane.  The taps are walked with the next tap's rows (at tap 8: the next step's tap 0) in
-// flight.  Same slabs, same fixed-order reduction as xtd9_kernel.
+// registers per lane.  The taps are walked with the rows of the next two taps in flight.  Same slabs, same
+// fixed-order reduction as xtd9_kernel.
 struct Xtd9Pos {
     uint32_t row;   // byte offset of the four voxels' first row, or kOutside
     unsigned in;    // bit t: tap t inside the crop
@@ -1386,11 +1386,12 @@ __global__ __launch_bounds__(512) void xtd9b_kernel(const float* __restrict__ X,
         for (int j = 0; j < 4; ++j)   // row (a multiple of 1024) | cd (< 256): their sum, or outside if either is
             w[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, (p.row | cd) + 256u * j, 0, 0));
     };
-    // one 16-voxel step; P = which of the two tap buffers holds tap 0 (nine taps: the parity flips per step)
-    float xb[2][4];
+    // one 16-voxel step.  The tap rows travel through a ring of three register sets, two taps ahead of their use (at
+    // the end of a step: the next step's first two taps); nine taps: tap t always sits in set t % 3.
+    constexpr int kXtdAhead = 2;
+    float xb[3][4];
     f32x4 dw[4];
-    auto step = [&](auto parity, const Xtd9Pos& cur, const Xtd9Pos& nxt) {
-        constexpr int P = decltype(parity)::value;
+    auto step = [&](const Xtd9Pos& cur, const Xtd9Pos& nxt) {
         Bf3Cols dp[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1405,11 +1406,11 @@ __global__ __launch_bounds__(512) void xtd9b_kernel(const float* __restrict__ X,
         load_d(nxt, dw);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            if (t < 8) load_tap(cur, t + 1, xb[(P + t + 1) & 1]);
-            else load_tap(nxt, 0, xb[(P + 9) & 1]);
+            if (t + kXtdAhead < 9) load_tap(cur, t + kXtdAhead, xb[(t + kXtdAhead) % 3]);
+            else load_tap(nxt, t + kXtdAhead - 9, xb[(t + kXtdAhead) % 3]);
             float xa[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xa[j] = RELU_X ? relu_1op(xb[(P + t) & 1][j]) : xb[(P + t) & 1][j];
+            for (int j = 0; j < 4; ++j) xa[j] = RELU_X ? relu_1op(xb[t % 3][j]) : xb[t % 3][j];
             Bf3 xp;
             bf3_split(xa, xp);
 #pragma unroll
@@ -1420,12 +1421,13 @@ __global__ __launch_bounds__(512) void xtd9b_kernel(const float* __restrict__ X,
     uint32_t st = blockIdx.x * 2u + rg;
     locate(st, p0);
     load_d(p0, dw);
-    load_tap(p0, 0, xb[0]);
-    for (; st < nstep; st += 2 * stride) {
+#pragma unroll
+    for (int t = 0; t < kXtdAhead; ++t) load_tap(p0, t, xb[t]);
+    for (; st < nstep; st += 2 * stride) {   // two steps per trip: the positions alternate without a copy
         locate(st + stride, p1);
-        step(std::integral_constant<int, 0>{}, p0, p1);
+        step(p0, p1);
         locate(st + 2 * stride, p0);
-        step(std::integral_constant<int, 1>{}, p1, p0);
+        step(p1, p0);
     }
     // acc[t][c][r] of lane (g, i): input unit 16 qa + 4 g + r, output unit 4 i + c
     float sm[4];
@@ -1465,6 +1467,96 @@ __global__ __launch_bounds__(512) void xtd9b_kernel(const float* __restrict__ X,
         float* out = partial + ((int64_t)t * gridDim.x + blockIdx.x) * (64 * 64 + 64);
         for (int e = threadIdx.x; e < 64 * 64 + 64; e += 512) out[e] = red[e];
         __syncthreads();
+    }
+}
+
+// xtd_kernel on the bf16 matrix pipe (three-piece operands), 16 voxels per step: [N][64] row tensors without a
+// gather, kdim and ndim multiples of 4.  512 threads = 8 waves, each accumulating the whole 64 x 64 product over
+// its share of the steps; a lane group reads four consecutive rows of X and of D as float4 (tile m of lane i =
+// column 4 i + m, as xtd_kernel's aligned form), through buffer resources of N x 256 bytes: rows beyond the batch
+// and padding columns read as zeros without a select.  Eight 16-byte loads per lane are in flight per step where
+// the f32 form has two per 4-voxel step -- at crop-batch sizes (190 k rows) that latency, not the MFMAs, was the
+// kernel's time.  Slabs and their fixed-order sum as xtd_kernel (one 16 KiB tile per wave, added in wave order).
+template <bool RELU_X>
+__global__ __launch_bounds__(512) void xtdb_kernel(const float* __restrict__ X, int kdim, const float* __restrict__ D,
+                                                   int ndim, float* __restrict__ partial, int64_t N) {
+    extern __shared__ float red8[];  // [kXtdTiles][64 * 64 + 64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float dbsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (uint32_t)(N * 256), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(D), 0, (uint32_t)(N * 256), 0x00020000);
+    const uint32_t colx = 4 * i < kdim ? 16u * i : kOutside, cold = 4 * i < ndim ? 16u * i : kOutside;
+    const uint32_t nstep = ((uint32_t)N + 15u) / 16u;
+    const uint32_t stride = gridDim.x * 8u;
+    struct Raw {
+        f32x4 x[4], d[4];
+    };
+    auto load = [&](uint32_t st, Raw& w) {   // a step beyond the batch reads beyond the buffers (N < 2^23: no wrap)
+        const uint32_t row = (st * 16u + 4u * g) * 256u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w.x[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, row + colx + 256u * j, 0, 0));
+            w.d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, row + cold + 256u * j, 0, 0));
+        }
+    };
+    auto compute = [&](const Raw& w) {
+        Bf3 xp[4];
+        Bf3Cols dp[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float xa[4], dd[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xa[j] = RELU_X ? relu_1op(w.x[j][m]) : w.x[j][m];
+                dd[j] = w.d[j][m];
+                dbsum[m] += dd[j];
+            }
+            bf3_split(xa, xp[m]);
+            bf3_cols(dd, dp[m]);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] = bf3_mfma(xp[a], dp[c], acc[a][c]);
+    };
+    Raw b0, b1;   // two sets in rotation, the loop unrolled by two (see xtd_kernel)
+    uint32_t st = blockIdx.x * 8u + wave;
+    load(st, b0);
+    for (; st < nstep; st += 2 * stride) {
+        load(st + stride, b1);
+        compute(b0);
+        load(st + 2 * stride, b0);
+        compute(b1);
+    }
+    // acc[a][c][r] of lane (g, i): row 4 (4 g + r) + a, column 4 i + c
+    float* red = red8 + wave * (64 * 64 + 64);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float4*>(red + (4 * (4 * g + r) + a) * 64 + 4 * i) =
+                make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
+    float sm[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        sm[m] = dbsum[m];
+        sm[m] += __shfl_xor(sm[m], 16, 64);
+        sm[m] += __shfl_xor(sm[m], 32, 64);
+    }
+    if (g == 0) *reinterpret_cast<float4*>(red + 64 * 64 + 4 * i) = make_float4(sm[0], sm[1], sm[2], sm[3]);
+    __syncthreads();
+    float* out = partial + (int64_t)blockIdx.x * (64 * 64 + 64);
+    for (int e = threadIdx.x; e < 64 * 64 + 64; e += 512) {
+        float t[kXtdTiles];
+#pragma unroll
+        for (int b = 0; b < kXtdTiles; ++b) t[b] = red8[b * (64 * 64 + 64) + e];
+        out[e] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     }
 }
 
@@ -2193,17 +2285,38 @@ struct Launcher {
                 const bool vec = (ld & 3) == 0 &&
                                  ((reinterpret_cast<uintptr_t>(Xa) | reinterpret_cast<uintptr_t>(Dc) |
                                    reinterpret_cast<uintptr_t>(Rc)) & 15) == 0;
-                auto kern = vec ? xtd_kernel<true> : xtd_kernel<false>;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXtdSmem);
-                hipLaunchKernelGGL(kern, dim3(nblk), dim3(1024), kXtdSmem, s, Xa, ld, ka, Dc, ld, nc, partial, N,
-                                   gather, relu_x, Rc);
+                if (pieces_ok(Xa, ka, Dc, nc, Rc)) {
+                    launch_xtdb(Xa, ka, Dc, nc, partial, nblk, relu_x);
+                } else {
+                    auto kern = vec ? xtd_kernel<true> : xtd_kernel<false>;
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXtdSmem);
+                    hipLaunchKernelGGL(kern, dim3(nblk), dim3(1024), kXtdSmem, s, Xa, ld, ka, Dc, ld, nc, partial, N,
+                                       gather, relu_x, Rc);
+                }
                 hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64), dim3(1024), 0, s, partial,
                                    nblk, dW + (int64_t)a * ldw + c, ldw, ka, nc, a == 0 && db ? db + c : nullptr, accum, 0);
             }
     }
     // one 64 x 64 slab (kdim, ndim <= 64) without its reduction, and the reduction of columns j0 .. of a slab
+    // the bf16 matrix pipe's form (xtdb_kernel): aligned [N][64] rows, no gather, no relu-masked delta, widths that are
+    // multiples of 4 (bit 524288 of the kernel selection: the exact-f32 kernel)
+    bool pieces_ok(const float* X, int kdim, const float* D, int ndim, const float* dref) const {
+        return ld == kLd && gather.Z == 0 && !dref && kdim % 4 == 0 && ndim % 4 == 0 && kdim <= 64 && ndim <= 64 &&
+               N < (1 << 23) && !(ctx->kernel_sel & 524288) &&
+               ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D)) & 15) == 0;
+    }
+    void launch_xtdb(const float* X, int kdim, const float* D, int ndim, float* partial, int nblk, int relu_x) const {
+        auto kern = relu_x ? xtdb_kernel<true> : xtdb_kernel<false>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)kXtdSmem);
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), kXtdSmem, s, X, kdim, D, ndim, partial, N);
+    }
     void xtd_only(const float* X, int kdim, const float* D, int ndim, float* partial, int nblk) const {
+        if (pieces_ok(X, kdim, D, ndim, nullptr)) {
+            launch_xtdb(X, kdim, D, ndim, partial, nblk, 0);
+            return;
+        }
         const bool vec = (ld & 3) == 0 &&
                          ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D)) & 15) == 0;
         auto kern = vec ? xtd_kernel<true> : xtd_kernel<false>;
