@@ -1477,9 +1477,10 @@ __global__ __launch_bounds__(512) void xtd9b_kernel(const float* __restrict__ X,
 // and padding columns read as zeros without a select.  Eight 16-byte loads per lane are in flight per step where
 // the f32 form has two per 4-voxel step -- at crop-batch sizes (190 k rows) that latency, not the MFMAs, was the
 // kernel's time.  Slabs and their fixed-order sum as xtd_kernel (one 16 KiB tile per wave, added in wave order).
-template <bool RELU_X>
+template <bool RELU_X, bool DREF>   // DREF: D is taken as D * (Dref > 0), the step through a relu folded into the load
 __global__ __launch_bounds__(512) void xtdb_kernel(const float* __restrict__ X, int kdim, const float* __restrict__ D,
-                                                   int ndim, float* __restrict__ partial, int64_t N) {
+                                                   int ndim, float* __restrict__ partial, int64_t N,
+                                                   const float* __restrict__ Dref) {
     extern __shared__ float red8[];  // [kXtdTiles][64 * 64 + 64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -1494,8 +1495,9 @@ __global__ __launch_bounds__(512) void xtdb_kernel(const float* __restrict__ X, 
     const uint32_t colx = 4 * i < kdim ? 16u * i : kOutside, cold = 4 * i < ndim ? 16u * i : kOutside;
     const uint32_t nstep = ((uint32_t)N + 15u) / 16u;
     const uint32_t stride = gridDim.x * 8u;
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DREF ? Dref : D), 0, (uint32_t)(N * 256), 0x00020000);
     struct Raw {
-        f32x4 x[4], d[4];
+        f32x4 x[4], d[4], r[DREF ? 4 : 1];
     };
     auto load = [&](uint32_t st, Raw& w) {   // a step beyond the batch reads beyond the buffers (N < 2^23: no wrap)
         const uint32_t row = (st * 16u + 4u * g) * 256u;
@@ -1503,6 +1505,7 @@ __global__ __launch_bounds__(512) void xtdb_kernel(const float* __restrict__ X, 
         for (int j = 0; j < 4; ++j) {
             w.x[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, row + colx + 256u * j, 0, 0));
             w.d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, row + cold + 256u * j, 0, 0));
+            if (DREF) w.r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, row + cold + 256u * j, 0, 0));
         }
     };
     auto compute = [&](const Raw& w) {
@@ -1514,7 +1517,7 @@ __global__ __launch_bounds__(512) void xtdb_kernel(const float* __restrict__ X, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 xa[j] = RELU_X ? relu_1op(w.x[j][m]) : w.x[j][m];
-                dd[j] = w.d[j][m];
+                dd[j] = DREF ? (w.r[j][m] > 0.0f ? w.d[j][m] : 0.0f) : w.d[j][m];
                 dbsum[m] += dd[j];
             }
             bf3_split(xa, xp[m]);
@@ -2274,8 +2277,9 @@ struct Launcher {
         (void)xw_ld(X, ldx, kdim, W, ldw, trans, b, Y, ld, ndim, act, accum, mask);
     }
     // dW (+)= X^T D, db (+)= sum D: 64 x 64 slabs of the (kdim x ndim) product, one launch pair per slab
+    // kzero > kdim: columns kdim .. kzero - 1 of X are known to hold zeros (a reader may take them along)
     void xtd(const float* X, int kdim, const float* D, int ndim, float* partial, int nblk, float* dW,
-             int ldw, float* db, int accum, int relu_x = 0, const float* dref = nullptr) const {
+             int ldw, float* db, int accum, int relu_x = 0, const float* dref = nullptr, int kzero = 0) const {
         for (int a = 0; a < kdim; a += 64)
             for (int c = 0; c < ndim; c += 64) {
                 const int ka = kdim - a < 64 ? kdim - a : 64, nc = ndim - c < 64 ? ndim - c : 64;
@@ -2285,8 +2289,9 @@ struct Launcher {
                 const bool vec = (ld & 3) == 0 &&
                                  ((reinterpret_cast<uintptr_t>(Xa) | reinterpret_cast<uintptr_t>(Dc) |
                                    reinterpret_cast<uintptr_t>(Rc)) & 15) == 0;
-                if (pieces_ok(Xa, ka, Dc, nc, Rc)) {
-                    launch_xtdb(Xa, ka, Dc, nc, partial, nblk, relu_x);
+                const int kread = kzero > kdim && kdim <= 64 ? (kzero < 64 ? kzero : 64) : ka;
+                if (pieces_ok(Xa, kread, Dc, nc, Rc)) {
+                    launch_xtdb(Xa, kread, Dc, nc, partial, nblk, relu_x, Rc);
                 } else {
                     auto kern = vec ? xtd_kernel<true> : xtd_kernel<false>;
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -2299,22 +2304,24 @@ struct Launcher {
             }
     }
     // one 64 x 64 slab (kdim, ndim <= 64) without its reduction, and the reduction of columns j0 .. of a slab
-    // the bf16 matrix pipe's form (xtdb_kernel): aligned [N][64] rows, no gather, no relu-masked delta, widths that are
-    // multiples of 4 (bit 524288 of the kernel selection: the exact-f32 kernel)
+    // the bf16 matrix pipe's form (xtdb_kernel): aligned [N][64] rows, no gather, widths that are multiples of 4
+    // (bit 524288 of the kernel selection: the exact-f32 kernel)
     bool pieces_ok(const float* X, int kdim, const float* D, int ndim, const float* dref) const {
-        return ld == kLd && gather.Z == 0 && !dref && kdim % 4 == 0 && ndim % 4 == 0 && kdim <= 64 && ndim <= 64 &&
+        return ld == kLd && gather.Z == 0 && kdim % 4 == 0 && ndim % 4 == 0 && kdim <= 64 && ndim <= 64 &&
                N < (1 << 23) && !(ctx->kernel_sel & 524288) &&
-               ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D)) & 15) == 0;
+               ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D) | reinterpret_cast<uintptr_t>(dref)) & 15) == 0;
     }
-    void launch_xtdb(const float* X, int kdim, const float* D, int ndim, float* partial, int nblk, int relu_x) const {
-        auto kern = relu_x ? xtdb_kernel<true> : xtdb_kernel<false>;
+    void launch_xtdb(const float* X, int kdim, const float* D, int ndim, float* partial, int nblk, int relu_x,
+                     const float* dref) const {
+        auto kern = dref ? (relu_x ? xtdb_kernel<true, true> : xtdb_kernel<false, true>)
+                         : (relu_x ? xtdb_kernel<true, false> : xtdb_kernel<false, false>);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)kXtdSmem);
-        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), kXtdSmem, s, X, kdim, D, ndim, partial, N);
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), kXtdSmem, s, X, kdim, D, ndim, partial, N, dref);
     }
     void xtd_only(const float* X, int kdim, const float* D, int ndim, float* partial, int nblk) const {
         if (pieces_ok(X, kdim, D, ndim, nullptr)) {
-            launch_xtdb(X, kdim, D, ndim, partial, nblk, 0);
+            launch_xtdb(X, kdim, D, ndim, partial, nblk, 0, nullptr);
             return;
         }
         const bool vec = (ld & 3) == 0 &&
@@ -2783,8 +2790,11 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             }
         }
     }
-    // first layer: delta_pre = dB * (h > 0); dW0 = n^T delta_pre
-    k.xtd(slot(0), T, dB, U, partial, slabs, grad + c.W0, U, grad + c.b0, 0, 0, slot(1));
+    // first layer: delta_pre = dB * (h > 0); dW0 = n^T delta_pre.  Columns T .. of n are zero up to the next multiple
+    // of 4 (normalise64_kernel, encoder_train_fwd_kernel): the reader may take whole float4s.
+    // (Having block 0's one-launch backward apply the mask it holds anyway was measured and lost: 16 selects more and
+    // the 512-register kernel spills 336 bytes per lane instead of 44, 1.00 ms against 0.78.)
+    k.xtd(slot(0), T, dB, U, partial, slabs, grad + c.W0, U, grad + c.b0, 0, 0, slot(1), (T + 3) & ~3);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }
