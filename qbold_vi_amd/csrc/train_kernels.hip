@@ -1607,6 +1607,130 @@ __global__ void stack_heads_kernel(const float* __restrict__ Wf, const float* __
     Wst[e] = k < 5 ? Wf[j * 5 + k] : Ws[j * T + (k - 5)];
 }
 
+// Both heads' backward in one pass over the rows, for 5 + T <= 16 head outputs and U % 4 == 0 units:
+//   d last = [g_q | g_ls] / sum(mask) . [Wf^T; Ws^T]      and      d[Wf | Ws] = last^T [g_q | g_ls] / sum(mask),
+// which the layer-wise form runs as head_delta_kernel + stack_heads_kernel + a GEMM + a weight-gradient pass: the
+// 16-column delta tensor written and read twice, `last` read once more.  Here a wave takes 16 voxels per tile and reads
+// the two head gradients straight from g_q / g_ls (twice, in the two operand layouts: 64 bytes per voxel, cache
+// hits), `last` once, and writes d last: 0.6 GB per million voxels instead of 1.2.  Exact float32 products
+// (v_mfma_f32_16x16x4_f32: K = 16 head outputs one way, 16 voxels the other -- 32 MFMAs per tile, far below the
+// memory time).  The weight gradients leave as one xtd-format slab per workgroup ([unit][64] + 64 bias sums, of
+// which columns 0 .. 15 are written), summed by slab_reduce_kernel in a fixed order like every other slab.
+__global__ __launch_bounds__(512) void heads_bwd_kernel(const float* __restrict__ g_q, const float* __restrict__ g_ls,
+                                                         int T, const double* __restrict__ sums,
+                                                         const float* __restrict__ last, const float* __restrict__ Wf,
+                                                         const float* __restrict__ Ws, int U, float* __restrict__ d_last,
+                                                         float* __restrict__ partial, int64_t N) {
+    constexpr int kTile = 64 * 16 + 16;   // one wave's [unit][16] gradients + 16 bias sums
+    __shared__ float red[8][kTile];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const float scale = sums ? (float)(1.0 / sums[2]) : 1.0f;   // 1 / sum(mask)
+    const int H = 5 + T;
+    // stacked head weights as the row operand of d last^T = Wst^T dA^T: unit 16 t + i, head output 4 s + g
+    float wst[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int u = 16 * t + i, k = 4 * s4 + g;
+            wst[t][s4] = u < U ? (k < 5 ? Wf[u * 5 + k] : (k < H ? Ws[u * T + k - 5] : 0.0f)) : 0.0f;
+        }
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(last), 0, (uint32_t)(N * 256), 0x00020000);
+    const uint32_t coll = 4 * i < U ? 16u * i : kOutside;
+    // head output k of voxel v: g_q[5 v + k] or g_ls[T v + k - 5], zero beyond 5 + T and beyond the batch -- one load
+    // from each array through a buffer resource, the one that does not apply at an offset outside it (returns 0):
+    // no branch around a load, all of a tile's loads in flight together
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g_q), 0, (uint32_t)(N * 20), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g_ls), 0, (uint32_t)(N * 4 * T), 0x00020000);
+    auto col_q = [&](int k) { return k < 5 ? 4u * k : kOutside; };
+    auto col_s = [&](int k) { return k >= 5 && k < H ? 4u * (k - 5) : kOutside; };
+    uint32_t q1[4], s1[4];   // columns 4 s + g (the data product's operand)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        q1[s4] = col_q(4 * s4 + g);
+        s1[s4] = col_s(4 * s4 + g);
+    }
+    const uint32_t q2 = col_q(i), s2 = col_s(i);   // column i (the gradient product's operand)
+    const uint32_t rowq = 20u, rows = 4u * T;
+    auto delta = [&](uint32_t v, uint32_t cq, uint32_t cs) {   // v < 2^23 + 2^16: no 32-bit wrap, rows beyond N are outside
+        const float a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rq, v * rowq + cq, 0, 0));
+        const float b = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, v * rows + cs, 0, 0));
+        return a + b;
+    };
+    f32x4 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float dbsum = 0.0f;
+    struct Raw {
+        float d1[4], d2[4];   // the delta as column operand of the data product (voxel i, output 4 s + g) and of the
+        f32x4 x[4];           // gradient product (voxel 4 s + g, output i); last rows 4 s + g, units 4 i ..
+    };
+    auto load = [&](int64_t tile, Raw& w) {
+        const uint32_t v0 = (uint32_t)tile * 16u;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            w.d1[s4] = delta(v0 + i, q1[s4], s1[s4]);
+            w.d2[s4] = delta(v0 + 4 * s4 + g, q2, s2);
+            // (rows beyond the batch are beyond the buffer)
+            w.x[s4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, (v0 + 4 * s4 + g) * 256u + coll, 0, 0));
+        }
+    };
+    const int64_t ntile = (N + 15) / 16;
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    auto compute = [&](int64_t tile, const Raw& w) {
+        // d last^T [unit][voxel]
+        f32x4 o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            o[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) o[t] = QB_MFMA16F(wst[t][s4], w.d1[s4] * scale, o[t]);
+        }
+        const int64_t v = tile * 16 + i;
+        if (v < N) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)   // o[t][r]: unit 16 t + 4 g + r of voxel i
+                *reinterpret_cast<float4*>(d_last + v * 64 + 16 * t + 4 * g) = make_float4(o[t][0], o[t][1], o[t][2], o[t][3]);
+        }
+        // d [Wf | Ws][unit][output] += last^T delta over the tile's voxels
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float d2 = w.d2[s4] * scale;
+            dbsum += d2;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(w.x[s4][m], d2, acc[m]);
+        }
+    };
+    Raw b0, b1;   // two sets in rotation, the loop unrolled by two (see xtd_kernel)
+    int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+    load(tile < ntile ? tile : ntile, b0);
+    for (; tile < ntile; tile += 2 * stride) {
+        load(tile + stride, b1);
+        compute(tile, b0);
+        load(tile + 2 * stride, b0);
+        if (tile + stride < ntile) compute(tile + stride, b1);
+    }
+    // acc[m][r] of lane (g, i): unit 4 (4 g + r) + m, head output i.  One 4 KiB tile per wave, added in wave order.
+    dbsum += __shfl_xor(dbsum, 16, 64);
+    dbsum += __shfl_xor(dbsum, 32, 64);
+    float* tl = red[wave];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tl[(4 * (4 * g + r) + m) * 16 + i] = acc[m][r];
+    if (g == 0) tl[64 * 16 + i] = dbsum;
+    __syncthreads();
+    float* out = partial + (int64_t)blockIdx.x * (64 * 64 + 64);
+    for (int e = threadIdx.x; e < kTile; e += 512) {
+        float t8[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) t8[b] = red[b][e];
+        const float sum = ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
+        out[e < 64 * 16 ? (e >> 4) * 64 + (e & 15) : 64 * 64 + (e - 64 * 16)] = sum;
+    }
+}
+
 // normalise_data into a [N][64] slot (model.py:97-113)
 __global__ void normalise64_kernel(QbDev c, const float* __restrict__ x, float* __restrict__ out,
                                    int ld, int64_t N) {
@@ -2639,9 +2763,6 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
           *dE = slot(base + 4);
     float* partial = ws + (int64_t)(base + 5) * N * ld;
     QB_HIP(hipMemsetAsync(grad, 0, sizeof(float) * c.total, k.s));
-    // head delta [N][64]: cols 0-4 = g_q, 5.. = g_ls, scaled by 1 / sum(mask)
-    hipLaunchKernelGGL(head_delta_kernel, dim3(k.ew()), dim3(256), 0, k.s, g_q,
-                       stream_sel == 2 ? g_ls : nullptr, T, sums, dA, ld, N);
     const float* last = stream_sel == 1 ? slot(2 + L - 1) : slot(6 + 5 * (L - 1));
     // dWf, dbf (and dWs, dbs), d_last = g_q Wf^T (+ g_ls Ws^T)
     // xtd slabs per launch: whole rounds of two 1024-thread blocks per CU, about 1024 voxels per block
@@ -2657,7 +2778,19 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     // the nine-tap kernel runs one 512-thread block per CU (144 accumulator registers per lane)
     const int slabs9 = (int)((N + 511) / 512 < ctx->num_cus ? ((N + 511) / 512 > 0 ? (N + 511) / 512 : 1)
                                                            : (ctx->num_cus < kSlabBlocks ? ctx->num_cus : kSlabBlocks));
-    if (stream_sel == 2 && g_ls && U <= 64 && ld == kLd && 5 + T <= 64 && !(ctx->kernel_sel & 16384)) {
+    const bool heads_one_pass = stream_sel == 2 && g_ls && U <= 64 && U % 4 == 0 && ld == kLd && 5 + T <= 16 &&
+                                N < (1 << 23) && !(ctx->kernel_sel & (16384 | 1048576)) &&
+                                ((reinterpret_cast<uintptr_t>(last) | reinterpret_cast<uintptr_t>(dB)) & 15) == 0;
+    if (!heads_one_pass)   // head delta [N][64]: cols 0-4 = g_q, 5.. = g_ls, scaled by 1 / sum(mask)
+        hipLaunchKernelGGL(head_delta_kernel, dim3(k.ew()), dim3(256), 0, k.s, g_q,
+                           stream_sel == 2 ? g_ls : nullptr, T, sums, dA, ld, N);
+    if (heads_one_pass) {
+        // both heads' data and weight gradients in one pass over the rows (heads_bwd_kernel): no delta tensor
+        hipLaunchKernelGGL(heads_bwd_kernel, dim3(slabs), dim3(512), 0, k.s, g_q, g_ls, T, sums, last, w + c.Wf, w + c.Ws,
+                           U, dB, partial, N);
+        k.reduce_cols(partial, slabs, grad + c.Wf, 5, U, 5, grad + c.bf, 0);
+        k.reduce_cols(partial, slabs, grad + c.Ws, T, U, T, grad + c.bs, 5);
+    } else if (stream_sel == 2 && g_ls && U <= 64 && ld == kLd && 5 + T <= 64 && !(ctx->kernel_sel & 16384)) {
         // both heads at once: one weight-gradient pass over the 5 + T delta columns (slab columns 0-4 -> Wf,
         // 5 .. -> Ws) and one backward-data GEMM with the stacked weights [Wf^T; Ws^T] -- instead of two
         // passes each, one of them over the unaligned column block dA + 5

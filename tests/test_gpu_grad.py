@@ -526,8 +526,9 @@ def test_one_launch_training_forward_and_block_backward(params, T, L, taps, monk
     out = {}
     for fused in (False, True):
         ctx = Context(p, True, True)
-        # QBOLD_KSEL_LAYERWISE_BWD = 131072: the layer-wise backward (gate_bwd_kernel + xw64 launches)
-        ctx.set_kernel_selection(0 if fused else 131072)
+        # QBOLD_KSEL_LAYERWISE_BWD = 131072: the layer-wise backward (gate_bwd_kernel + xw64 launches);
+        # QBOLD_KSEL_HEADS_BWD_LAYERWISE = 1048576: the heads' backward through a delta tensor
+        ctx.set_kernel_selection(0 if fused else 131072 | 1048576)
         ew = EncoderWeights(ctx, T, U, L, True, -3.0, spatial_taps=taps).set_from_arrays(w)
         st = TrainState(ctx, ew)
         st.fused_forward = fused
@@ -572,7 +573,7 @@ def test_fused_training_kernels_over_widths_and_batch_sizes(params, monkeypatch)
         out = {}
         for fused in (False, True):
             ctx = Context(params, True, True)
-            ctx.set_kernel_selection(0 if fused else 131072)   # QBOLD_KSEL_LAYERWISE_BWD
+            ctx.set_kernel_selection(0 if fused else 131072 | 1048576)   # QBOLD_KSEL_LAYERWISE_BWD | _HEADS_BWD_LAYERWISE
             ew = EncoderWeights(ctx, 11, U, L, True, -3.0).set_from_arrays(w)
             st = TrainState(ctx, ew)
             st.fused_forward = fused
