@@ -683,6 +683,18 @@ def main():
                                    "step_frac": r["step"]["frac"]}}
                 del vm
             m = {"w": w_headline, "params": params_headline}
+            # one fine-tuning step (forward with saved activations, ELBO backward, encoder backward, AdamW) on a
+            # 1 M-voxel batch and on the reference's 38 x 25 x 25 x 8 crop batch: SURVEY rows N2 / N1, timed by
+            # scripts/bench_train.py's own loop (150 ms ramp, HIP events)
+            torch.cuda.empty_cache()
+            try:
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts"))
+                import bench_train
+                line["training_step"] = bench_train.measure(
+                    steps=20, S=1, K=70,   # the reference's training defaults (mc_samples 1, 70 KL draws)
+                    config_dir=os.path.join(os.path.dirname(os.path.abspath(__file__)), "config"))
+            except Exception as e:
+                line["training_step"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(m["params"], m["w"], S, K, args.cpu_budget_s)
         print(json.dumps(line), flush=True)

@@ -15,6 +15,13 @@ from qbold_vi_amd.ops import Context, EncoderWeights, TrainState  # noqa: E402
 from qbold_vi_amd.training import get_params  # noqa: E402
 
 
+def measure(voxels=1 << 20, crops=(38, 25, 25, 8), steps=10, S=1, K=70, graph=False, only=None, ksel=0,
+            config_dir="config"):
+    """ms per fine-tuning step on a voxel batch and on a crop batch (bench.py embeds this in its JSON line)."""
+    a = argparse.Namespace(voxels=voxels, crops=list(crops), steps=steps, S=S, K=K, graph=graph, only=only, ksel=ksel)
+    return _run(a, config_dir)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--voxels", type=int, default=1 << 20)
@@ -26,8 +33,11 @@ def main():
     ap.add_argument("--only", choices=["voxel", "crop"], default=None)
     ap.add_argument("--ksel", type=int, default=0, help="qbold_ctx_set_kernel_selection mask (QBOLD_KSEL_* of include/qbold_hip.h)")
     a = ap.parse_args()
-    os.chdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-    params = get_params("config")
+    print(json.dumps(_run(a, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "config"))))
+
+
+def _run(a, config_dir):
+    params = get_params(config_dir)
     ctx = Context(params, True, True)
     if a.ksel:
         ctx.set_kernel_selection(a.ksel)
@@ -81,8 +91,7 @@ def main():
         st.adamw(5e-3, 2e-4, 0.9, 0.9, 1e-7)
 
     if a.only == "voxel":
-        print(json.dumps(out))
-        return
+        return out
     ms = timed(crop_step)
     out["crop_batch"] = dict(crops=[B, X, Y, Z], voxels=V, ms_per_step=ms, voxels_per_s=V / ms * 1e3)
     if a.graph:  # how much of the step is launch gaps: replay the same launches from a captured hipGraph
@@ -103,7 +112,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             out["crop_batch_graph_replay_ms"] = e0.elapsed_time(e1) / a.steps
-    print(json.dumps(out))
+    return out
 
 
 if __name__ == "__main__":

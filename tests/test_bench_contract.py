@@ -83,6 +83,15 @@ def check_variants(d):
     assert 0.8 < v["voxels_4194304"]["value"] / d["value"] < 1.25
 
 
+def check_training_step(d):
+    """One fine-tuning step on a voxel batch and on the reference's crop batch, timed in the default run too
+    (round 3: 2.68 -> ~2.55 ms and 2.62 -> ~1.65 ms; the bounds leave room for the slower boxes of the pool)."""
+    t = d["training_step"]
+    assert "error" not in t, t
+    assert t["voxel_batch"]["voxels"] == 1 << 20 and 0.0 < t["voxel_batch"]["ms_per_step"] < 2.9
+    assert t["crop_batch"]["crops"] == [38, 25, 25, 8] and 0.0 < t["crop_batch"]["ms_per_step"] < 1.9
+
+
 def test_committed_bench_line_keeps_the_contract():
     d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
     check_line(d, expect_cpu_baseline=True)
@@ -103,6 +112,7 @@ def test_committed_round3_line_carries_the_variants():
     assert "variants" in d and d["n_gpus"] == 1 and d["config"]["global_voxels"] == 1 << 20 and d["dtype"] == "f32"
     assert d["roofline"]["kernel"] == "vi_fwd_kernel" and d["roofline"]["bound"] == "valu-issue"
     assert d["value"] > 2.0e9                                   # round 2's driver-witnessed headline: 2.04e9
+    check_training_step(d)
     assert 0.015 < d["roofline"]["hbm"]["frac"] < 0.05          # the metric's HBM roofline: ~2 - 3 % by arithmetic
     d3 = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_config3.json")))
     check_line(d3, expect_cpu_baseline=False)
@@ -193,6 +203,7 @@ def test_driver_command_line_carries_every_variant():
     d = json.loads(lines[0])
     check_line(d, expect_cpu_baseline=True)
     assert "variants" in d and d["config"]["global_voxels"] == 1 << 20 and d["dtype"] == "f32"
+    check_training_step(d)
 
 
 @pytest.mark.gpu
