@@ -99,6 +99,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define QB_ENC_BASE_PRIO 0
 #endif
 #define QB_LO_SCALE 2048.0f
+#ifndef QB_SPLIT_MIX
+#define QB_SPLIT_MIX 1
+#endif
 #define QB_LO_UNSCALE (1.0f / 2048.0f)
 
 // Reduced-precision mode (qbold_encoder_shape.precision = QBOLD_ENC_BF16; BASELINE config 5, "bf16
@@ -118,12 +121,36 @@ __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo
         hi = __builtin_bit_cast(f16x8, b);
         lo = hi;  // unused
     } else {
+#if QB_SPLIT_MIX
+        // lo = f16((x - hi) 2^11) = f16(fma(hi, -2^11, 2^11 x)): one mixed-precision FMA per value reads the f16 hi half
+        // in place and writes the f16 lo half in place (the FMA's float32 result is exact -- hi is x rounded -- so its
+        // one rounding is the cast's; bit-identical to the three-instruction form below).  Two instructions per
+        // value (packed hi conversion, packed 2^11 x, the FMA) instead of three (conversion back, subtraction,
+        // scale, conversion) on kernels bound by vector-pipe issue.
+        typedef uint32_t u32x4s8 __attribute__((ext_vector_type(4)));
+        u32x4s8 hp, lp;
+        const float nscale = -QB_LO_SCALE;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float a = v[2 * p], b = v[2 * p + 1];
+            uint32_t h = __builtin_bit_cast(uint32_t, f16x2{(_Float16)a, (_Float16)b}), l;
+            typedef float f32x2s8 __attribute__((ext_vector_type(2)));
+            const f32x2s8 sc = f32x2s8{a, b} * QB_LO_SCALE;   // one v_pk_mul_f32
+            asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "s"(nscale), "v"(sc[0]));
+            asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "s"(nscale), "v"(sc[1]));
+            hp[p] = h;
+            lp[p] = l;
+        }
+        hi = __builtin_bit_cast(f16x8, hp);
+        lo = __builtin_bit_cast(f16x8, lp);
+#else
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const _Float16 h = (_Float16)v[j];
             hi[j] = h;
             lo[j] = (_Float16)((v[j] - (float)h) * QB_LO_SCALE);
         }
+#endif
     }
 }
 
