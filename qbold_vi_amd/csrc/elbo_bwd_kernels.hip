@@ -25,7 +25,6 @@ int elbo_grid(const qbold_ctx* ctx);
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kVoxPerBlock = kBlock / QB_LANES_PER_VOXEL;
 
 struct FwdGrad {
     float s, ds_doef, ds_ddbv;
@@ -58,7 +57,13 @@ __device__ __forceinline__ FwdGrad fwd_signal_grad(const qb::FwdLds* L, const Qb
     return g;
 }
 
-template <int T, int SE>
+// LPV = lanes per voxel.  4 is the forward kernels' mapping (a voxel's draws dealt to four lanes, lane groups 16
+// apart): right for the evaluation's S = 32 draws.  Training runs the reference's defaults S = 1, K = 70: with four
+// lanes per voxel the one likelihood draw keeps one lane in four busy while all four repeat the voxel's loads and
+// its per-voxel preparation, 3,000 vector instructions per 16 voxels.  LPV = 1 (chosen for S <= 2) gives every
+// lane its own voxel and walks the draws in order: 3,700 per 64.  The draws themselves are keyed by (seed, voxel,
+// draw index), not by lane: the two mappings differ in summation order only.
+template <int T, int SE, int LPV>
 __global__ __launch_bounds__(kBlock) void elbo_bwd_kernel(
     QbDev c, const float4* __restrict__ g_tab, const float* __restrict__ x,
     const float* __restrict__ mask, const float* __restrict__ q, const float* __restrict__ prior,
@@ -70,12 +75,14 @@ __global__ __launch_bounds__(kBlock) void elbo_bwd_kernel(
     qb::fwd_lds_fill(&L, g_tab, false);
     __syncthreads();
 
+    constexpr int kVoxPerBlock = kBlock / LPV, kVoxPerWave = 64 / LPV;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int part = lane >> 4;
+    const int part = LPV == 1 ? 0 : lane >> 4;
+    auto voxel_sum = [](float x) { return LPV == 1 ? x : qb::voxel_sum(x); };
     float s_nll = 0.0f, s_kl = 0.0f, s_m = 0.0f;
     const int64_t ntile = (N + kVoxPerBlock - 1) / kVoxPerBlock;
     for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        const int64_t v = tile * kVoxPerBlock + wave * QB_VOX_PER_WAVE + (lane & 15);
+        const int64_t v = tile * kVoxPerBlock + wave * kVoxPerWave + (LPV == 1 ? lane : lane & 15);
         if (v < N) {
             float xv[T], lsv[T], qv[5], pv[5];
 #pragma unroll
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void elbo_bwd_kernel(
             int n_lik = 0, n_kl = 0;
 
             // ---- likelihood draws --------------------------------------------------------
-            for (int j = part; 2 * j < S; j += QB_LANES_PER_VOXEL) {
+            for (int j = part; 2 * j < S; j += LPV) {
                 float z[4];
                 const bool two = 2 * j + 1 < S;
                 qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_LIK, z);
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void elbo_bwd_kernel(
             const float reach = fmaxf(fabsf(qm.mu_o) + kZMax * qm.e_so, fabsf(qm.mu_d) + kZMax * (fabsf(qm.c) + qm.e_sd));
             if (QB_BWD_WHITENED && __all(reach < QB_LOGIT_CLIP)) {
                 float s0 = 0.0f, s1 = 0.0f, s00 = 0.0f, s11 = 0.0f, s01 = 0.0f;
-                for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
+                for (int j = part; 2 * j < K; j += LPV) {
                     float z[4];
                     const bool two = 2 * j + 1 < K;
                     qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_KL, z);
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void elbo_bwd_kernel(
                 k_c = B0 * s0 + B1 * s00 + B2 * s01;
                 k_sd = (B0 * s1 + B1 * s01 + B2 * s11) * qm.e_sd;
             } else
-            for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
+            for (int j = part; 2 * j < K; j += LPV) {
                 float z[4];
                 const bool two = 2 * j + 1 < K;
                 qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_KL, z);
@@ -265,16 +272,16 @@ __global__ __launch_bounds__(kBlock) void elbo_bwd_kernel(
                 g_sd = fmaf(wk, k_sd, g_sd);
                 g_c = fmaf(wk, k_c, g_c);
             }
-            // combine the four lanes of the voxel
-            g_mu_o = qb::voxel_sum(g_mu_o);
-            g_so = qb::voxel_sum(g_so);
-            g_mu_d = qb::voxel_sum(g_mu_d);
-            g_sd = qb::voxel_sum(g_sd);
-            g_c = qb::voxel_sum(g_c);
+            // combine the lanes of the voxel
+            g_mu_o = voxel_sum(g_mu_o);
+            g_so = voxel_sum(g_so);
+            g_mu_d = voxel_sum(g_mu_d);
+            g_sd = voxel_sum(g_sd);
+            g_c = voxel_sum(g_c);
 #pragma unroll
-            for (int t = 0; t < T; ++t) gls[t] = qb::voxel_sum(gls[t]);
-            const float nll = qb::voxel_sum(nll_sum) * inv_S;
-            const float kl = K > 0 ? qb::voxel_sum(kl_sum) / (float)K : 0.0f;
+            for (int t = 0; t < T; ++t) gls[t] = voxel_sum(gls[t]);
+            const float nll = voxel_sum(nll_sum) * inv_S;
+            const float kl = K > 0 ? voxel_sum(kl_sum) / (float)K : 0.0f;
             if (part == 0) {
                 // transform_std / transform_offdiag (model.py:288-294): s = 3 tanh(raw) - 1,
                 // c = tanh(raw) e^-2.  NB the -(s_o + s_d)_q term of the KL is stop-gradient.
@@ -289,7 +296,8 @@ __global__ __launch_bounds__(kBlock) void elbo_bwd_kernel(
                 s_nll += nll * m;
                 s_kl += m > 0.0f ? kl : 0.0f;
                 s_m += m;
-            } else if (part == 1) {
+            }
+            if (part == (LPV == 1 ? 0 : 1)) {
 #pragma unroll
                 for (int t = 0; t < T; ++t) g_ls[v * T + t] = gls[t];
             }
@@ -316,24 +324,32 @@ extern "C" int qbold_elbo_bwd(const qbold_ctx* ctx, const float* x, const float*
     }
     hipStream_t s = (hipStream_t)stream;
     double* partials = reinterpret_cast<double*>(workspace);
-    const int64_t ntile = (N + kVoxPerBlock - 1) / kVoxPerBlock;
+    const int lpv = S <= 2 ? 1 : QB_LANES_PER_VOXEL;   // see elbo_bwd_kernel
+    const int vpb = kBlock / lpv;
+    const int64_t ntile = (N + vpb - 1) / vpb;
     const int grid = (int)(ntile < qb::elbo_grid(ctx) ? (ntile > 0 ? ntile : 1) : qb::elbo_grid(ctx));
     float2* out = reinterpret_cast<float2*>(nll_kl);
+#define QB_LAUNCH_BWD(TT, SEC)                                                                                          \
+    do {                                                                                                                \
+        if (lpv == 1)                                                                                                   \
+            hipLaunchKernelGGL((elbo_bwd_kernel<TT, SEC, 1>), dim3(grid), dim3(kBlock), 0, s, ctx->dev, ctx->d_tab, x,   \
+                               mask, q, prior, log_sigma, S, K, seed, voxel0, g_q, g_log_sigma, out, partials, N);      \
+        else                                                                                                            \
+            hipLaunchKernelGGL((elbo_bwd_kernel<TT, SEC, QB_LANES_PER_VOXEL>), dim3(grid), dim3(kBlock), 0, s, ctx->dev, \
+                               ctx->d_tab, x, mask, q, prior, log_sigma, S, K, seed, voxel0, g_q, g_log_sigma, out,     \
+                               partials, N);                                                                            \
+    } while (0)
     if (ctx->dev.T == 24) {
-        hipLaunchKernelGGL((elbo_bwd_kernel<24, -1>), dim3(grid), dim3(kBlock), 0, s, ctx->dev, ctx->d_tab,
-                           x, mask, q, prior, log_sigma, S, K, seed, voxel0, g_q, g_log_sigma, out,
-                           partials, N);
+        QB_LAUNCH_BWD(24, -1);
     } else if (ctx->dev.T != 11) {
         qb::set_error("qbold_elbo_bwd: kernels are built for T = 11 or 24 taus");
         return QBOLD_ERR_UNSUPPORTED;
-    } else if (ctx->dev.se_idx == 2 && !ctx->dev.multi_norm)
-        hipLaunchKernelGGL((elbo_bwd_kernel<11, 2>), dim3(grid), dim3(kBlock), 0, s, ctx->dev, ctx->d_tab,
-                           x, mask, q, prior, log_sigma, S, K, seed, voxel0, g_q, g_log_sigma, out,
-                           partials, N);
-    else
-        hipLaunchKernelGGL((elbo_bwd_kernel<11, -1>), dim3(grid), dim3(kBlock), 0, s, ctx->dev, ctx->d_tab,
-                           x, mask, q, prior, log_sigma, S, K, seed, voxel0, g_q, g_log_sigma, out,
-                           partials, N);
+    } else if (ctx->dev.se_idx == 2 && !ctx->dev.multi_norm) {
+        QB_LAUNCH_BWD(11, 2);
+    } else {
+        QB_LAUNCH_BWD(11, -1);
+    }
+#undef QB_LAUNCH_BWD
     QB_HIP(hipGetLastError());
     hipLaunchKernelGGL(qb::reduce_partials_kernel, dim3(1), dim3(192), 0, s, partials, grid, sums);
     QB_HIP(hipGetLastError());
