@@ -54,8 +54,10 @@ def _case(oracle32, n, seed):
     return x, mask, q, prior, sigma
 
 
-@pytest.mark.parametrize("S,K", [(4, 10), (3, 7)])
+@pytest.mark.parametrize("S,K", [(4, 10), (3, 7), (1, 70), (2, 5)])
 def test_elbo_head_gradients_vs_oracle_fd(ctx, oracle32, oracle64, S, K):
+    """S > 2: a voxel's draws dealt to four lanes (the forward kernels' mapping); S <= 2 -- the reference's training
+    defaults are S = 1, K = 70 -- one lane per voxel (elbo_bwd_kernel's LPV).  48 voxels: a partial wave either way."""
     n, seed = 48, 11
     x, mask, q, prior, sigma = _case(oracle32, n, 5)
     ls = np.log(sigma.astype(np.float64))
