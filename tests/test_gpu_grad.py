@@ -593,3 +593,40 @@ def test_fused_training_kernels_over_widths_and_batch_sizes(params, monkeypatch)
                 assert (a - b).abs().max() <= 3e-4 * float(a.abs().max()) + 1e-30, \
                     (U, L, N, name, l, float((a - b).abs().max()), float(a.abs().max()))
 
+
+
+def test_voxel_batch_weight_gradients_bf16_pieces_and_one_pass_heads_against_exact_f32(params):
+    """The layer-wise backward of a voxel batch with its 1 x 1 weight gradients on the bf16 matrix pipe (xtdb_kernel,
+    three bfloat16 pieces per float32 operand) and both heads in one pass (heads_bwd_kernel), against the same
+    backward with QBOLD_KSEL_DW_EXACT_F32 | QBOLD_KSEL_HEADS_BWD_LAYERWISE (exact float32 products, delta tensor):
+    ragged batches from a single voxel to several workgroups' worth, widths that pad the 64-unit rows differently
+    (widths that are no multiple of 4 take the exact kernels either way), deltas over five decades."""
+    from qbold_vi_amd.init import init_encoder_weights
+    from qbold_vi_amd.ops import Context, EncoderWeights, TrainState
+    rng = np.random.default_rng(77)
+    layerwise = 131072                      # QBOLD_KSEL_LAYERWISE_BWD: every weight gradient through xtd / xtdb
+    for U, L, N in [(8, 1, 1), (20, 2, 17), (33, 1, 64), (60, 2, 255), (60, 2, 4097), (64, 2, 70001), (64, 1, 16)]:
+        w = init_encoder_weights(T=11, U=U, L=L, channelwise_gating=True, resid_init_std=0.3, im_loss_sigma=0.05,
+                                 seed=U + L)
+        x = torch.as_tensor(rng.uniform(0.2, 1.0, (N, 11)).astype(np.float32), device="cuda")
+        scale = np.exp(rng.uniform(np.log(1e-9), np.log(1e-4), (N, 1)))
+        g_q = torch.as_tensor((rng.normal(size=(N, 5)) * scale).astype(np.float32), device="cuda")
+        g_ls = torch.as_tensor((rng.normal(size=(N, 11)) * scale).astype(np.float32), device="cuda")
+        grads = {}
+        for sel in (layerwise, layerwise | 524288 | 1048576):
+            ctx = Context(params, True, True)
+            ctx.set_kernel_selection(sel)
+            ew = EncoderWeights(ctx, 11, U, L, True, -3.0).set_from_arrays(w)
+            st = TrainState(ctx, ew)
+            st.fused_forward = False
+            st.workspace(N).fill_(float("nan"))
+            st.forward(x, 2)
+            grads[sel] = st.backward(2, g_q, g_ls).double().clone()
+        a, b = grads[layerwise | 524288 | 1048576], grads[layerwise]
+        assert torch.isfinite(b).all(), (U, L, N)
+        for name, pieces in ew._slices().items():
+            for l, (off, shape) in enumerate(pieces):
+                cnt = int(np.prod(shape))
+                ta, tb = a[off:off + cnt], b[off:off + cnt]
+                assert float((ta - tb).abs().max()) <= 3e-6 * float(ta.abs().max()) + 1e-30, \
+                    (U, L, N, name, l, float((ta - tb).abs().max()), float(ta.abs().max()))
