@@ -45,8 +45,9 @@ def crop_batch(oracle32, B, X, Y, Z, seed):
     return x.reshape(B, X, Y, Z, 11)
 
 
-@pytest.mark.parametrize("U,L,cw", [(60, 2, True), (20, 1, False)])
+@pytest.mark.parametrize("U,L,cw", [(60, 2, True), (20, 1, False), (33, 1, True)])
 def test_spatial_forward_matches_oracle(ctx, oracle32, U, L, cw):
+    # (widths that are no multiple of 4 take conv9_kernel's exact-f32 form: conv9h_kernel reads whole float4 quarters)
     from qbold_vi_amd.ops import TrainState
     w, ew = make(ctx, U, L, cw)
     x = crop_batch(oracle32, 3, 7, 6, 2, seed=1)
@@ -88,7 +89,7 @@ def test_smoothness_loss_and_gradient(ctx, oracle64):
             assert abs(g[idx + (ch,)] - fd) < 1e-3 * (abs(fd) + 1e-2)
 
 
-@pytest.mark.parametrize("U,L,cw", [(24, 2, True), (20, 1, False)])
+@pytest.mark.parametrize("U,L,cw", [(24, 2, True), (20, 1, False), (33, 1, True)])
 def test_spatial_weight_gradient_directional(ctx, oracle32, oracle64, U, L, cw):
     """d/dw [masked-mean NLL + KL + 5 * TV] through the spatial encoder, against central differences
     of the float64 oracle along random weight directions (every tap of the 3x3x1 kernels moves)."""
