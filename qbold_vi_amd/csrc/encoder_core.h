@@ -89,6 +89,28 @@ __device__ __forceinline__ f32x4 load4(const float* __restrict__ p) {
     return v;
 }
 
+// global -> LDS copy of n4 float4 with a thread's loads in flight eight at a time.  Written as `dst[p] = src[p]` per
+// trip the compiler issues one load, waits for it and stores it: a kernel's weight image took ten dependent L2 round
+// trips per thread (more where the block is smaller) before its first tile.
+template <int THREADS>
+__device__ __forceinline__ void copy_to_lds(float* __restrict__ dst, const float* __restrict__ src, int n4) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int base = 0; base < n4; base += 8 * THREADS) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = base + u * THREADS + (int)threadIdx.x;
+            v[u] = s4[p < n4 ? p : n4 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = base + u * THREADS + (int)threadIdx.x;
+            if (p < n4) d4[p] = v[u];
+        }
+    }
+}
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 

@@ -114,8 +114,7 @@ __global__ __launch_bounds__(kEncBlock) void encoder_fwd_kernel(
     float* __restrict__ out1, float* __restrict__ out2, float* __restrict__ sigma, int64_t N) {
     constexpr EncLayout e = qb::make_enc_layout(T, 64, NL);
     extern __shared__ __align__(16) float lds_w[];
-    for (int p = threadIdx.x; p < e.total / 4; p += kEncBlock)
-        reinterpret_cast<float4*>(lds_w)[p] = reinterpret_cast<const float4*>(packed)[p];
+    qb::copy_to_lds<kEncBlock>(lds_w, packed, e.total / 4);
     __syncthreads();
 
     constexpr int HT = (5 + T + 15) / 16;
@@ -220,8 +219,7 @@ __global__ __launch_bounds__(kEncBlock) void encoder_train_fwd_kernel(
     float* __restrict__ ws, float* __restrict__ out_q, float* __restrict__ out_ls, int64_t N) {
     constexpr EncLayout e = qb::make_enc_layout(T, 64, NL);
     extern __shared__ __align__(16) float lds_w[];
-    for (int p = threadIdx.x; p < e.total / 4; p += kEncBlock)
-        reinterpret_cast<float4*>(lds_w)[p] = reinterpret_cast<const float4*>(packed)[p];
+    qb::copy_to_lds<kEncBlock>(lds_w, packed, e.total / 4);
     __syncthreads();
 
     constexpr int HT = (5 + T + 15) / 16;

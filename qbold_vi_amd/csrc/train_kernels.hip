@@ -95,6 +95,29 @@ __device__ __forceinline__ float relu_1op(float x) {
     return y;
 }
 
+// Staging a weight block into LDS: a thread's loads first, all in flight together, then its LDS stores.  Written as
+// one loop -- `if (inside) v = W[..]; Wl[..] = v;` -- the compiler keeps each load inside its branch and waits for it
+// before the store: 16 dependent L2 round trips per thread, 10 us at the head of EVERY launch of these kernels (a
+// third of a 1 x 1 layer's 30 us at the crop batch's 190 k voxels).  load(e) must be branch-free and read a valid
+// address whatever e (clamp, do not skip); store(e, v) decides what element e becomes.
+template <int THREADS, class Load, class Store>
+__device__ __forceinline__ void stage_in_flight(int total, Load load, Store store) {
+    for (int base = 0; base < total; base += 16 * THREADS) {
+        float wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = base + u * THREADS + (int)threadIdx.x;
+            wv[u] = load(e < total ? e : total - 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = base + u * THREADS + (int)threadIdx.x;
+            if (e < total) store(e, wv[u]);
+        }
+    }
+}
+__device__ __forceinline__ int clamp_hi(int v, int n) { return v < n ? v : n - 1; }   // n >= 1
+
 // Y[N][ldy] (cols < ndim) = act(X[N][ldx] (cols < kdim) . W + b), W given as Wl[k][j]:
 //   trans = 0: Wl[k][j] = W[k * ldw + j]   (forward, W canonical [in][out])
 //   trans = 1: Wl[k][j] = W[j * ldw + k]   (backward-data: dX = dY . W^T)
@@ -118,13 +141,16 @@ __global__ __launch_bounds__(256) void xw_kernel(const float* __restrict__ X, in
     const bool vout = (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
                       (!mask || ((ldm & 3) == 0 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0));
     const int kpad = vec ? (kdim + 15) & ~15 : (kdim + 3) & ~3;
-    for (int e = threadIdx.x; e < kpad * 64; e += 256) {
-        const int k = e >> 6, j = n0 + (e & 63);
-        float v = 0.0f;
-        if (k < kdim && j < ndim) v = trans ? W[j * ldw + k] : W[k * ldw + j];
-        const int jj = e & 63;
-        Wl[k * kWs + (vout ? 16 * (jj & 3) + (jj >> 2) : jj)] = v;
-    }
+    stage_in_flight<256>(
+        kpad * 64,
+        [&](int e) {
+            const int k = clamp_hi(e >> 6, kdim), j = clamp_hi(n0 + (e & 63), ndim);
+            return trans ? W[j * ldw + k] : W[k * ldw + j];
+        },
+        [&](int e, float v) {
+            const int k = e >> 6, jj = e & 63;
+            Wl[k * kWs + (vout ? 16 * (jj & 3) + (jj >> 2) : jj)] = k < kdim && n0 + jj < ndim ? v : 0.0f;
+        });
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -280,12 +306,16 @@ __global__ __launch_bounds__(256) void xw64_kernel(const float* __restrict__ X, 
                                                    int64_t N) {
     extern __shared__ float Wl[];
     const int kpad = (kdim + 15) & ~15;
-    for (int e = threadIdx.x; e < kpad * 64; e += 256) {
-        const int k = e >> 6, j = e & 63;
-        float v = 0.0f;
-        if (k < kdim && j < ndim) v = trans ? W[j * ldw + k] : W[k * ldw + j];
-        Wl[k * kWs + 16 * (j & 3) + (j >> 2)] = v;   // tile m of lane i = column 4 i + m
-    }
+    stage_in_flight<256>(
+        kpad * 64,
+        [&](int e) {
+            const int k = clamp_hi(e >> 6, kdim), j = clamp_hi(e & 63, ndim);
+            return trans ? W[j * ldw + k] : W[k * ldw + j];
+        },
+        [&](int e, float v) {
+            const int k = e >> 6, j = e & 63;
+            Wl[k * kWs + 16 * (j & 3) + (j >> 2)] = k < kdim && j < ndim ? v : 0.0f;   // tile m of lane i = column 4 i + m
+        });
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -378,12 +408,17 @@ __global__ __launch_bounds__(256) void xw64_heads_kernel(const float* __restrict
     extern __shared__ float Wl[];
     const int ndim = 5 + T;
     const int kpad = (kdim + 15) & ~15;
-    for (int e = threadIdx.x; e < kpad * 64; e += 256) {
-        const int k = e >> 6, j = e & 63;
-        float v = 0.0f;
-        if (k < kdim && j < ndim) v = j < 5 ? Wf[k * 5 + j] : Ws[k * T + (j - 5)];
-        Wl[k * kWs + 16 * (j & 3) + (j >> 2)] = v;   // tile m of lane i = column 4 i + m
-    }
+    stage_in_flight<256>(
+        kpad * 64,
+        [&](int e) {
+            const int k = clamp_hi(e >> 6, kdim), j = clamp_hi(e & 63, ndim);
+            const float* src = j < 5 ? Wf + k * 5 + j : Ws + k * T + (j - 5);
+            return *src;
+        },
+        [&](int e, float v) {
+            const int k = e >> 6, j = e & 63;
+            Wl[k * kWs + 16 * (j & 3) + (j >> 2)] = k < kdim && j < ndim ? v : 0.0f;   // tile m of lane i = column 4 i + m
+        });
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -456,13 +491,18 @@ __global__ __launch_bounds__(256) void xw64_fork_kernel(const float* __restrict_
     extern __shared__ float Wl[];  // [2][kpad][kWs]
     const int kpad = (kdim + 15) & ~15;
     float* Wl2 = Wl + kpad * kWs;
-    for (int e = threadIdx.x; e < 2 * kpad * 64; e += 256) {
-        const int which = e >= kpad * 64, ee = which ? e - kpad * 64 : e;
-        const int k = ee >> 6, j = ee & 63;
-        float v = 0.0f;
-        if (k < kdim && j < ndim) v = (which ? W2 : W1)[k * ldw + j];
-        (which ? Wl2 : Wl)[k * kWs + 16 * (j & 3) + (j >> 2)] = v;
-    }
+    stage_in_flight<256>(
+        2 * kpad * 64,
+        [&](int e) {
+            const int which = e >= kpad * 64, ee = which ? e - kpad * 64 : e;
+            const int k = clamp_hi(ee >> 6, kdim), j = clamp_hi(ee & 63, ndim);
+            return (which ? W2 : W1)[k * ldw + j];
+        },
+        [&](int e, float v) {
+            const int which = e >= kpad * 64, ee = which ? e - kpad * 64 : e;
+            const int k = ee >> 6, j = ee & 63;
+            (which ? Wl2 : Wl)[k * kWs + 16 * (j & 3) + (j >> 2)] = k < kdim && j < ndim ? v : 0.0f;
+        });
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -546,13 +586,18 @@ __global__ __launch_bounds__(256) void xw64_dual_kernel(const float* __restrict_
     extern __shared__ float Wl[];  // [2][kpad][kWs]
     const int kpad = (kdim + 15) & ~15;
     float* Wl2 = Wl + kpad * kWs;
-    for (int e = threadIdx.x; e < 2 * kpad * 64; e += 256) {
-        const int which = e >= kpad * 64, ee = which ? e - kpad * 64 : e;
-        const int k = ee >> 6, j = ee & 63;
-        float v = 0.0f;
-        if (k < kdim && j < ndim) v = (which ? W2 : W1)[j * ldw + k];   // transposed: dX = dY W^T
-        (which ? Wl2 : Wl)[k * kWs + 16 * (j & 3) + (j >> 2)] = v;
-    }
+    stage_in_flight<256>(
+        2 * kpad * 64,
+        [&](int e) {
+            const int which = e >= kpad * 64, ee = which ? e - kpad * 64 : e;
+            const int k = clamp_hi(ee >> 6, kdim), j = clamp_hi(ee & 63, ndim);
+            return (which ? W2 : W1)[j * ldw + k];   // transposed: dX = dY W^T
+        },
+        [&](int e, float v) {
+            const int which = e >= kpad * 64, ee = which ? e - kpad * 64 : e;
+            const int k = ee >> 6, j = ee & 63;
+            (which ? Wl2 : Wl)[k * kWs + 16 * (j & 3) + (j >> 2)] = k < kdim && j < ndim ? v : 0.0f;
+        });
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -641,12 +686,16 @@ __global__ __launch_bounds__(256) void xw64_gate_kernel(const float* __restrict_
                                                         int ldy, int ndim, float offset, int64_t N) {
     extern __shared__ float Wl[];
     const int kpad = (kdim + 15) & ~15;
-    for (int e = threadIdx.x; e < kpad * 64; e += 256) {
-        const int k = e >> 6, j = e & 63;
-        float v = 0.0f;
-        if (k < kdim && j < ndim) v = W[k * ldw + j];
-        Wl[k * kWs + 16 * (j & 3) + (j >> 2)] = v;   // tile m of lane i = column 4 i + m
-    }
+    stage_in_flight<256>(
+        kpad * 64,
+        [&](int e) {
+            const int k = clamp_hi(e >> 6, kdim), j = clamp_hi(e & 63, ndim);
+            return W[k * ldw + j];
+        },
+        [&](int e, float v) {
+            const int k = e >> 6, j = e & 63;
+            Wl[k * kWs + 16 * (j & 3) + (j >> 2)] = k < kdim && j < ndim ? v : 0.0f;   // tile m of lane i = column 4 i + m
+        });
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -735,13 +784,17 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
     extern __shared__ float Wl[];  // [9][64][kWs]: all nine taps stay resident (146 KiB), one block per CU
     const bool vout = (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
                       (!mask || ((ldm & 3) == 0 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0));
-    for (int e = threadIdx.x; e < 9 * 64 * 64; e += 1024) {
-        const int tap = e >> 12, k = (e >> 6) & 63, j = e & 63;
-        const float* W = K9 + (int64_t)tap * U * U;
-        float v = 0.0f;
-        if (k < U && j < U) v = flip ? W[j * U + k] : W[k * U + j];
-        Wl[(tap * 64 + k) * kWs + (vout ? 16 * (j & 3) + (j >> 2) : j)] = v;  // columns permuted as in xw_kernel
-    }
+    stage_in_flight<1024>(
+        9 * 64 * 64,
+        [&](int e) {
+            const int tap = e >> 12, k = clamp_hi((e >> 6) & 63, U), j = clamp_hi(e & 63, U);
+            const float* W = K9 + (int64_t)tap * U * U;
+            return flip ? W[j * U + k] : W[k * U + j];
+        },
+        [&](int e, float v) {
+            const int tap = e >> 12, k = (e >> 6) & 63, j = e & 63;
+            Wl[(tap * 64 + k) * kWs + (vout ? 16 * (j & 3) + (j >> 2) : j)] = k < U && j < U ? v : 0.0f;  // columns permuted as in xw_kernel
+        });
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -1884,10 +1937,8 @@ __global__ __launch_bounds__(kBlkThreads) void block_bwd_kernel(
     extern __shared__ __align__(16) float lds_img[];
     float* F = lds_img;
     float* B = lds_img + qb::BLK_FLOATS;
-    for (int p = threadIdx.x; p < qb::BLK_FLOATS / 4; p += kBlkThreads) {
-        reinterpret_cast<float4*>(F)[p] = reinterpret_cast<const float4*>(img_f)[p];
-        reinterpret_cast<float4*>(B)[p] = reinterpret_cast<const float4*>(img_b)[p];
-    }
+    qb::copy_to_lds<kBlkThreads>(F, img_f, qb::BLK_FLOATS / 4);
+    qb::copy_to_lds<kBlkThreads>(B, img_b, qb::BLK_FLOATS / 4);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -2066,10 +2117,8 @@ __global__ __launch_bounds__(kDwThreads) void block_bwd_dw_kernel(
     extern __shared__ __align__(16) float lds_img[];
     float* F = lds_img;
     float* B = lds_img + qb::BLK_FLOATS;
-    for (int p = threadIdx.x; p < qb::BLK_FLOATS / 4; p += kDwThreads) {
-        reinterpret_cast<float4*>(F)[p] = reinterpret_cast<const float4*>(img_f)[p];
-        reinterpret_cast<float4*>(B)[p] = reinterpret_cast<const float4*>(img_b)[p];
-    }
+    qb::copy_to_lds<kDwThreads>(F, img_f, qb::BLK_FLOATS / 4);
+    qb::copy_to_lds<kDwThreads>(B, img_b, qb::BLK_FLOATS / 4);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;

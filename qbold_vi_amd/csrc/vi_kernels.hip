@@ -85,8 +85,7 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
     float* lds_w = reinterpret_cast<float*>(smem);
     Lds* L = reinterpret_cast<Lds*>(smem + sizeof(float) * e.total);
     double* red = reinterpret_cast<double*>(smem + sizeof(float) * e.total + sizeof(Lds));
-    for (int p = threadIdx.x; p < e.total / 4; p += kBlock)
-        reinterpret_cast<float4*>(lds_w)[p] = reinterpret_cast<const float4*>(packed)[p];
+    qb::copy_to_lds<kBlock>(lds_w, packed, e.total / 4);
     if constexpr (qb::IsGtLds<Lds>::value) {
         qb::gt_lds_fill(L, g_tab, c);
     } else {
