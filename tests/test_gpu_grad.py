@@ -91,10 +91,11 @@ def test_elbo_head_gradients_vs_oracle_fd(ctx, oracle32, oracle64, S, K):
         assert np.max(np.abs(gls[:, t] - fd)) / scale < 2e-3, t
 
 
+@pytest.mark.parametrize("S", [3, 1])      # 3: four lanes per voxel; 1 (the training default): one lane per voxel
 @pytest.mark.parametrize("variant", [dict(student_t_df=2.0, multi_image_normalisation=True),
                                      dict(predict_log_data=True),
                                      dict(student_t_df=5.0, predict_log_data=True, multi_image_normalisation=True)])
-def test_elbo_head_gradients_loss_variants(params, oracle64, variant):
+def test_elbo_head_gradients_loss_variants(params, oracle64, variant, S):
     """The likelihood switches of EncoderTrainer (model.py:527-568): Student-t (df < 50; the reference's
     sweep configuration uses df = 2), log data, three-image normalisation -- forward value against the
     float32 oracle, head gradients against central differences of the float64 oracle."""
@@ -104,7 +105,7 @@ def test_elbo_head_gradients_loss_variants(params, oracle64, variant):
     c.set_grad_node0(False)
     o32 = Oracle("f32", params, **variant)
     o64 = Oracle("f64", params, node0_zero=True, **variant)
-    n, S, K, seed = 40, 3, 6, 9
+    n, K, seed = 40, 6, 9
     x, mask, q, prior, sigma = _case(o32, n, 6)
     ls = np.log(sigma.astype(np.float64))
     zs = o32.philox_normals(seed, 0, 0, n, S)
