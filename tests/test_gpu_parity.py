@@ -612,6 +612,10 @@ def test_24_tau_protocol(params):
     assert torch.allclose(nk, nk2, rtol=1e-4, atol=1e-4)
     s3, gq, gls, nk3 = ctx.elbo_bwd(dev(x), dev(mask), q, dev(prior), torch.log(sg), S, K, seed=seed)
     assert torch.allclose(nk3, nk2, rtol=1e-4, atol=1e-4) and bool(torch.isfinite(gq).all())
+    # the backward's one-lane-per-voxel mapping (S <= 2, the training defaults) against the forward kernel's values
+    s4, nk4 = ctx.elbo_fwd(dev(x), dev(mask), q, dev(prior), sg, 1, 70, seed=seed)
+    s5, gq1, gls1, nk5 = ctx.elbo_bwd(dev(x), dev(mask), q, dev(prior), torch.log(sg), 1, 70, seed=seed)
+    assert torch.allclose(nk5, nk4, rtol=1e-4, atol=1e-4) and bool(torch.isfinite(gq1).all() and torch.isfinite(gls1).all())
 
 
 def test_wide_encoder_shapes_and_edges(params, oracle32):
