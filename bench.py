@@ -287,9 +287,18 @@ def rehearse_launch(args, world, rank):
 class Spec:
     """One workload of the bench: which BASELINE configuration, how many voxels, which encoder arithmetic."""
 
-    def __init__(self, config=2, protocol=11, voxels=1 << 20, encoder_precision="f32", tissue="table", exact=False):
+    def __init__(self, config=2, protocol=11, voxels=1 << 20, encoder_precision="f32", tissue="table", exact=False,
+                 wide_posterior=False, off_grid=False):
         self.config, self.protocol, self.voxels = config, protocol, voxels
         self.encoder_precision, self.tissue, self.exact = encoder_precision, tissue, exact
+        # the slow sides of the headline kernel's data-dependent switches (VERDICT round 3, item 8):
+        #   wide_posterior -- the posterior head's log-std biases at +3 (s = 3 tanh(3) - 1 = 1.99, e^s = 7.3): every
+        #                     voxel's draws can reach the reference's logit clip, so every wave runs the GENERAL KL loop
+        #                     (clipped logits, 19 instructions per draw) instead of the whitened form;
+        #   off_grid       -- tau_start = -17 ms: image 2 still normalises (model.py:95) but its tau is -1 ms, so the
+        #                     grid does not mirror about it: no table-free spin-echo signal, no shared tau pairs, no
+        #                     per-tau table (the x-indexed table for all 11 taus).
+        self.wide_posterior, self.off_grid = wide_posterior, off_grid
 
 
 def run_workload(spec, args, steps, warmup, rank, device, use_pg, world, S, K):
@@ -314,11 +323,15 @@ def run_workload(spec, args, steps, warmup, rank, device, use_pg, world, S, K):
     elif spec.protocol == 24:
         params.update(tau_start="-0.028", tau_end="0.065", tau_step="0.004")
         T = 24
+    elif spec.off_grid:
+        params.update(tau_start="-0.017", tau_end="0.071", tau_step="0.008")
     n = spec.voxels
     ctx, x = make_inputs(n, params, seed=1 + rank, device=device)
     ctx.set_tissue_mode(spec.tissue)
     w = init_encoder_weights(T=T, U=U, L=L, channelwise_gating=True, resid_init_std=0.05,
                              im_loss_sigma=0.05, seed=1)
+    if spec.wide_posterior:
+        w["bf"][1] = w["bf"][3] = 3.0
     if spec.encoder_precision == "bf16" and spec.config != 2:
         raise SystemExit("--encoder_precision bf16 applies to the fused kernel (config 2)")
     ew = EncoderWeights(ctx, T, U, L, True, -3.0, precision=spec.encoder_precision).set_from_arrays(w)
@@ -423,85 +436,128 @@ def run_workload(spec, args, steps, warmup, rank, device, use_pg, world, S, K):
                 step_kernel_ms=step_kernel_ms, enc_kernel_ms=enc_kernel_ms, sums=s, n_allreduce=n_allreduce)
 
 
+# Issue cost of one wave64 vector instruction on gfx950, cycles, measured with scripts/ubench/ubench*.hip:
+# the class counters of rocprofv3 (SQ_INSTS_VALU_*) x these costs / SIMD-cycles = roofline.issue.model_frac
+ISSUE_COST = {"SQ_INSTS_VALU_TRANS_F32": 8.45, "SQ_INSTS_VALU_CVT": 4.6, "SQ_INSTS_VALU_INT32": 4.0,
+              "SQ_INSTS_VALU_FMA_F32": 2.9, "SQ_INSTS_VALU_MUL_F32": 2.9, "SQ_INSTS_VALU_ADD_F32": 2.9}
+ISSUE_COST_OTHER = 3.5    # logic, moves, max / med3, compares, permlane: between the 2.9 and 4.4-cycle classes
+N_SIMD = 256 * 4
+
+
+def issue_object(prof):
+    """How much of the chip's vector-issue time the kernel uses, from the counters of a profiles/rNN_*_pmc.json file
+    (None without one).  One formula each:
+      frac       = SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles          (SQ_ACTIVE_INST_* count quad-cycles)
+      model_frac = sum_class(SQ_INSTS_VALU_class x ISSUE_COST[class]) / SIMD-cycles
+      SIMD-cycles = GRBM_GUI_ACTIVE / 8 x 1024                      (the counter sums the 8 XCDs; 256 CUs x 4 SIMDs)
+    frac near 1 = the kernel IS its vector instruction stream: the lever is the instruction count."""
+    if not prof:
+        return None
+    c = prof.get("counters", {})
+    if not all(k in c for k in ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU")):
+        return None
+    simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * N_SIMD
+    out = {"frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles, "simd_cycles": simd_cycles,
+           "valu_instructions": c["SQ_INSTS_VALU"],
+           "cycles_per_valu_instruction": c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"],
+           "formula": "SQ_ACTIVE_INST_VALU * 4 / (GRBM_GUI_ACTIVE / 8 * 1024)",
+           "source": "profiles/" + prof.get("_file", "")}
+    if all(k in c for k in ISSUE_COST):
+        classed = sum(c[k] for k in ISSUE_COST)
+        cyc = sum(c[k] * v for k, v in ISSUE_COST.items()) + max(c["SQ_INSTS_VALU"] - classed, 0.0) * ISSUE_COST_OTHER
+        out["model_frac"] = cyc / simd_cycles
+        out["model_formula"] = ("(sum_k SQ_INSTS_VALU_k * cost_k + (SQ_INSTS_VALU - sum_k SQ_INSTS_VALU_k) * "
+                                f"{ISSUE_COST_OTHER}) / SIMD-cycles, cost = " + json.dumps(ISSUE_COST))
+        out["transcendental_share_of_instructions"] = c["SQ_INSTS_VALU_TRANS_F32"] / c["SQ_INSTS_VALU"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        out["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
+    return out
+
+
 def roofline_of(spec, m, S, K, step_kernel_ms, kernel_ms):
-    """The roofline object of one workload (see the notes inside): dominant kernel, its bound, achieved / peak."""
+    """The roofline object of one workload.  Three figures, each from one formula:
+      hbm      -- the roofline BASELINE.json's metric names: SURVEY 8(d)'s algorithmic bytes per voxel x voxels / the
+                  step's kernel time, against the guide's 8 TB/s.  The path moves 96 B per voxel against ~90 kFLOP, so
+                  this is ~0.03 by arithmetic whatever the kernel does.
+      issue    -- what the counters say binds the fused kernel: vector-issue time used / available (issue_object).
+      two_pipe -- SURVEY 8(d)'s flops priced at the guide's two dense peaks, serial sum, no overlap assumed: the
+                  encoder's 2 x MACs at the f16 / bf16 MFMA peak (ONE pass -- the three split-f16 passes that
+                  float32-grade products take are this implementation's cost, not required work), the rest at the f32
+                  vector peak.  'survey_tflops' is SURVEY's flop count per second, not machine flops: SURVEY prices a
+                  (draw, tau) evaluation at 60 flop, the kernel executes ~12 instructions for it.
+    Top level (the contract's keys): config 2 -> the hbm figure (bound "hbm"); config 3 -> its dominant kernel, the
+    one-launch encoder, against the dense f16 MFMA peak (bound "mfma")."""
     T, U, L, n, two_launch = m["T"], m["U"], m["L"], m["n"], m["two_launch"]
     enc_flops_v = 2.0 * encoder_macs_per_voxel(T, U, L)
     flops_v = float(algorithmic_flops_per_voxel(T, U, L, S, K))
     passes = 1.0 if spec.encoder_precision == "bf16" else 3.0
-    byts = algorithmic_bytes_per_voxel(T) * n
-    # Two pipes share the step: the encoder's MACs run on the f16/bf16 matrix pipe (three split-f16 passes
-    # in f32 mode, one pass in bf16 mode), sampling + ELBO on the f32 vector pipe.  The step's roof is their
-    # serial sum (no overlap assumed), expressed as one composite peak so that frac = achieved / peak.
+    bytes_v = algorithmic_bytes_per_voxel(T)
     if spec.exact:   # every flop of this path, the encoder's included, runs at the f32 rate
         t_min = flops_v / (F32_MFMA_PEAK_TFLOPS * 1e12) * n
     else:
-        t_min = (passes * enc_flops_v / (BF16_MFMA_PEAK_TFLOPS * 1e12) +
-                 (flops_v - enc_flops_v) / (F32_MFMA_PEAK_TFLOPS * 1e12)) * n
-    step_ach = flops_v * n / (step_kernel_ms * 1e-3) / 1e12
-    step_peak = flops_v * n / t_min / 1e12
+        t_min = (enc_flops_v / (BF16_MFMA_PEAK_TFLOPS * 1e12) + (flops_v - enc_flops_v) / (F32_MFMA_PEAK_TFLOPS * 1e12)) * n
+    survey_tflops = flops_v * n / (step_kernel_ms * 1e-3) / 1e12
+    two_pipe = {"frac": t_min / (step_kernel_ms * 1e-3), "floor_ms": t_min * 1e3, "kernel_ms": step_kernel_ms,
+                "survey_tflops": survey_tflops, "survey_flops_per_voxel": flops_v,
+                "encoder_flops_per_voxel": enc_flops_v, "encoder_mfma_passes_executed": passes,
+                "peaks_tflops": {"f16_bf16_mfma_dense": BF16_MFMA_PEAK_TFLOPS, "f32_vector": F32_MFMA_PEAK_TFLOPS},
+                "formula": ("(encoder_flops / f16_mfma_peak + (survey_flops - encoder_flops) / f32_vector_peak) * voxels "
+                            "/ kernel time" if not spec.exact else "survey_flops / f32_vector_peak * voxels / kernel time")}
+    hbm_gbs = bytes_v * n / (step_kernel_ms * 1e-3) / 1e9
+    hbm = {"algorithmic_bytes_per_voxel": bytes_v, "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": hbm_gbs / HBM_PEAK_GBS, "formula": "algorithmic_bytes_per_voxel * voxels / kernel time / 8 TB/s"}
     prof = None
     if two_launch:
-        # dominant kernel: the one-launch encoder, on the f16 matrix pipe
-        kname, bound = "wide_fused_kernel<4, 2, true>", "mfma"
-        ach = enc_flops_v * n / (kernel_ms * 1e-3) / 1e12
-        peak = BF16_MFMA_PEAK_TFLOPS / passes
+        kname = "wide_fused_kernel<4, 2, true>"
         prof = measured_profile(PROFILE_TAG + "_config3_pmc.json", "wide_fused_kernel") if n == 1 << 20 else None
-        note = ("dominant kernel = the one-launch wide encoder (activations in registers, weights streamed "
-                "L2 -> LDS): 'achieved' = SURVEY 8(d)'s encoder flops per voxel x voxels / its launch duration "
-                "(HIP events inside the timed region); 'peak' = the guide's dense f16 MFMA peak / 3, because "
-                "float32-grade products take three f16 MFMA passes; under this kernel's matrix load the chip "
+        ach = enc_flops_v * n / (kernel_ms * 1e-3) / 1e12
+        top = {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": ach / BF16_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_voxel": enc_flops_v,
+               "three_pass": {"peak": BF16_MFMA_PEAK_TFLOPS / passes, "frac": ach * passes / BF16_MFMA_PEAK_TFLOPS,
+                              "note": "the same launch against peak / 3: float32-grade products take three f16 MFMA "
+                                      "passes (hi.hi, hi.lo, lo.hi) in this implementation"}}
+        note = ("dominant kernel = the one-launch wide encoder (activations in registers, weights streamed L2 -> LDS): "
+                "'achieved' = SURVEY 8(d)'s encoder flops per voxel x voxels / its launch duration (HIP events inside "
+                "the timed region) against the guide's dense f16 MFMA peak; under this kernel's matrix load the chip "
                 "holds ~1.6-2.0 GHz, not the 2.4 GHz the peak assumes (DESIGN 4.7); the second launch "
-                "(elbo_fwd_lds_kernel, VALU-bound) and the step's composite two-pipe figure are in 'step'")
-    elif spec.exact:
-        kname, bound = "xw64_kernel / xw64_fork_kernel / xw64_gate_kernel / xw64_heads_kernel + elbo_fwd_kernel", "mfma"
-        ach, peak = step_ach, step_peak
-        note = ("the strictly-float32 encoder (v_mfma_f32_16x16x4_f32 GEMMs, one launch per layer, float32 "
-                "activations through HBM) + the ELBO kernel: every flop priced at the f32 matrix / vector peak; the "
-                "layer GEMMs are HBM-bound (DESIGN 4.5), which is why the headline path splits operands instead")
+                "(elbo_fwd_lds_kernel, vector-issue-bound) is in 'two_pipe' / 'hbm', which cover the whole step")
     else:
-        kname = "vi_fwd_kernel"
-        ach, peak = step_ach, step_peak
-        # the counter file of this very configuration, if one was measured on these sources
-        pmc_name = {(11, "f32"): "_vi_fwd_pmc.json", (24, "f32"): "_p24_vi_fwd_pmc.json",
-                    (11, "bf16"): "_bf16_vi_fwd_pmc.json"}.get((spec.protocol, spec.encoder_precision))
-        prof = measured_profile(PROFILE_TAG + pmc_name, "vi_fwd_kernel") \
-            if (pmc_name and spec.config == 2 and spec.tissue == "table" and n == 1 << 20) else None
-        # what the counters say; without a valid counter file the kernel's known regime (DESIGN 4.4)
-        bound = "valu-issue"
-        note = ("one launch on two pipes: 'peak' is the composite of MI355X_MICROARCH.md's dense peaks -- the "
-                "encoder's flops at the f16/bf16 MFMA peak (x the split passes), sampling + ELBO at the f32 "
-                "vector (= f32 matrix) peak, serial sum, no overlap assumed; the kernel is bound by the vector "
-                "pipe's ISSUE rate (SQ_ACTIVE_INST_VALU ~0.9 of SIMD cycles; scalar f32 instructions cost "
-                "2.9-8.5 cycles each, DESIGN 4.4), hence 'valu-issue'; 'single_pipe_f32_frac' prices ALL of "
-                "SURVEY 8(d)'s flops at the f32 peak alone and can pass 1 because the encoder's share runs "
-                "concurrently on the matrix pipe; the metric's HBM roofline (BASELINE.json) is 'hbm': the path "
-                "moves 96 B per voxel against ~90 kFLOP, so its HBM fraction is ~0.02 by arithmetic (SURVEY H1)")
+        if spec.exact:
+            kname = "xw64_kernel / xw64_fork_kernel / xw64_gate_kernel / xw64_heads_kernel + elbo_fwd_kernel"
+            note = ("the strictly-float32 encoder (v_mfma_f32_16x16x4_f32 GEMMs, one launch per layer, float32 activations "
+                    "through HBM) + the ELBO kernel; the layer GEMMs are HBM-bound on their activation traffic "
+                    "(DESIGN 4.5), which the algorithmic-byte figure here does not count")
+        else:
+            kname = "vi_fwd_kernel"
+            pmc_name = {(11, "f32"): "_vi_fwd_pmc.json", (24, "f32"): "_p24_vi_fwd_pmc.json",
+                        (11, "bf16"): "_bf16_vi_fwd_pmc.json"}.get((spec.protocol, spec.encoder_precision))
+            prof = measured_profile(PROFILE_TAG + pmc_name, "vi_fwd_kernel") \
+                if (pmc_name and spec.config == 2 and spec.tissue == "table" and n == 1 << 20
+                    and not spec.wide_posterior and not spec.off_grid) else None
+            note = ("one launch; top level = the HBM roofline the metric names (algorithmic bytes / kernel time against "
+                    "8 TB/s): ~0.03 by arithmetic, the path is compute-bound by two orders of magnitude (SURVEY H1). "
+                    "What binds the kernel is in 'issue' (vector-issue time used / available, from the counters) and the "
+                    "flop-based composite in 'two_pipe'; quote the three together")
+        top = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+               "algorithmic_bytes_per_voxel": bytes_v}
     counters, traffic = {}, None
     if prof:
         traffic = prof.get("hbm_bytes_per_launch")
         counters = dict(prof.get("counters", {}), source="profiles/" + prof.get("_file", ""),
                         measured_on_sources=prof.get("source_sha256", "")[:12], kernel=prof.get("kernel"))
-    ach_gbs = byts / (step_kernel_ms * 1e-3) / 1e9
-    return {"kernel": kname, "bound": bound, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-            "frac": ach / peak, "traffic": traffic, "kernel_ms": kernel_ms,
+    issue = issue_object(prof)
+    return {"kernel": kname, **top, "traffic": traffic, "kernel_ms": kernel_ms,
+            "limiter": ("matrix pipe (power-limited clock)" if two_launch else "HBM (layer-wise activations)" if spec.exact
+                        else "vector issue"),
+            "hbm": hbm, "issue": issue, "two_pipe": two_pipe,
             **({"counters": counters} if counters else {}),
-            "algorithmic_flops_per_voxel": enc_flops_v if two_launch else flops_v,
-            "peak_components": {"f32_matrix_or_packed_vector_tflops": F32_MFMA_PEAK_TFLOPS,
-                                "f16_bf16_mfma_tflops": BF16_MFMA_PEAK_TFLOPS,
-                                "encoder_mfma_passes": passes,
-                                "encoder_flops_per_voxel": enc_flops_v},
-            "single_pipe_f32_frac": step_ach / F32_MFMA_PEAK_TFLOPS,
             "step": {"launches": (["wide_fused_kernel", "elbo_fwd_lds_kernel", "reduce_partials_kernel"] if two_launch
                                   else ["layer-wise encoder (9 launches)", "elbo_fwd_kernel", "reduce_partials_kernel"]
                                   if spec.exact else ["vi_fwd_kernel", "reduce_partials_kernel"]),
-                     "kernel_ms": step_kernel_ms, "algorithmic_flops_per_voxel": flops_v,
-                     "achieved": step_ach, "peak": step_peak, "frac": step_ach / step_peak,
-                     "unit": "TFLOP/s", "bound": "two pipes, serial sum (composite)"},
-            "note": note,
-            "hbm": {"algorithmic_bytes_per_voxel": algorithmic_bytes_per_voxel(T),
-                    "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach_gbs / HBM_PEAK_GBS}}
+                     "kernel_ms": step_kernel_ms,
+                     **({"traffic": prof["step"].get("hbm_bytes"), "algorithmic_bytes": prof["step"].get("algorithmic_bytes")}
+                        if (prof and "step" in prof) else {})},
+            "note": note}
 
 
 def workload_text(spec, m, S, K):
@@ -515,19 +571,23 @@ def workload_text(spec, m, S, K):
         arith = "operands rounded to bf16, one MFMA pass, f32 accumulate"
     entry = ("qbold_encoder_train_fwd + qbold_elbo_fwd (vi_fwd_exact)" if spec.exact else
              "qbold_encoder_fused_fwd + qbold_elbo_fwd_logsigma (= qbold_vi_fwd)" if m["two_launch"] else "fused qbold_vi_fwd")
+    slow = ("; posterior log-std biases +3: every wave on the general (clipped-logit) KL loop" if spec.wide_posterior else
+            "; tau_start -17 ms: spin-echo image off tau = 0, no mirrored pairs, x-indexed table" if spec.off_grid else "")
     return (f"{n} synthetic voxels/GPU x {T} tau, S={S} likelihood draws, K={K} KL draws, encoder U={U}, L={L} "
             f"({'optimal.yaml' if U == 60 else 'BASELINE config 3'}), {entry}, tissue integral: {spec.tissue}; "
-            f"encoder arithmetic: {arith}; sampling, forward model and ELBO sums: f32")
+            f"encoder arithmetic: {arith}; sampling, forward model and ELBO sums: f32{slow}")
 
 
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 # what the default N = 1 run times after the headline: every configuration a summary
 # quotes, so that each number has a driver-witnessed line
 VARIANTS = (("config3_64tau_width256", dict(config=3)),
             ("bf16_encoder", dict(encoder_precision="bf16")),
             ("voxels_4194304", dict(voxels=4194304)),
             ("protocol_24tau", dict(protocol=24)),
-            ("exact_f32_encoder", dict(exact=True)))
+            ("exact_f32_encoder", dict(exact=True)),
+            ("general_kl_loop_wide_posteriors", dict(wide_posterior=True)),
+            ("off_grid_spin_echo", dict(off_grid=True)))
 
 
 def main():
@@ -645,6 +705,7 @@ def main():
                        "global_voxels": total_vox, "parallelism": f"voxel-shard x{world}",
                        "collective": "all_reduce(3 x f64)/step, overlapped with the next step" if use_pg else "none"},
             "neg_elbo": neg_elbo,
+            "sum_mask": float(s[2]),   # the (all-reduced) sum of the masks: voxels x ranks for the all-ones mask
             "ranks_seen": dist.get_world_size() if use_pg else 1,
             "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if use_pg else "none",
             **({"allreduce_per_timed_step": m["n_allreduce"] / args.steps} if use_pg else {}),
@@ -678,9 +739,10 @@ def main():
                     "value": vm["n"] * 1e3 / vms, "unit": "voxel-ELBO evals/s",
                     "neg_elbo": float((vsum[0] + vsum[1]) / vsum[2]),
                     "roofline": {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
-                                                   "kernel_ms", "algorithmic_flops_per_voxel")}
+                                                   "kernel_ms", "limiter", "issue")}
                                 | {"step_kernel_ms": vm["step_kernel_ms"], "hbm_frac": r["hbm"]["frac"],
-                                   "step_frac": r["step"]["frac"]}}
+                                   "two_pipe_frac": r["two_pipe"]["frac"],
+                                   **({"three_pass_frac": r["three_pass"]["frac"]} if "three_pass" in r else {})}}
                 del vm
             m = {"w": w_headline, "params": params_headline}
             # one fine-tuning step (forward with saved activations, ELBO backward, encoder backward, AdamW) on a

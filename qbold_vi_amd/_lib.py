@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqbold_hip.so")
+# QBOLD_LIB selects another build of the SAME ABI for a timing experiment (build.build_lib(extra_flags=...) writes
+# such builds to their own object directory and library file, never over this one).
+LIB_PATH = os.environ.get("QBOLD_LIB") or os.path.join(_HERE, "libqbold_hip.so")
 
 QBOLD_OK = 0
 QBOLD_TISSUE_TABLE = 0

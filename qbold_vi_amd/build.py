@@ -87,7 +87,14 @@ def build_lib(force=False, verbose=False, extra_flags=()):
     """Compile every .hip translation unit and link libqbold_hip.so.  Returns the library path.
     Translation units listed in ISA_CHECKS are compiled with -save-temps and their ISA is verified before the
     object is accepted (a stamp beside the object records the verdict of exactly that object)."""
-    os.makedirs(OBJ, exist_ok=True)
+    obj_dir, lib_path = OBJ, LIB
+    if extra_flags:
+        # a build with extra flags (ablation hooks, tuning macros) never shares objects or the library file with the
+        # default build: its own directory and file, named by the flags; load it with QBOLD_LIB=<path>
+        import hashlib
+        tag = hashlib.sha256(" ".join(extra_flags).encode()).hexdigest()[:10]
+        obj_dir, lib_path = os.path.join(HERE, "_obj_var_" + tag), os.path.join(HERE, f"libqbold_hip_var_{tag}.so")
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     hdr_time = _newest(hdrs)
@@ -95,7 +102,7 @@ def build_lib(force=False, verbose=False, extra_flags=()):
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(o)
         stamp = o + ".isa_ok"
         stale = force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time)
@@ -118,7 +125,7 @@ def build_lib(force=False, verbose=False, extra_flags=()):
             o = cmd[-1]
             src = os.path.basename(cmd[-3])
             stem = src[:-len(".hip")]
-            asm = os.path.join(OBJ, f"{stem}-hip-amdgcn-amd-amdhsa-gfx950.s")
+            asm = os.path.join(obj_dir, f"{stem}-hip-amdgcn-amd-amdhsa-gfx950.s")
             try:
                 report = verify_isa(src, asm)
             except Exception:
@@ -126,7 +133,7 @@ def build_lib(force=False, verbose=False, extra_flags=()):
                     os.remove(o)       # never link an object whose ISA failed the check
                 raise
             finally:
-                _drop_temps(OBJ, stem)
+                _drop_temps(obj_dir, stem)
             with open(o + ".isa_ok", "w") as fh:
                 fh.write("\n".join(report) + "\n")
             if verbose:
@@ -134,9 +141,9 @@ def build_lib(force=False, verbose=False, extra_flags=()):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    if jobs or not os.path.exists(lib_path):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs])
+    return lib_path
 
 
 if __name__ == "__main__":

@@ -199,7 +199,16 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
     {
         const int nseg = qb::gtab_segs(T), se = d.se_idx;
         const bool proto = (T == 11 && se == 2);   // the protocol the table-driven kernels are instantiated for
-        if (nseg > 0 && proto && d.taus[se] == 0.0f && P->full_model) {
+        // One prediction is scored at tau_{se+j} and at its mirror tau_{se-j} (elbo_core.h): that needs |tau| and the
+        // blood bracket to agree on both sides.  The reference's float32 grid start + i step mirrors to an ulp, not
+        // exactly (-8 / +8 ms differ by one), so the test is relative, at the level of that rounding.
+        bool mirrors = true;
+        for (int j = 1; se - j >= 0 && se + j < T; ++j) {
+            const float ta = fabsf(d.taus[se - j]), tb = fabsf(d.taus[se + j]);
+            const float ba = d.blood_B[se - j], bb = d.blood_B[se + j];
+            mirrors = mirrors && fabsf(ta - tb) <= 1e-6f * fmaxf(ta, tb) && fabsf(ba - bb) <= 4e-6f * fmaxf(fabsf(ba), fabsf(bb));
+        }
+        if (nseg > 0 && proto && d.taus[se] == 0.0f && P->full_model && mirrors) {
             const int J = qb::gtab_taus(T, se);
             ctx->h_gtab.resize((size_t)4 * J * nseg);
             const double hh = (double)QB_GT_OEF_RANGE / nseg;

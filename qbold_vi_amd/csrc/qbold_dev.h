@@ -162,12 +162,24 @@ __device__ __forceinline__ float nlogp(const LogitObs& o, const LogitMvn& m) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Philox4x32-10 (Random123) and the normal stream: ctr = (voxel_lo, voxel_hi, pair index,
-// stream id), key = (seed_lo, seed_hi).  One call yields the (z0, z1) normals of two draws.
+// Philox4x32 (Random123) and the normal stream.
+//
+// The stream is this library's own definition (the reference's tf.random.normal stream is irreproducible);
+// the oracle restates it word for word (oracle/qbold_oracle.c, qbo_philox_normals).  Round 4:
+//   draw i of (seed, voxel, stream) = word (i & 3) of Philox4x32-7(ctr = (voxel_lo, voxel_hi, i >> 2, stream), key = seed)
+//   word w -> radius  r = sqrt(-2 ln u1),  u1 = ((w >> 16) + 0.5) 2^-16   (u1 in (0, 1): |z| <= 4.8549)
+//             angle   theta = (w & 0xffff) 2^-16 revolutions
+//             (z0, z1) = r (cos 2 pi theta, sin 2 pi theta)
+// i.e. one Philox call serves FOUR draws (rounds 1-3: two, with 32-bit uniforms and ten rounds) and a draw costs
+// 7 + 11 vector instructions instead of 20 + 11.  Seven rounds are the Crush-resistant minimum Random123 publishes for
+// Philox4x32 (Salmon et al., SC'11, table 2; known-answer vectors for 7 rounds: tests/test_oracle.py); sixteen-bit
+// radius and angle put the normals on a 65,536 x 65,536 polar lattice (radial step at the mode 2.6e-5), whose moments
+// tests/test_oracle.py holds against the Gaussian's.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+template <int ROUNDS>
+__device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         // one 32x32->64 multiply (v_mad_u64_u32) per word instead of a mul_hi / mul_lo pair
         const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
@@ -180,28 +192,57 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
     }
     return c;
 }
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) { return philox4x32<10>(c, k); }
+__device__ __forceinline__ uint4 philox4x32_7(uint4 c, uint2 k) { return philox4x32<7>(c, k); }
 
-__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
-    // u in (0, 1]: all 32 bits, converted with round-to-nearest and centred -- v_cvt_f32_u32 + one FMA
-    // (two instructions per uniform; the 24-bit (x >> 8) + 0.5 form took four), and the float grid is finer
-    // near 0, where the radius sqrt(-2 ln u1) needs it.  u = 1 (from a >= 2^32 - 128) gives radius 0.
-    float u1 = fmaf((float)a, 0x1p-32f, 0x1p-33f);
-    float u2 = fmaf((float)b, 0x1p-32f, 0x1p-33f);
+#define QB_Z_MAX 4.8549f   // sqrt(-2 ln 2^-17) = 4.85487: the largest |z| the stream can produce
+
+// one word -> the two normals of one draw
+__device__ __forceinline__ void box_muller16(uint32_t w, float& z0, float& z1) {
+    const float u1 = fmaf((float)(w >> 16), 0x1p-16f, 0x1p-17f);   // exact in float32
+    const float th = (float)(w & 0xffffu) * 0x1p-16f;             // revolutions, exact
     // r = sqrt(-2 ln u1) via v_log_f32 (log2) and v_sqrt_f32; v_sin/v_cos take revolutions
-    float r = __builtin_amdgcn_sqrtf((-2.0f * QB_LN2) * log2f_(u1));
-    z0 = r * __builtin_amdgcn_cosf(u2);
-    z1 = r * __builtin_amdgcn_sinf(u2);
+    const float r = __builtin_amdgcn_sqrtf((-2.0f * QB_LN2) * log2f_(u1));
+    z0 = r * __builtin_amdgcn_cosf(th);
+    z1 = r * __builtin_amdgcn_sinf(th);
 }
 
 enum { STREAM_LIK = 0, STREAM_KL = 1, STREAM_MOMENTS = 2, STREAM_R2P = 3 };
 
-// normals of draws (2*pair, 2*pair+1) of `stream` for global voxel `vox`
+// The four draws of Philox call `quad` of a stream, served one at a time: the words stay words until a draw is taken
+// (four live registers instead of eight normals, and the Box-Muller code sits once in a draw loop that is not unrolled).
+struct DrawQuad {
+    uint32_t w0, w1, w2, w3;
+    __device__ __forceinline__ void load(uint64_t seed, uint64_t vox, uint32_t quad, uint32_t stream) {
+        const uint4 o = philox4x32_7(make_uint4((uint32_t)vox, (uint32_t)(vox >> 32), quad, stream),
+                                     make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        w0 = o.x; w1 = o.y; w2 = o.z; w3 = o.w;
+    }
+    __device__ __forceinline__ void next(float& z0, float& z1) {   // draws 4 quad, 4 quad + 1, ... in order
+        box_muller16(w0, z0, z1);
+        w0 = w1; w1 = w2; w2 = w3;
+    }
+};
+
+// normals of draws (4 quad .. 4 quad + 3): z[2 d], z[2 d + 1] for draw 4 quad + d
+__device__ __forceinline__ void normals8(uint64_t seed, uint64_t vox, uint32_t quad, uint32_t stream, float z[8]) {
+    const uint4 o = philox4x32_7(make_uint4((uint32_t)vox, (uint32_t)(vox >> 32), quad, stream),
+                                 make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    box_muller16(o.x, z[0], z[1]);
+    box_muller16(o.y, z[2], z[3]);
+    box_muller16(o.z, z[4], z[5]);
+    box_muller16(o.w, z[6], z[7]);
+}
+
+// normals of draws (2*pair, 2*pair+1) of `stream` for global voxel `vox`: half a Philox call's words (the kernels off
+// the hot path walk their draws in pairs; the hot loops take whole calls through DrawQuad / normals8)
 __device__ __forceinline__ void normals4(uint64_t seed, uint64_t vox, uint32_t pair,
                                          uint32_t stream, float z[4]) {
-    uint4 o = philox4x32_10(make_uint4((uint32_t)vox, (uint32_t)(vox >> 32), pair, stream),
-                            make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
-    box_muller(o.x, o.y, z[0], z[1]);
-    box_muller(o.z, o.w, z[2], z[3]);
+    const uint4 o = philox4x32_7(make_uint4((uint32_t)vox, (uint32_t)(vox >> 32), pair >> 1, stream),
+                                 make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    const bool hi = (pair & 1u) != 0u;
+    box_muller16(hi ? o.z : o.x, z[0], z[1]);
+    box_muller16(hi ? o.w : o.y, z[2], z[3]);
 }
 
 // ---------------------------------------------------------------------------------------------

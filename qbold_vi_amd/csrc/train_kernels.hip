@@ -2259,12 +2259,15 @@ __global__ void gelu_kernel(const float* __restrict__ in, float* __restrict__ ou
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
         out[e] = gelu_(in[e]);
 }
-__global__ void gelu_bwd_mul_kernel(const float* __restrict__ d, const float* __restrict__ z,
-                                    float* __restrict__ out, int64_t n) {
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+// d[row][col] *= gelu'(z[row][col]) in place, columns < U only: the padding columns of Z hold stale workspace data
+// (possibly NaN / Inf), which must not reach the delta tensors.
+__global__ void gelu_bwd_mul_kernel(float* d, const float* __restrict__ z, int64_t rows, int ld, int U) {
+    const int64_t n = rows * (int64_t)U;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = (i / U) * ld + (i % U);
         const float v = z[e];
         const float dg = 0.5f * (1.0f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
-        out[e] = d[e] * dg;
+        d[e] *= dg;
     }
 }
 
@@ -2725,7 +2728,7 @@ static int train_bwd_gelu(const qbold_ctx* ctx, const qbold_encoder_shape* shape
         hipLaunchKernelGGL(gelu_kernel, dim3(k.ew()), dim3(256), 0, k.s, in, out, ne);
     };
     auto times_dgelu = [&](float* d, const float* z) {   // d *= gelu'(z)
-        hipLaunchKernelGGL(gelu_bwd_mul_kernel, dim3(k.ew()), dim3(256), 0, k.s, d, z, d, ne);
+        hipLaunchKernelGGL(gelu_bwd_mul_kernel, dim3(k.ew()), dim3(256), 0, k.s, d, z, N, ld, U);
     };
     // heads: dWf, dbf (and dWs, dbs); dB = g_q Wf^T (+ g_ls Ws^T)
     k.xtd(last, U, dA, 5, partial, slabs, grad + c.Wf, 5, grad + c.bf, 0);

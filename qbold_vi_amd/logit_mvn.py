@@ -22,6 +22,16 @@ class LogitMVN:
     # logit_mvn.py:20-38: ||L^-1 (obs - mean)||^2 with L = [[e^so, 0], [cov, e^sd]]
     @staticmethod
     def squared_whitened_residual(obs, mean, oef_log_std, dbv_log_std, oef_dbv_cov):
+        # Host tensors and tensors inside an autograd graph keep the reference's own expression (device-agnostic and
+        # differentiable, like logit_mvn.py:20-38); the kernel serves ROCm tensors outside a graph.
+        tensors = (obs, mean, oef_log_std, dbv_log_std, oef_dbv_cov)
+        if any((not t.is_cuda) or t.requires_grad for t in tensors):
+            out_shape = mean.shape[:-1]
+            r = obs.reshape(-1, 2) - mean.reshape(-1, 2)
+            so, sd, cov = oef_log_std.reshape(-1), dbv_log_std.reshape(-1), oef_dbv_cov.reshape(-1)
+            w0 = r[:, 0] * torch.exp(so * -1.0)
+            w1 = r[:, 1] * torch.exp(sd * -1.0) + r[:, 0] * (torch.exp(so * -1.0 + sd * -1.0) * cov * -1.0)
+            return (w0 * w0 + w1 * w1).reshape(out_shape)
         from . import _lib
         from .ops import _f32, _ptr, _stream
         out_shape = mean.shape[:-1]

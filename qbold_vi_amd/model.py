@@ -222,8 +222,16 @@ class FineTuner:
             sums, q, nll_kl = tr._ctx.vi_fwd(self.encoder_model.weights, x, m, p5, S, K, seed=seed, voxel0=voxel0,
                                              range_check=True)
         if not tr._use_mvg and mog:   # model.py:666-685: one draw per dimension against the mixture (no prior cost)
-            kl_v = tr._ctx.kl_mog(q, torch.as_tensor(self.pop_prior, device=x.device).reshape(-1, 4), seed=seed,
-                                  voxel0=voxel0)
+            # The reference tiles the batch S-fold before this loss (model.py:245-246, 656), so a voxel is scored at S
+            # independent draws and their mean enters the masked sum; copy s of voxel i is row s * N + i of the tiled
+            # batch, which is the Philox key kl_loss() gives it.  kl_tiled=False: one draw per voxel.
+            comps = torch.as_tensor(self.pop_prior, device=x.device).reshape(-1, 4)
+            tiled = tr._kl_tiled if kl_tiled is None else kl_tiled
+            copies = max(int(S), 1) if tiled else 1
+            kl_v = tr._ctx.kl_mog(q, comps, seed=seed, voxel0=voxel0)
+            for s in range(1, copies):
+                kl_v = kl_v + tr._ctx.kl_mog(q, comps, seed=seed, voxel0=voxel0 + s * x.shape[0])
+            kl_v = kl_v / copies
             live = kl_v if m is None else torch.where(m > 0, kl_v, torch.zeros_like(kl_v))
             sums[1] = live.sum(dtype=torch.float64)
             nll_kl[:, 1] = kl_v

@@ -326,7 +326,11 @@ class CropDataset:
     crop_size x crop_size crops over (X, Y) keeping every slice and channel."""
 
     def __init__(self, real_data, model, crop_size=20, training=True, blank_crop=True):
-        if blank_crop and real_data.shape[1] > 34 + 8 and real_data.shape[2] > 20 + 8:
+        # train.py:18-20 crops [17:-17, 10:-10] unconditionally.  Deviation, documented in DESIGN.md: a volume of at
+        # most 34 x 20 in-plane voxels would be left EMPTY by that slice (the reference then fails inside Keras); such
+        # volumes -- the small stand-ins of the tests -- are kept whole.  Every volume the reference can process is
+        # cropped exactly as it crops it.
+        if blank_crop and real_data.shape[1] > 34 and real_data.shape[2] > 20:
             real_data = real_data[:, 17:-17, 10:-10]
         self.mask = real_data[..., -1].contiguous()
         self.data = (real_data[..., :-1] * real_data[..., -1:]).contiguous()
@@ -420,6 +424,9 @@ def _train_full_model_crops(config_dict, trainer, full_model, study_dataset, tra
         vn, vk, vs = vn / 4, vk / 4, vs / 4
         metrics.update({"val_nll": vn, "val_elbo": vn + vk, "val_elbo_smooth": vn + vk * 1.0 + vs * sw,
                         "val_smoothness": vs, "val_smoothness_scaled": vs * sw, "val_kl": vk})
+        # evaluations whose split-f16 encoder left its operand range and were recomputed on the exact-float32
+        # path (ops.Context.vi_fwd, range_check): cumulative count, 0 in a healthy run
+        metrics["range_fallbacks"] = int(getattr(trainer.context, "range_fallbacks", 0))
         log.log(metrics)
         if max_steps and step >= max_steps:
             break
@@ -490,6 +497,7 @@ def train_full_model(config_dict, trainer, full_model, study_dataset, train_data
         metrics = {"epoch": epoch, "loss": nll + kl, "predicted_images_loss": nll, "predictions_loss": kl}
         metrics.update(validation_elbo(config_dict, trainer, full_model, (vx, vmask, vprior), kl_samples,
                                        seed=epoch))
+        metrics["range_fallbacks"] = int(getattr(trainer.context, "range_fallbacks", 0))   # see _train_full_model_crops
         log.log(metrics)
         if max_steps and step >= max_steps:
             break
