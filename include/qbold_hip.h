@@ -299,7 +299,9 @@ int qbold_kl_diag(const qbold_ctx* ctx, const float* q, const float* prior, cons
 /* The counter-based normal stream the fused kernels consume: z [N][n][2] for global voxels
  * voxel0 .. voxel0+N-1; stream_id 0 = likelihood draws, 1 = KL draws, 2 = moments, 3 = noise.
  * Replaces tf.random.normal at model.py:25 with a reproducible, sharding-invariant generator
- * (Random123 Philox4x32-10 + Box-Muller). */
+ * (Random123 Philox4x32-7, four draws per call: draw i = word i & 3 of call i >> 2 keyed (voxel, call, stream_id; seed);
+ * Box-Muller on the word's high sixteen bits (radius, u1 = (hi + 0.5) 2^-16, so |z| <= 4.8549) and low sixteen bits
+ * (angle, lo 2^-16 revolutions).  The definition is this library's; oracle/qbold_oracle.c restates it. */
 int qbold_normals(const qbold_ctx* ctx, uint64_t seed, uint32_t stream_id, int64_t voxel0, int n,
                   float* z, int64_t N, void* stream);
 
@@ -318,7 +320,7 @@ int64_t qbold_elbo_workspace_bytes(const qbold_ctx* ctx);
  * model (model.py:245-248,273), fine_tune_loss_fn (model.py:527-568), kl_loss -> mvg_kl_samples
  * (model.py:654-665, 592-610), masked sums as train.py:351.
  *   x [N][T], mask [N] (NULL = ones), q / prior [N][5], sigma [N][T]
- *   zs [N][S][2], zk [N][K][2] explicit normals, or NULL for the in-kernel Philox4x32-10 stream
+ *   zs [N][S][2], zk [N][K][2] explicit normals, or NULL for the in-kernel Philox4x32-7 stream (qbold_normals)
  *   keyed (seed; global voxel voxel0+i; draw) -- identical for any sharding of the voxels
  *   nll_kl [N][2] per-voxel (nll averaged over S, kl) or NULL
  *   sums: DEVICE double[3] = (sum_v m*nll, sum_v [m>0] kl, sum_v m), overwritten

@@ -382,11 +382,11 @@ class Oracle:
         return dict(nll_v=nll_v, kl_v=kl_v, sums=sums, nll=nll, kl=kl, elbo=nll + kl)
 
     # -- RNG -----------------------------------------------------------------------------
-    def philox(self, ctr, key):
+    def philox(self, ctr, key, rounds=10):
         c = (C.c_uint32 * 4)(*ctr)
         k = (C.c_uint32 * 2)(*key)
         o = (C.c_uint32 * 4)()
-        self.lib.qbo_philox4x32_10(c, k, o)
+        {10: self.lib.qbo_philox4x32_10, 7: self.lib.qbo_philox4x32_7}[rounds](c, k, o)
         return tuple(int(v) for v in o)
 
     def philox_normals(self, seed, stream, voxel0, N, n):

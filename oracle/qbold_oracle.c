@@ -942,12 +942,18 @@ void qbo_elbo(const qbo_phys *P, const qbo_loss_cfg *C, const real *x, const rea
 }
 
 /* ------------------------------------------------------------------------------------------
- * Random123 Philox4x32-10 (Salmon et al., SC'11) and the normal stream shared with the kernels.
+ * Random123 Philox4x32 (Salmon et al., SC'11) and the normal stream shared with the kernels.
+ *
+ * The stream is the LIBRARY's definition, not the reference's (tf.random.normal cannot be reproduced); this
+ * is its restatement, word for word (qbold_vi_amd/csrc/qbold_dev.h).  Round 4:
+ *   draw i of (seed, voxel, stream) = word (i & 3) of Philox4x32-7(ctr = (voxel_lo, voxel_hi, i >> 2, stream), key = seed)
+ *   word w: u1 = ((w >> 16) + 0.5) 2^-16, r = sqrt(-2 ln u1); theta = (w & 0xffff) 2^-16 revolutions;
+ *           (z0, z1) = r (cos 2 pi theta, sin 2 pi theta), everything in double, rounded once.
  * ---------------------------------------------------------------------------------------- */
-void qbo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+static void philox4x32_rounds(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
     uint32_t k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -960,15 +966,19 @@ void qbo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+void qbo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    philox4x32_rounds(ctr, key, 10, out);
+}
+void qbo_philox4x32_7(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    philox4x32_rounds(ctr, key, 7, out);
+}
 
-static inline void box_muller(uint32_t a, uint32_t b, real *z0, real *z1) {
-    /* u in (0,1]: the float32 value fma(float(a), 2^-32, 2^-33) that the kernels form (uint32 -> float32
-     * round-to-nearest, one FMA), then everything in double, rounded once. */
-    double u1 = (double)fmaf((float)a, 0x1p-32f, 0x1p-33f);
-    double u2 = (double)fmaf((float)b, 0x1p-32f, 0x1p-33f);
+static inline void box_muller16(uint32_t w, real *z0, real *z1) {
+    double u1 = ((double)(w >> 16) + 0.5) * 0x1p-16;       /* in (0, 1): |z| <= sqrt(-2 ln 2^-17) = 4.8549 */
+    double th = (double)(w & 0xffffu) * 0x1p-16;            /* revolutions */
     double rr = sqrt(-2.0 * log(u1));
-    *z0 = R(rr * cos(2.0 * M_PI * u2));
-    *z1 = R(rr * sin(2.0 * M_PI * u2));
+    *z0 = R(rr * cos(2.0 * M_PI * th));
+    *z1 = R(rr * sin(2.0 * M_PI * th));
 }
 
 void qbo_philox_normals(uint64_t seed, uint32_t stream, int64_t voxel0, int64_t N, int n,
@@ -977,13 +987,14 @@ void qbo_philox_normals(uint64_t seed, uint32_t stream, int64_t voxel0, int64_t 
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < N; ++i) {
         uint64_t vox = (uint64_t)(voxel0 + i);
-        for (int j = 0; 2 * j < n; ++j) {
-            uint32_t ctr[4] = {(uint32_t)vox, (uint32_t)(vox >> 32), (uint32_t)j, stream};
+        for (int g = 0; 4 * g < n; ++g) {
+            uint32_t ctr[4] = {(uint32_t)vox, (uint32_t)(vox >> 32), (uint32_t)g, stream};
             uint32_t o[4];
-            qbo_philox4x32_10(ctr, key, o);
-            real *zz = z + ((int64_t)i * n + 2 * j) * 2;
-            box_muller(o[0], o[1], &zz[0], &zz[1]);
-            if (2 * j + 1 < n) box_muller(o[2], o[3], &zz[2], &zz[3]);
+            qbo_philox4x32_7(ctr, key, o);
+            for (int d = 0; d < 4 && 4 * g + d < n; ++d) {
+                real *zz = z + ((int64_t)i * n + 4 * g + d) * 2;
+                box_muller16(o[d], &zz[0], &zz[1]);
+            }
         }
     }
 }

@@ -160,6 +160,7 @@ void qbo_elbo(const qbo_phys *P, const qbo_loss_cfg *C, const real *x, const rea
 
 /* Random123 Philox4x32-10. */
 void qbo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void qbo_philox4x32_7(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 /* Counter-RNG normals shared bit-for-bit (integer part) with the HIP kernels:
  * ctr = (voxel_lo, voxel_hi, draw>>1 pair index, stream), key = (seed_lo, seed_hi).
  * z [N][n][2] for global voxels voxel0 .. voxel0+N-1. */

@@ -193,22 +193,29 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
         ctx->h_tab[4 * i + 3] = (float)(2.0 * (f[i] - f[i + 1]) + g[i] + g[i + 1]);
     }
 
+    // Does the protocol mirror about its spin-echo image?  The sampling fast paths evaluate the signal ONCE for
+    // tau_{se+j} and its mirror tau_{se-j} (the signal is even in tau) and score the pair as one merged data point
+    // (elbo_core.h): that needs tau = 0 at the spin echo, and |tau| and the blood bracket to agree on both sides.  The
+    // reference's float32 grid start + i step mirrors to an ulp, not exactly (-8 / +8 ms differ by one), so the test
+    // is relative, at the level of that rounding.
+    {
+        const int se = d.se_idx;
+        bool mirrors = se >= 0 && se < T && d.taus[se] == 0.0f;
+        for (int j = 1; mirrors && se - j >= 0 && se + j < T; ++j) {
+            const float ta = fabsf(d.taus[se - j]), tb = fabsf(d.taus[se + j]);
+            const float ba = d.blood_B[se - j], bb = d.blood_B[se + j];
+            mirrors = fabsf(ta - tb) <= 1e-6f * fmaxf(ta, tb) && fabsf(ba - bb) <= 4e-6f * fmaxf(fabsf(ba), fabsf(bb));
+        }
+        ctx->grid_mirrors = mirrors;
+    }
+
     // Per-tau OEF-indexed table of the sampling fast path (qbold_dev.h, GtLds): G_j(OEF) = F(|tau_j| dw_coef OEF) on
     // gtab_segs(T) cubic-Hermite segments over OEF in [0.04, 0.84], j = 1 .. gtab_taus(T, se_idx), built for the
     // protocols whose spin-echo image sits at tau = 0 exactly (both of the reference's, signals.py:117-121).
     {
         const int nseg = qb::gtab_segs(T), se = d.se_idx;
-        const bool proto = (T == 11 && se == 2);   // the protocol the table-driven kernels are instantiated for
-        // One prediction is scored at tau_{se+j} and at its mirror tau_{se-j} (elbo_core.h): that needs |tau| and the
-        // blood bracket to agree on both sides.  The reference's float32 grid start + i step mirrors to an ulp, not
-        // exactly (-8 / +8 ms differ by one), so the test is relative, at the level of that rounding.
-        bool mirrors = true;
-        for (int j = 1; se - j >= 0 && se + j < T; ++j) {
-            const float ta = fabsf(d.taus[se - j]), tb = fabsf(d.taus[se + j]);
-            const float ba = d.blood_B[se - j], bb = d.blood_B[se + j];
-            mirrors = mirrors && fabsf(ta - tb) <= 1e-6f * fmaxf(ta, tb) && fabsf(ba - bb) <= 4e-6f * fmaxf(fabsf(ba), fabsf(bb));
-        }
-        if (nseg > 0 && proto && d.taus[se] == 0.0f && P->full_model && mirrors) {
+        const bool proto = (T == 11 && se == 2) || (T == 24 && se == 7);   // the protocols the table-driven kernels are instantiated for
+        if (nseg > 0 && proto && ctx->grid_mirrors && P->full_model) {
             const int J = qb::gtab_taus(T, se);
             ctx->h_gtab.resize((size_t)4 * J * nseg);
             const double hh = (double)QB_GT_OEF_RANGE / nseg;

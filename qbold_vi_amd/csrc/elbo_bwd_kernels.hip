@@ -110,14 +110,15 @@ __global__ __launch_bounds__(kBlock) void elbo_bwd_kernel(
             int n_lik = 0, n_kl = 0;
 
             // ---- likelihood draws --------------------------------------------------------
-            for (int j = part; 2 * j < S; j += LPV) {
-                float z[4];
-                const bool two = 2 * j + 1 < S;
-                qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_LIK, z);
-                n_lik += two ? 2 : 1;
+            for (int g = part; 4 * g < S; g += LPV) {
+                const int cnt = S - 4 * g < 4 ? S - 4 * g : 4;
+                n_lik += cnt;
+                qb::DrawQuad dq;
+                dq.load(seed, vox, (uint32_t)g, qb::STREAM_LIK);
 #pragma unroll 1
-                for (int d = 0; d < (two ? 2 : 1); ++d) {
-                    const float z0 = d ? z[2] : z[0], z1 = d ? z[3] : z[1];
+                for (int d = 0; d < cnt; ++d) {
+                    float z0, z1;
+                    dq.next(z0, z1);
                     float a, b;
                     qb::reparam_logits(qm, z0, z1, a, b);
                     const float sa = qb::sigmoidf_(a), sb = qb::sigmoidf_(b);
@@ -194,18 +195,17 @@ __global__ __launch_bounds__(kBlock) void elbo_bwd_kernel(
             // -- are then linear / quadratic in (1, z0, z1): the loop only gathers the draws' five second moments (five
             // instructions per draw besides Philox, instead of thirty-five) and the sums are assembled once per voxel.
             // Valid while the logit clip cannot bind (the same per-wave bound as the forward kernels).
-            constexpr float kZMax = 6.7636f;
+            constexpr float kZMax = QB_Z_MAX;
             const float reach = fmaxf(fabsf(qm.mu_o) + kZMax * qm.e_so, fabsf(qm.mu_d) + kZMax * (fabsf(qm.c) + qm.e_sd));
             if (QB_BWD_WHITENED && __all(reach < QB_LOGIT_CLIP)) {
                 float s0 = 0.0f, s1 = 0.0f, s00 = 0.0f, s11 = 0.0f, s01 = 0.0f;
-                for (int j = part; 2 * j < K; j += LPV) {
-                    float z[4];
-                    const bool two = 2 * j + 1 < K;
-                    qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_KL, z);
-                    n_kl += two ? 2 : 1;
-                    if (!two) z[2] = z[3] = 0.0f;     // an untaken draw adds nothing to any moment
+                for (int g = part; 4 * g < K; g += LPV) {
+                    float z[8];
+                    const int cnt = K - 4 * g < 4 ? K - 4 * g : 4;
+                    qb::normals8(seed, vox, (uint32_t)g, qb::STREAM_KL, cnt, z);   // beyond K: z = 0, adds nothing to any moment
+                    n_kl += cnt;
 #pragma unroll
-                    for (int d = 0; d < 2; ++d) {
+                    for (int d = 0; d < 4; ++d) {
                         const float z0 = z[2 * d], z1 = z[2 * d + 1];
                         s0 += z0;
                         s1 += z1;
@@ -235,14 +235,15 @@ __global__ __launch_bounds__(kBlock) void elbo_bwd_kernel(
                 k_c = B0 * s0 + B1 * s00 + B2 * s01;
                 k_sd = (B0 * s1 + B1 * s01 + B2 * s11) * qm.e_sd;
             } else
-            for (int j = part; 2 * j < K; j += LPV) {
-                float z[4];
-                const bool two = 2 * j + 1 < K;
-                qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_KL, z);
-                n_kl += two ? 2 : 1;
+            for (int g = part; 4 * g < K; g += LPV) {
+                const int cnt = K - 4 * g < 4 ? K - 4 * g : 4;
+                n_kl += cnt;
+                qb::DrawQuad dq;
+                dq.load(seed, vox, (uint32_t)g, qb::STREAM_KL);
 #pragma unroll 1
-                for (int d = 0; d < (two ? 2 : 1); ++d) {
-                    const float z0 = d ? z[2] : z[0], z1 = d ? z[3] : z[1];
+                for (int d = 0; d < cnt; ++d) {
+                    float z0, z1;
+                    dq.next(z0, z1);
                     float a, b;
                     qb::reparam_logits(qm, z0, z1, a, b);
                     const float l0 = qb::clampf_(a, -QB_LOGIT_CLIP, QB_LOGIT_CLIP);

@@ -2,8 +2,8 @@
 // (elbo_kernels.hip) and the fused encoder+ELBO kernel (vi_kernels.hip).
 //
 // A wave owns 16 voxels; the four lanes l, l+16, l+32, l+48 share voxel (l & 15) and split its
-// Monte-Carlo draws by Philox pair index (pair j -> draws 2j, 2j+1; pair j belongs to lane group
-// j & 3).  Everything a lane needs per voxel lives in registers: T normalised data points, T
+// Monte-Carlo draws by Philox call (call g -> draws 4g .. 4g+3, qbold_dev.h; call g belongs to lane group
+// g & 3).  Everything a lane needs per voxel lives in registers: T normalised data points, T
 // inverse sigmas, the transformed posterior / prior parameters.
 #pragma once
 // Wave priorities of the sampling phases (s_setprio; the fused kernel runs its encoder phase at 2-3, see
@@ -21,6 +21,13 @@
 #ifndef QB_GT_DEPTH
 #define QB_GT_DEPTH 8   // table rows requested ahead in the per-tau-table likelihood loop (measured on the fused
                         // kernel, 1 M voxels: 2: 0.4630, 4: 0.4608, 8 = all of a draw's rows: 0.4596 ms)
+#endif
+#ifndef QB_GT_DEPTH_LONG
+#define QB_GT_DEPTH_LONG 2   // the same for protocols of more than 16 taus (T = 24: 34 data registers live; scratch per lane
+                             // 296 / 196 / 144 bytes at depth 8 / 4 / 2 before the rest of the kernel was trimmed)
+#endif
+#ifndef QB_X_DEPTH
+#define QB_X_DEPTH 2    // the same ring on the x-indexed table (compile-time spin-echo kernels without a per-tau table)
 #endif
 #ifndef QB_PRIO_KL
 #define QB_PRIO_KL 2    // round 3, whitened KL loop: 3: 0.4630, 2: 0.4607, 1: 0.4642 ms
@@ -74,16 +81,23 @@ __device__ __forceinline__ float se_norm(const QbDev& c, const float (&v)[T]) {
 // PRESCALE (fast path with a compile-time spin-echo index only): yt holds yt / sigma, see sample_sq_fast.
 // LINEAR: the caller dispatched on the fast path (Gaussian likelihood on linear data), so the log-data and
 // Student-t switches are compiled out (left as run-time selects they cost 11 v_log + 50 selects per tile).
-template <int T, int SE, bool LOGSIG, bool PRESCALE = false, bool LINEAR = false>
+// MIR (with PRESCALE; the protocol mirrors about its spin-echo image, qbold_ctx::grid_mirrors): the signal is even in
+// tau, so tau_{SE+j} and tau_{SE-j} share ONE prediction yh, and their two residuals are one:
+//   (a1 - yh s1)^2 + (a2 - yh s2)^2 = (Q - yh P)^2 + D,   P = sqrt(s1^2 + s2^2),  Q = (a1 s1 + a2 s2) / P,
+//   D = ((a1 s2 - a2 s1) / P)^2                      (a = y / sigma, s = 1 / sigma; exact algebra, no cancellation)
+// The pair is stored as the single data point (Q, P) at index SE + j, its draw-independent remainder D goes into the
+// per-draw constant, and the entries below the spin echo are dead: two registers and two FMAs less per pair and draw
+// (T = 11: 2 pairs, T = 24: 7 -- the 24-tau kernel's spills -- T = 64: 12).
+template <int T, int SE, bool LOGSIG, bool PRESCALE = false, bool LINEAR = false, bool MIR = false>
 __device__ __forceinline__ void prepare_lik(const QbDev& c, const float (&x)[T],
                                             const float (&sigma)[T], float mask, VoxelLik<T>& k) {
+    static_assert(!MIR || (PRESCALE && SE >= 0), "merged mirror pairs need pre-scaled data and a compile-time spin echo");
     const float inv_nt = rcpf_(se_norm<T, SE>(c, x));
     float ls = 0.0f;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         float y = x[t] * inv_nt;
         if (!LINEAR && c.predict_log) y = mask > 0.0f ? __logf(y) : 0.0f;  // model.py:548
-        k.yt[t] = y;
         if (LOGSIG) {
             k.inv_s[t] = exp2f_(-QB_LOG2E * sigma[t]);
             ls += sigma[t];
@@ -91,12 +105,32 @@ __device__ __forceinline__ void prepare_lik(const QbDev& c, const float (&x)[T],
             k.inv_s[t] = rcpf_(sigma[t]);
             ls += QB_LN2 * log2f_(sigma[t]);
         }
+        k.yt[t] = y;
     }
     if (PRESCALE) {
 #pragma unroll
         for (int t = 0; t < T; ++t) k.yt[t] *= k.inv_s[t];
     }
-    k.log_s_sum = (!LINEAR && c.use_student_t) ? ls : ls + (float)T * 0.9189385332046727f;  // log sqrt(2 pi)
+    float half_d = 0.0f;
+    if constexpr (MIR) {
+        constexpr int kSE = SE >= 0 ? SE : 0;
+        float dsum = 0.0f;
+#pragma unroll
+        for (int t = kSE + 1; t < T; ++t) {
+            const int tm = 2 * kSE - t;
+            if (tm >= 0) {
+                const float a1 = k.yt[t], s1 = k.inv_s[t], a2 = k.yt[tm >= 0 ? tm : 0], s2 = k.inv_s[tm >= 0 ? tm : 0];
+                const float p2 = fmaf(s1, s1, s2 * s2);
+                const float ip = __builtin_amdgcn_rsqf(p2);
+                const float cr = fmaf(a1, s2, -(a2 * s1)) * ip;
+                k.inv_s[t] = p2 * ip;
+                k.yt[t] = fmaf(a1, s1, a2 * s2) * ip;
+                dsum = fmaf(cr, cr, dsum);
+            }
+        }
+        half_d = 0.5f * dsum;
+    }
+    k.log_s_sum = ((!LINEAR && c.use_student_t) ? ls : ls + (float)T * 0.9189385332046727f) + half_d;  // log sqrt(2 pi)
     k.mask = mask;
 }
 
@@ -171,14 +205,9 @@ __device__ __forceinline__ float sample_sq_fast(const GtLds<T, SE>* L, const QbD
     }
     // evaluation order: SE + 1 .. T - 1, then the taus below the spin echo that have no partner on the grid
     constexpr int NA = T - 1 - SE, NB = (2 * SE - (T - 1)) > 0 ? 2 * SE - (T - 1) : 0, NE = NA + NB;
-    auto score = [&](int t, float yh) {   // the normalised prediction at tau index t, scored at t and its mirror
-        const float r = fmaf(-yh, k.inv_s[t], k.yt[t]);
-        acc = fmaf(r, r, acc);
-        const int tm = 2 * SE - t;        // the mirrored tau: the signal is even in tau
-        if (t > SE && tm >= 0) {
-            const float r1 = fmaf(-yh, k.inv_s[tm >= 0 ? tm : 0], k.yt[tm >= 0 ? tm : 0]);
-            acc = fmaf(r1, r1, acc);
-        }
+    auto score = [&](int t, float yh) {   // the normalised prediction at tau index t against the data point at t: for
+        const float r = fmaf(-yh, k.inv_s[t], k.yt[t]);   // t > SE with a mirror on the grid that is the MERGED pair
+        acc = fmaf(r, r, acc);                            // (prepare_lik<.., MIR>), the signal being even in tau
     };
     // The rows of a draw sit at immediate offsets from one address, so nothing orders their reads: left alone the
     // compiler requests all of them up front and spills under the fused kernel's 128-register budget.  A ring keeps
@@ -238,7 +267,9 @@ __device__ __forceinline__ float sample_sq_fast(const GtLds<T, SE>* L, const QbD
             score(t, exp2f_(fmaf(fv.nd, F, lt)) + exp2f_(fmaf(fv.ng, st.bb, lb)));
         };
         auto tau_of = [](int e) { return e < NA ? SE + 1 + e : e - NA; };
-        constexpr int D = QB_GT_DEPTH < NE ? QB_GT_DEPTH : NE;
+        constexpr int kDepth = T <= 16 ? QB_GT_DEPTH : QB_GT_DEPTH_LONG;
+        constexpr int D = kDepth < NE ? kDepth : NE;
+        if (qb_phase_fence()) {   // a basic block of its own: see the x-indexed form below
         Stage ring[D + 1];
 #pragma unroll
         for (int e = 0; e < D; ++e) ring[e] = issue(tau_of(e));
@@ -249,11 +280,12 @@ __device__ __forceinline__ float sample_sq_fast(const GtLds<T, SE>* L, const QbD
             finish(tau_of(e), ring[e % (D + 1)]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
         return acc;
     }
 }
 
-template <int T, int SE>
+template <int T, int SE, bool MIR = false>
 __device__ __forceinline__ float sample_sq_fast(const FwdLds* L, const QbDev& c,
                                                 const VoxelLik<T>& k, float oef, float dbv) {
     const FwdFast fv = fwd_fast(c, oef, dbv);
@@ -264,47 +296,58 @@ __device__ __forceinline__ float sample_sq_fast(const FwdLds* L, const QbDev& c,
         //   yhat_t = (tissue_w 2^(nd F_t) + blood_w 2^(ng B_t)) / (s_se + 1e-3)          model.py:545
         // go into the exponents (two log2 per draw instead of three multiplies per tau), and the data
         // arrive pre-divided by sigma (prepare_lik<.., PRESCALE>): r_t = yt_t / s_t - yhat_t / s_t.
-        // tau = 0 at the spin echo (the reference's protocols): x = 0, F(0) = 0 exactly (the table's first
-        // coefficient), so the tissue factor is tissue_w and no lookup is needed -- bit-identical.
+        // MIR (tau = 0 at the spin echo and the grid mirrors about it: the reference's protocols): x = 0 there,
+        // F(0) = 0 exactly (the table's first coefficient), so the tissue factor is tissue_w and no lookup is needed
+        // -- bit-identical.
         constexpr int kSE = SE >= 0 ? SE : 0;
-        const bool se0 = fmaf((float)kSE, c.tauh_step, c.tauh0) == 0.0f;  // uniform: tau = 0 at the spin echo
-        const float s_se = se0 ? fmaf(fv.tissue_w, 1.0f, fv.blood_w * exp2f_(fv.ng * c.blood_B[kSE]))
+        const float s_se = MIR ? fmaf(fv.tissue_w, 1.0f, fv.blood_w * exp2f_(fv.ng * c.blood_B[kSE]))
                                : fwd_signal_fast(L, c, fv, kSE);
         const float inv_np = rcpf_(s_se + 1e-3f);
         const float lt = log2f_(fv.tissue_w * inv_np), lb = log2f_(fv.blood_w * inv_np);  // log2(0) = -inf: term vanishes
-        auto signal = [&](int t) -> float {  // normalised prediction at tau index t
-            const float u = fabsf(fmaf((float)t, fv.ub, fv.ua));
-            const float4 kk = L->tab[(int)u];
-            const float f = __builtin_amdgcn_fractf(u);
-            const float F = fmaf(fmaf(fmaf(kk.w, f, kk.z), f, kk.y), f, kk.x);
-            return exp2f_(fmaf(fv.nd, F, lt)) + exp2f_(fmaf(fv.ng, L->blood_B[t], lb));
-        };
         auto residual = [&](int t, float yh) {
             const float r = fmaf(-yh, k.inv_s[t], k.yt[t]);
             acc = fmaf(r, r, acc);
         };
-        // keep at most two table rows in flight: without a compiler barrier all T LDS reads are hoisted to
-        // the top of the draw and the kernel spills (every 2 taus measured best: 0.611 ms; every 4: 0.612 ms)
         residual(kSE, s_se * inv_np);
-        if (se0) {
-            // The signal is even in tau (|x| enters F, and the blood bracket swaps its two roots), and the
-            // protocol samples both sides of the spin echo on one grid: tau_{SE-j} = -tau_{SE+j}.  Each
-            // mirrored pair is evaluated once (9 evaluations instead of 11 for tau = -16 .. 64 ms).
+        // The evaluated taus: MIR -- SE + 1 .. T - 1 (a mirrored pair is evaluated once, at its tau above the spin
+        // echo, and scored against the pair's merged data point, prepare_lik<.., MIR>; 17 evaluations instead of 24
+        // for tau = -28 .. 64 ms), then the taus below the spin echo that have no partner on the grid; otherwise every
+        // tau but SE.  A ring keeps QB_X_DEPTH table rows in flight, and sched_barrier pins requests AND arithmetic:
+        // left to itself the compiler hoists all T row reads to the top of the draw and spills (with straight-line
+        // code and only a memory clobber every two taus the 24-tau kernel took 550 bytes of scratch per lane).
+        constexpr int NA = T - 1 - kSE, NB = (2 * kSE - (T - 1)) > 0 ? 2 * kSE - (T - 1) : 0;
+        constexpr int NE = MIR ? NA + NB : T - 1;
+        auto tau_of = [](int e) { return MIR ? (e < NA ? kSE + 1 + e : e - NA) : (e < kSE ? e : e + 1); };
+        struct Stage {
+            float4 kk;
+            float f, bb;
+        };
+        auto issue = [&](int t) -> Stage {
+            Stage st;
+            const float u = fabsf(fmaf((float)t, fv.ub, fv.ua));
+            st.kk = L->tab[(int)u];
+            st.f = __builtin_amdgcn_fractf(u);
+            st.bb = L->blood_B[t];
+            return st;
+        };
+        auto finish = [&](int t, const Stage& st) {
+            const float F = fmaf(fmaf(fmaf(st.kk.w, st.f, st.kk.z), st.f, st.kk.y), st.f, st.kk.x);
+            residual(t, exp2f_(fmaf(fv.nd, F, lt)) + exp2f_(fmaf(fv.ng, st.bb, lb)));
+        };
+        constexpr int D = QB_X_DEPTH < NE ? QB_X_DEPTH : NE;
+        // (behind an opaque always-taken branch: as a basic block of its own the tau loop is scheduled and
+        // register-allocated apart from the draw's prologue -- 472 -> 164 bytes of scratch at T = 24, 36 -> 0 at T = 11)
+        if (qb_phase_fence()) {
+        Stage ring[D + 1];
 #pragma unroll
-            for (int t = kSE + 1; t < T; ++t) {
-                const float yh = signal(t);
-                residual(t, yh);
-                if (2 * kSE - t >= 0) residual(2 * kSE - t, yh);
-                if (((t - kSE) % QB_LIK_BARRIER) == 0) asm volatile("" ::: "memory");
-            }
+        for (int e = 0; e < D; ++e) ring[e] = issue(tau_of(e));
 #pragma unroll
-            for (int t = 0; t < 2 * kSE - (T - 1); ++t) residual(t, signal(t));  // no partner on the grid
-        } else {
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                if (t != kSE) residual(t, signal(t));
-                if ((t & 1) == 1) asm volatile("" ::: "memory");
-            }
+        for (int e = 0; e < NE; ++e) {
+            if (e + D < NE) ring[(e + D) % (D + 1)] = issue(tau_of(e + D));
+            __builtin_amdgcn_sched_barrier(0);
+            finish(tau_of(e), ring[e % (D + 1)]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         }
         return acc;
     }
@@ -351,13 +394,14 @@ __device__ __forceinline__ float kl_swr_diff(const LogitMvn& q, const LogitMvn& 
 // fixed per voxel: swr_p - swr_q = |d + M z|^2 - |z|^2, seven instructions per draw instead of nineteen, no logits
 // formed (and none of their cancellation: against the float64 oracle this form is at 2e-6 where the general one --
 // the reference's arithmetic -- is at 8e-4 for far-apart q and prior).  Valid while the clip of the logits at
-// +-13.8155 (model.py:393-396) cannot bind: Box-Muller on u >= 2^-33 bounds |z| by 6.7636, so it cannot when
-// |mu| + 6.7636 (|c| + e^s) stays below the clip for both logits.  Decided per wave (any lane over the bound, or
-// explicit normals: the general loop for all).
+// +-13.8155 (model.py:393-396) cannot bind: Box-Muller on u1 >= 2^-17 bounds |z| by 4.8549 (QB_Z_MAX), so it cannot
+// when
+// |mu| + 4.8549 (|c| + e^s) stays below the clip for both logits (rounds 1-3: 6.7636 with 32-bit uniforms).  Decided per
+// wave (any lane over the bound, or explicit normals: the general loop for all).
 __device__ __forceinline__ float kl_draws_fast(const LogitMvn& q, const LogitMvn& prior, int K,
                                                const float* __restrict__ zk, uint64_t seed, uint64_t vox, int part,
                                                int& n_kl) {
-    constexpr float kZMax = 6.7636f;
+    constexpr float kZMax = QB_Z_MAX;
     const float reach = fmaxf(fabsf(q.mu_o) + kZMax * q.e_so, fabsf(q.mu_d) + kZMax * (fabsf(q.c) + q.e_sd));
     float kl_sum = 0.0f;
     if (zk == nullptr && __all(reach < QB_LOGIT_CLIP)) {
@@ -365,18 +409,34 @@ __device__ __forceinline__ float kl_draws_fast(const LogitMvn& q, const LogitMvn
         const float d0 = dmu_o * prior.i_so, m00 = q.e_so * prior.i_so;
         const float d1 = fmaf(dmu_d, prior.i_sd, dmu_o * prior.i_bl);
         const float m10 = fmaf(q.c, prior.i_sd, q.e_so * prior.i_bl), m11 = q.e_sd * prior.i_sd;
-        float sp = 0.0f, sq = 0.0f, untaken = 0.0f;
-        for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
-            float z[4];
-            const bool two = 2 * j + 1 < K;
-            n_kl += two ? 2 : 1;
-            normals4(seed, vox, (uint32_t)j, STREAM_KL, z);
-            if (!two) {   // an odd K: the pair's second draw is not taken -- with z = 0 it adds |d|^2, removed below
-                z[2] = z[3] = 0.0f;
-                untaken = fmaf(d0, d0, d1 * d1);
+        float sp = 0.0f, sq = 0.0f;
+        int untaken = 0;
+#ifdef QB_EXP_KL_SERIAL
+        for (int g = part; 4 * g < K; g += QB_LANES_PER_VOXEL) {
+            const int cnt = K - 4 * g < 4 ? K - 4 * g : 4;
+            n_kl += cnt;
+            DrawQuad dq;
+            dq.load(seed, vox, (uint32_t)g, STREAM_KL);
+#pragma unroll 1
+            for (int d = 0; d < cnt; ++d) {
+                float z0, z1;
+                dq.next(z0, z1);
+                const float w0 = fmaf(m00, z0, d0), w1 = fmaf(m11, z1, fmaf(m10, z0, d1));
+                sp = fmaf(w0, w0, sp);
+                sp = fmaf(w1, w1, sp);
+                sq = fmaf(z0, z0, sq);
+                sq = fmaf(z1, z1, sq);
             }
+        }
+#else
+        for (int g = part; 4 * g < K; g += QB_LANES_PER_VOXEL) {
+            float z[8];
+            const int cnt = K - 4 * g < 4 ? K - 4 * g : 4;
+            n_kl += cnt;
+            untaken += 4 - cnt;
+            normals8(seed, vox, (uint32_t)g, STREAM_KL, cnt, z);   // draws beyond K: z = 0, each adds |d|^2 (removed below)
 #pragma unroll
-            for (int d = 0; d < 2; ++d) {
+            for (int d = 0; d < 4; ++d) {
                 const float w0 = fmaf(m00, z[2 * d], d0), w1 = fmaf(m11, z[2 * d + 1], fmaf(m10, z[2 * d], d1));
                 sp = fmaf(w0, w0, sp);
                 sp = fmaf(w1, w1, sp);
@@ -384,22 +444,25 @@ __device__ __forceinline__ float kl_draws_fast(const LogitMvn& q, const LogitMvn
                 sq = fmaf(z[2 * d + 1], z[2 * d + 1], sq);
             }
         }
-        return (sp - untaken) - sq;
+#endif
+        return fmaf(-(float)untaken, fmaf(d0, d0, d1 * d1), sp) - sq;
     }
-    for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
-        float z[4];
-        const bool two = 2 * j + 1 < K;
-        n_kl += two ? 2 : 1;
-        if (zk) {
-            z[0] = zk[4 * j];
-            z[1] = zk[4 * j + 1];
-            z[2] = two ? zk[4 * j + 2] : 0.0f;
-            z[3] = two ? zk[4 * j + 3] : 0.0f;
-        } else {
-            normals4(seed, vox, (uint32_t)j, STREAM_KL, z);
+    for (int g = part; 4 * g < K; g += QB_LANES_PER_VOXEL) {
+        const int cnt = K - 4 * g < 4 ? K - 4 * g : 4;
+        n_kl += cnt;
+        DrawQuad dq;
+        if (!zk) dq.load(seed, vox, (uint32_t)g, STREAM_KL);
+#pragma unroll 1
+        for (int d = 0; d < cnt; ++d) {
+            float z0, z1;
+            if (zk) {
+                z0 = zk[2 * (4 * g + d)];
+                z1 = zk[2 * (4 * g + d) + 1];
+            } else {
+                dq.next(z0, z1);
+            }
+            kl_sum += kl_swr_diff(q, prior, z0, z1);
         }
-        kl_sum += kl_swr_diff(q, prior, z[0], z[1]);
-        if (two) kl_sum += kl_swr_diff(q, prior, z[2], z[3]);
     }
     return kl_sum;
 }
@@ -409,7 +472,8 @@ __device__ __forceinline__ float kl_draws_fast(const LogitMvn& q, const LogitMvn
 //   kl_sum  = sum over this half's KL draws of log q(y) - log p(y)          model.py:596-603
 // zs / zk: explicit normals of this voxel ([S][2] / [K][2]) or nullptr for the Philox stream.
 // FAST: requires c.full_model, table mode, !predict_log, !use_student_t (checked on the host).
-template <int T, int SE, bool FAST, bool LITERAL, class LDS>
+// MIR: `lik` was prepared with merged mirror pairs (prepare_lik<.., MIR>; always with the per-tau table).
+template <int T, int SE, bool FAST, bool LITERAL, bool MIR = false, class LDS>
 __device__ __forceinline__ void voxel_mc_sums(const LDS* L, const QbDev& c,
                                               const VoxelLik<T>& lik, const LogitMvn& q,
                                               const float* __restrict__ prior_row, int S, int K,
@@ -420,29 +484,65 @@ __device__ __forceinline__ void voxel_mc_sums(const LDS* L, const QbDev& c,
     nll_sum = 0.0f;
     kl_sum = 0.0f;
     int n_lik = 0, n_kl = 0;  // draws taken by this lane
+    // Across the likelihood loop only what the reparameterisation reads stays live (mu, e^s, c) plus the one number
+    // the KL's constant needs; the inverse scales come back from two reciprocals afterwards (five registers less
+    // through the loop that owns the register budget).
+    const float q_s_sum = q.s_o + q.s_d;
     __builtin_amdgcn_s_setprio(QB_PRIO_LIK);
+#ifdef QB_EXP_PAIR_LIK
     for (int j = part; 2 * j < S; j += QB_LANES_PER_VOXEL) {
         float z[4];
         const bool two = 2 * j + 1 < S;
         n_lik += two ? 2 : 1;
-        if (zs) {
-            z[0] = zs[4 * j];
-            z[1] = zs[4 * j + 1];
-            z[2] = two ? zs[4 * j + 2] : 0.0f;
-            z[3] = two ? zs[4 * j + 3] : 0.0f;
-        } else {
-            normals4(seed, vox, (uint32_t)j, STREAM_LIK, z);
-        }
-        // one draw at a time (not unrolled): two draws in flight double the live registers
+        normals4(seed, vox, (uint32_t)j, STREAM_LIK, z);
 #pragma unroll 1
         for (int d = 0; d < (two ? 2 : 1); ++d) {
             float a, b, oef, dbv;
             reparam_logits(q, d ? z[2] : z[0], d ? z[3] : z[1], a, b);
             forward_transform(a, b, oef, dbv);
-            if constexpr (FAST) nll_sum += sample_sq_fast<T, SE>(L, c, lik, oef, dbv);
+            if constexpr (FAST && IsGtLds<LDS>::value) nll_sum += sample_sq_fast<T, SE>(L, c, lik, oef, dbv);
+            else if constexpr (FAST) nll_sum += sample_sq_fast<T, SE, MIR>(L, c, lik, oef, dbv);
             else nll_sum += sample_nll<T, SE, LITERAL>(L, c, lik, oef, dbv);
         }
     }
+#else
+    // This lane's draws: Philox calls part, part + 4, ... -> draws 4 g .. 4 g + 3 each, the last call possibly short.
+    // ONE loop over them (a call's words are refilled every fourth trip): nested as calls x draws the register
+    // allocator split far more live ranges around the inner loop (612 against 88 bytes of scratch at T = 24).
+    {
+        const int calls = S > 4 * part ? (S - 4 * part + 15) / 16 : 0;           // calls g = part + 4 k < ceil(S / 4)
+        const int last = calls > 0 ? S - 4 * (part + 4 * (calls - 1)) : 0;      // draws of the last call: 1 .. 4
+        n_lik = calls > 0 ? 4 * (calls - 1) + (last < 4 ? last : 4) : 0;
+        DrawQuad dq;
+        uint32_t g = (uint32_t)part;
+#pragma unroll 1
+        for (int i = 0; i < n_lik; ++i) {
+            float z0, z1;
+            if (zs) {
+                const int draw = 4 * (part + 4 * (i >> 2)) + (i & 3);
+                z0 = zs[2 * draw];
+                z1 = zs[2 * draw + 1];
+            } else {
+                if ((i & 3) == 0) {
+                    dq.load(seed, vox, g, STREAM_LIK);
+                    g += QB_LANES_PER_VOXEL;
+                }
+                dq.next(z0, z1);
+            }
+            float a, b, oef, dbv;
+            reparam_logits(q, z0, z1, a, b);
+            forward_transform(a, b, oef, dbv);
+            if constexpr (FAST && IsGtLds<LDS>::value) {
+                static_assert(!IsGtLds<LDS>::value || MIR, "the per-tau table scores merged mirror pairs");
+                nll_sum += sample_sq_fast<T, SE>(L, c, lik, oef, dbv);
+            } else if constexpr (FAST) {
+                nll_sum += sample_sq_fast<T, SE, MIR>(L, c, lik, oef, dbv);
+            } else {
+                nll_sum += sample_nll<T, SE, LITERAL>(L, c, lik, oef, dbv);
+            }
+        }
+    }
+#endif
     if (FAST) {  // sum_d [0.5 sum_t r^2 + sum_t log sigma + T log sqrt(2 pi)] over this lane's draws
         nll_sum = fmaf(0.5f, nll_sum, (float)n_lik * lik.log_s_sum);
     }
@@ -454,7 +554,13 @@ __device__ __forceinline__ void voxel_mc_sums(const LDS* L, const QbDev& c,
     const LogitMvn prior = make_mvn(pv);
     __builtin_amdgcn_s_setprio(QB_PRIO_KL);
     if constexpr (FAST) {
-        kl_sum = kl_draws_fast(q, prior, K, zk, seed, vox, part, n_kl);
+        LogitMvn qk;
+        qk.mu_o = q.mu_o; qk.mu_d = q.mu_d; qk.c = q.c; qk.e_so = q.e_so; qk.e_sd = q.e_sd;
+        qk.s_o = q_s_sum; qk.s_d = 0.0f;                  // only their sum is used below
+        qk.i_so = rcpf_(q.e_so);
+        qk.i_sd = rcpf_(q.e_sd);
+        qk.i_bl = -(qk.i_so * qk.i_sd) * q.c;
+        kl_sum = kl_draws_fast(qk, prior, K, zk, seed, vox, part, n_kl);
     } else {
         for (int j = part; 2 * j < K; j += QB_LANES_PER_VOXEL) {
             float z[4];
@@ -482,7 +588,7 @@ __device__ __forceinline__ void voxel_mc_sums(const LDS* L, const QbDev& c,
     }
     __builtin_amdgcn_s_setprio(QB_PRIO_AFTER);
     if (FAST) {  // log q - log p = 0.5 (swr_p - swr_q) + (s_o + s_d)_p - (s_o + s_d)_q per draw
-        kl_sum = fmaf(0.5f, kl_sum, (float)n_kl * ((prior.s_o + prior.s_d) - (q.s_o + q.s_d)));
+        kl_sum = fmaf(0.5f, kl_sum, (float)n_kl * ((prior.s_o + prior.s_d) - q_s_sum));
     }
 }
 

@@ -21,7 +21,9 @@ template <int T, int SE>
 struct ElboLds<T, SE, true> { using type = qb::GtLds<T, SE>; };
 
 // GT: per-tau OEF-indexed table (GtLds) instead of the x-indexed one; needs FAST and a compile-time spin echo.
-template <int T, int SE, bool FAST, bool LITERAL, bool GT = false>
+// MIR: the protocol mirrors about the spin echo (qbold_ctx::grid_mirrors): mirrored tau pairs are evaluated once and
+// scored as one merged data point (elbo_core.h, prepare_lik); GT implies it.
+template <int T, int SE, bool FAST, bool LITERAL, bool GT = false, bool MIR = false>
 __global__ __launch_bounds__(kBlock) void elbo_fwd_kernel(
     QbDev c, const float4* __restrict__ g_tab, const float* __restrict__ x,
     const float* __restrict__ mask, const float* __restrict__ q, const float* __restrict__ prior,
@@ -31,6 +33,8 @@ __global__ __launch_bounds__(kBlock) void elbo_fwd_kernel(
     // same choice of sampling table as the fused kernel (vi_kernels.hip), so that the fused and the unfused
     // evaluation of a voxel run the same arithmetic
     static_assert(!GT || (FAST && SE >= 0 && qb::gtab_segs(T) > 0), "GT needs the fast path with a compile-time spin echo");
+    static_assert(!MIR || (FAST && SE >= 0), "merged mirror pairs: fast path with a compile-time spin echo");
+    constexpr bool kMir = GT || MIR;
     using Lds = typename ElboLds<T, SE, GT>::type;
     __shared__ Lds L;
     __shared__ double red[3 * (kBlock / 64)];
@@ -59,10 +63,10 @@ __global__ __launch_bounds__(kBlock) void elbo_fwd_kernel(
             for (int i = 0; i < 5; ++i) qv[i] = q[v * 5 + i];
             const float m = mask ? mask[v] : 1.0f;
             qb::VoxelLik<T> lik;
-            qb::prepare_lik<T, SE, false, (FAST && SE >= 0), FAST>(c, xv, sv, m, lik);
+            qb::prepare_lik<T, SE, false, (FAST && SE >= 0), FAST, kMir>(c, xv, sv, m, lik);
             const qb::LogitMvn qm = qb::make_mvn(qv);
             float nll_part, kl_part;
-            qb::voxel_mc_sums<T, SE, FAST, LITERAL>(&L, c, lik, qm, prior + v * 5, S, K, zs ? zs + v * S * 2 : nullptr,
+            qb::voxel_mc_sums<T, SE, FAST, LITERAL, kMir>(&L, c, lik, qm, prior + v * 5, S, K, zs ? zs + v * S * 2 : nullptr,
                                           zk ? zk + v * K * 2 : nullptr, seed,
                                           (uint64_t)(voxel0 + v), part, nll_part, kl_part);
             // the four lanes of a voxel are active together (v depends on lane & 15 only)
@@ -138,22 +142,22 @@ __global__ __launch_bounds__(kGenBlock) void elbo_fwd_generic_kernel(
             const float* zkv = zk ? zk + v * K * 2 : nullptr;
             float nll_sum = 0.0f, kl_sum = 0.0f;
             int n_lik = 0, n_kl = 0;
-            for (int j = part; 2 * j < S; j += QB_LANES_PER_VOXEL) {
-                float z[4];
-                const bool two = 2 * j + 1 < S;
-                if (zsv) {
-                    z[0] = zsv[4 * j];
-                    z[1] = zsv[4 * j + 1];
-                    z[2] = two ? zsv[4 * j + 2] : 0.0f;
-                    z[3] = two ? zsv[4 * j + 3] : 0.0f;
-                } else {
-                    qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_LIK, z);
-                }
-                n_lik += two ? 2 : 1;
+            for (int g = part; 4 * g < S; g += QB_LANES_PER_VOXEL) {
+                const int cnt = S - 4 * g < 4 ? S - 4 * g : 4;
+                n_lik += cnt;
+                qb::DrawQuad dq;
+                if (!zsv) dq.load(seed, vox, (uint32_t)g, qb::STREAM_LIK);
 #pragma unroll 1
-                for (int d = 0; d < (two ? 2 : 1); ++d) {
+                for (int d = 0; d < cnt; ++d) {
+                    float z0, z1;
+                    if (zsv) {
+                        z0 = zsv[2 * (4 * g + d)];
+                        z1 = zsv[2 * (4 * g + d) + 1];
+                    } else {
+                        dq.next(z0, z1);
+                    }
                     float a, b, oef, dbv;
-                    qb::reparam_logits(qm, d ? z[2] : z[0], d ? z[3] : z[1], a, b);
+                    qb::reparam_logits(qm, z0, z1, a, b);
                     qb::forward_transform(a, b, oef, dbv);
                     const qb::FwdFast fv = qb::fwd_fast(c, oef, dbv);
                     if (mirrored) {
@@ -292,22 +296,22 @@ __global__ __launch_bounds__(kLdsBlock) void elbo_fwd_lds_kernel(
             float nll_sum = 0.0f, kl_sum = 0.0f;
             int n_lik = 0, n_kl = 0;
             __builtin_amdgcn_s_setprio(QB_PRIO_LIK);
-            for (int j = part; 2 * j < S; j += QB_LANES_PER_VOXEL) {
-                float z[4];
-                const bool two = 2 * j + 1 < S;
-                if (zsv) {
-                    z[0] = zsv[4 * j];
-                    z[1] = zsv[4 * j + 1];
-                    z[2] = two ? zsv[4 * j + 2] : 0.0f;
-                    z[3] = two ? zsv[4 * j + 3] : 0.0f;
-                } else {
-                    qb::normals4(seed, vox, (uint32_t)j, qb::STREAM_LIK, z);
-                }
-                n_lik += two ? 2 : 1;
+            for (int g = part; 4 * g < S; g += QB_LANES_PER_VOXEL) {
+                const int cnt = S - 4 * g < 4 ? S - 4 * g : 4;
+                n_lik += cnt;
+                qb::DrawQuad dq;
+                if (!zsv) dq.load(seed, vox, (uint32_t)g, qb::STREAM_LIK);
 #pragma unroll 1
-                for (int d = 0; d < (two ? 2 : 1); ++d) {
+                for (int d = 0; d < cnt; ++d) {
+                    float z0, z1;
+                    if (zsv) {
+                        z0 = zsv[2 * (4 * g + d)];
+                        z1 = zsv[2 * (4 * g + d) + 1];
+                    } else {
+                        dq.next(z0, z1);
+                    }
                     float a, b, oef, dbv;
-                    qb::reparam_logits(qm, d ? z[2] : z[0], d ? z[3] : z[1], a, b);
+                    qb::reparam_logits(qm, z0, z1, a, b);
                     qb::forward_transform(a, b, oef, dbv);
                     const qb::FwdFast fv = qb::fwd_fast(c, oef, dbv);
                     // tau = 0 at the spin echo (checked by the host dispatch): F(0) = 0, no table row
@@ -641,6 +645,10 @@ int elbo_fwd_launch(const qbold_ctx* ctx, const float* x, const float* mask, con
     hipLaunchKernelGGL((elbo_fwd_kernel<TT, SE, FAST, LIT>), dim3(grid), dim3(kBlock), 0, s,      \
                        ctx->dev, ctx->d_tab, x, mask, q, prior, sigma, zs, zk, S, K, seed, voxel0, \
                        out, partials, N)
+#define QB_LAUNCH_ELBO_MIR(TT, SE)                                                               \
+    hipLaunchKernelGGL((elbo_fwd_kernel<TT, SE, true, false, false, true>), dim3(grid), dim3(kBlock), 0, s, \
+                       ctx->dev, ctx->d_tab, x, mask, q, prior, sigma, zs, zk, S, K, seed, voxel0, \
+                       out, partials, N)
 #define QB_LAUNCH_ELBO_GT(TT, SE)                                                                \
     hipLaunchKernelGGL((elbo_fwd_kernel<TT, SE, true, false, (qb::gtab_segs(TT) > 0)>), dim3(grid), dim3(kBlock), 0, s, \
                        ctx->dev, ctx->d_gtab, x, mask, q, prior, sigma, zs, zk, S, K, seed, voxel0, \
@@ -672,6 +680,7 @@ int elbo_fwd_launch(const qbold_ctx* ctx, const float* x, const float* mask, con
     } else switch (ctx->dev.T) {
         case 11:
             if (fast && ctx->dev.se_idx == 2 && !ctx->dev.multi_norm && gt) QB_LAUNCH_ELBO_GT(11, 2);
+            else if (fast && ctx->dev.se_idx == 2 && !ctx->dev.multi_norm && ctx->grid_mirrors) QB_LAUNCH_ELBO_MIR(11, 2);
             else if (fast && ctx->dev.se_idx == 2 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(11, 2, true, false);
             else if (fast) QB_LAUNCH_ELBO(11, -1, true, false);
             else if (lit && ctx->dev.se_idx == 2 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(11, 2, false, true);
@@ -680,6 +689,7 @@ int elbo_fwd_launch(const qbold_ctx* ctx, const float* x, const float* mask, con
             break;
         case 24:  // the reference's second protocol (signals.py:120-121); se_idx = 7
             if (fast && ctx->dev.se_idx == 7 && !ctx->dev.multi_norm && gt) QB_LAUNCH_ELBO_GT(24, 7);
+            else if (fast && ctx->dev.se_idx == 7 && !ctx->dev.multi_norm && ctx->grid_mirrors) QB_LAUNCH_ELBO_MIR(24, 7);
             else if (fast && ctx->dev.se_idx == 7 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(24, 7, true, false);
             else if (fast) QB_LAUNCH_ELBO(24, -1, true, false);
             else if (lit && ctx->dev.se_idx == 7 && !ctx->dev.multi_norm) QB_LAUNCH_ELBO(24, 7, false, true);
@@ -701,6 +711,8 @@ int elbo_fwd_launch(const qbold_ctx* ctx, const float* x, const float* mask, con
         }
     }
 #undef QB_LAUNCH_ELBO
+#undef QB_LAUNCH_ELBO_MIR
+#undef QB_LAUNCH_ELBO_GT
     QB_HIP(hipGetLastError());
     hipLaunchKernelGGL(qb::reduce_partials_kernel, dim3(1), dim3(192), 0, s, partials, grid, sums);
     QB_HIP(hipGetLastError());

@@ -20,6 +20,7 @@ struct qbold_ctx {
     float4* d_gtab = nullptr;       // per-tau OEF-indexed table of the sampling fast path (qbold_dev.h, GtLds)
     std::vector<float> h_gtab;      // host copy: [j - 1][segment][4]
     bool gtab_ok = false;           // built: T = 11, spin echo at index 2 with tau = 0 there, taus mirrored about it
+    bool grid_mirrors = false;      // tau = 0 at the spin-echo image and the taus mirror about it (ctx.hip)
     int num_cus = 256;
     float dF_node0_ref = 0.0f;      // TF-gradient slope of Simpson node 0 (see qbold_ctx_set_grad_node0)
     int kernel_sel = 0;             // qbold_ctx_set_kernel_selection: which of several EQUIVALENT kernels runs

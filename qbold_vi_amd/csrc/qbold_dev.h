@@ -224,14 +224,21 @@ struct DrawQuad {
     }
 };
 
-// normals of draws (4 quad .. 4 quad + 3): z[2 d], z[2 d + 1] for draw 4 quad + d
-__device__ __forceinline__ void normals8(uint64_t seed, uint64_t vox, uint32_t quad, uint32_t stream, float z[8]) {
+// normals of draws (4 quad .. 4 quad + 3): z[2 d], z[2 d + 1] for draw 4 quad + d; the draws d >= cnt (beyond the
+// number asked for) come out as exact zeros -- one select on the radius each
+__device__ __forceinline__ void normals8(uint64_t seed, uint64_t vox, uint32_t quad, uint32_t stream, int cnt, float z[8]) {
     const uint4 o = philox4x32_7(make_uint4((uint32_t)vox, (uint32_t)(vox >> 32), quad, stream),
                                  make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
-    box_muller16(o.x, z[0], z[1]);
-    box_muller16(o.y, z[2], z[3]);
-    box_muller16(o.z, z[4], z[5]);
-    box_muller16(o.w, z[6], z[7]);
+    const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const float u1 = fmaf((float)(w[d] >> 16), 0x1p-16f, 0x1p-17f);
+        const float th = (float)(w[d] & 0xffffu) * 0x1p-16f;
+        float r = __builtin_amdgcn_sqrtf((-2.0f * QB_LN2) * log2f_(u1));
+        if (d > 0) r = d < cnt ? r : 0.0f;
+        z[2 * d] = r * __builtin_amdgcn_cosf(th);
+        z[2 * d + 1] = r * __builtin_amdgcn_sinf(th);
+    }
 }
 
 // normals of draws (2*pair, 2*pair+1) of `stream` for global voxel `vox`: half a Philox call's words (the kernels off
@@ -343,9 +350,14 @@ __host__ __device__ constexpr int gtab_taus(int T, int SE) { return SE > T - 1 -
 #ifndef QB_GT_SEGS_11
 #define QB_GT_SEGS_11 138
 #endif
-// T = 24 keeps the x-indexed table: 52 segments would fit beside its weight image, but with 48 data registers live the
-// ring spills (0.947 against 0.755 ms per 1 M voxels, measured)
-__host__ __device__ constexpr int gtab_segs(int T) { return T == 11 ? QB_GT_SEGS_11 : 0; }
+// T = 24: 16 taus x 52 segments = 13 KiB is what the LDS has left beside that protocol's larger weight image (max
+// |G - F| = 2.3e-5 at 64 ms, i.e. <= 4.7e-6 of the signal at DBV = 0.2).  Round 3 measured this form slower (0.947
+// against 0.755 ms): with 48 data registers live its row ring spilled; with the mirrored pairs merged (34 data registers,
+// elbo_core.h) it fits.
+#ifndef QB_GT_SEGS_24
+#define QB_GT_SEGS_24 52
+#endif
+__host__ __device__ constexpr int gtab_segs(int T) { return T == 11 ? QB_GT_SEGS_11 : (T == 24 ? QB_GT_SEGS_24 : 0); }
 // Pair-interleaved rows (QB_GT_PAIRS): when every evaluated tau lies above the spin echo and they come in pairs, rows
 // 2p and 2p + 1 of the table hold (c0a, c0b, c1a, c1b) and (c2a, c2b, c3a, c3b) of taus j = 2p + 1 (a) and 2p + 2 (b),
 // so that a row read delivers aligned float32 pairs for v_pk_fma_f32 (elbo_core.h).  Measured and NOT adopted: 137

@@ -69,7 +69,9 @@ constexpr size_t kLdsLimit = 160 * 1024;   // gfx950: LDS per workgroup
 
 // GT: the sampling fast path reads the per-tau OEF-indexed table (GtLds) instead of the x-indexed one (FwdLds);
 // requires FAST and a compile-time spin-echo index.
-template <int T, int NL, int SE, bool FAST, bool LITERAL, bool BF, bool GT = false>
+// MIR: the protocol mirrors about the spin echo (qbold_ctx::grid_mirrors): mirrored tau pairs are evaluated once and
+// scored as one merged data point (elbo_core.h, prepare_lik); GT implies it.
+template <int T, int NL, int SE, bool FAST, bool LITERAL, bool BF, bool GT = false, bool MIR = false>
 __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
     QbDev c, const float4* __restrict__ g_tab, const float* __restrict__ packed,
     const float* __restrict__ x, const float* __restrict__ mask, const float* __restrict__ prior,
@@ -80,6 +82,8 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
     // the sampling phase's table: per-tau OEF-indexed rows (GtLds) on the fast path with a compile-time spin-echo
     // index, the x-indexed table + literal nodes (FwdLds) otherwise; g_tab points at the matching device table
     static_assert(!GT || (FAST && SE >= 0 && qb::gtab_segs(T) > 0), "GT needs the fast path with a compile-time spin echo");
+    static_assert(!MIR || (FAST && SE >= 0), "merged mirror pairs: fast path with a compile-time spin echo");
+    constexpr bool kMir = GT || MIR;
     using Lds = typename ViLds<T, SE, GT>::type;
     extern __shared__ __align__(16) unsigned char smem[];
     float* lds_w = reinterpret_cast<float*>(smem);
@@ -95,12 +99,20 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
     __syncthreads();
 
     constexpr int HT = (5 + T + 15) / 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, i = lane & 15;
+    const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float s_nll = 0.0f, s_kl = 0.0f, s_m = 0.0f;
     const int64_t ntile = (N + 15) / 16;
     for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntile;
          tile += (int64_t)gridDim.x * kWaves) {
+        // The lane index is made opaque once per tile: everything derived from it (the encoder's LDS fragment
+        // addresses, the voxel's row pointers) is then recomputed per tile -- a handful of vector instructions --
+        // instead of being hoisted out of the tile loop as 20-70 loop-invariant registers that the sampling phase
+        // (which needs none of them) has to spill and reload around itself.
+        int lane = lane0;
+#ifndef QB_EXP_NO_LANE_LAUNDER
+        asm volatile("" : "+v"(lane));
+#endif
+        const int g = lane >> 4, i = lane & 15;
         const int64_t v = tile * 16 + i;
         const int64_t vc = v < N ? v : N - 1;
         float o[5 + T];
@@ -136,25 +148,32 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
             for (int k = 0; k < 5; ++k) qv[k] = o[k];
 #pragma unroll
             for (int t = 0; t < T; ++t) sv[t] = o[5 + t];  // log sigma; sigma = exp(.), model.py:214
-            const float m = mask ? mask[v] : 1.0f;
+            // the mask: the likelihood needs it only on log data (model.py:548); the sums read it again after the draws
+            // (a second load through an opaque pointer) instead of carrying it through the loops
             qb::VoxelLik<T> lik;
-            qb::prepare_lik<T, SE, true, (FAST && SE >= 0), FAST>(c, xv, sv, m, lik);
+            qb::prepare_lik<T, SE, true, (FAST && SE >= 0), FAST, kMir>(c, xv, sv, FAST ? 1.0f : (mask ? mask[v] : 1.0f), lik);
             const qb::LogitMvn qm = qb::make_mvn(qv);
+            // posterior parameters leave before the draws (lane group 1), so that they do not live through them
+            if (g == 1 && q_out) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) q_out[v * 5 + k] = qv[k];
+            }
+            // an activation beyond the f16 operand range: this voxel's terms become NaN (never a silent clamp) -- through
+            // the per-draw constant, which every draw's NLL adds
+            if (!BF && qb::split_overflowed(amax)) lik.log_s_sum = __builtin_nanf("");
             float nll_part, kl_part;
-            qb::voxel_mc_sums<T, SE, FAST, LITERAL>(L, c, lik, qm, prior + v * 5, S, K, nullptr, nullptr, seed,
+            qb::voxel_mc_sums<T, SE, FAST, LITERAL, kMir>(L, c, lik, qm, prior + v * 5, S, K, nullptr, nullptr, seed,
                                                     (uint64_t)(voxel0 + v), g, nll_part, kl_part);
-            // an activation beyond the f16 operand range: this voxel's terms become NaN (never a silent clamp)
-            if (!BF && qb::split_overflowed(amax)) nll_part = __builtin_nanf("");
             const float nll = qb::voxel_sum(nll_part) / (float)S;
             const float kl = K > 0 ? qb::voxel_sum(kl_part) / (float)K : 0.0f;
             if (g == 0) {
+                const float* mp = mask;
+                asm volatile("" : "+v"(mp));
+                const float m = mp ? mp[v] : 1.0f;
                 if (nll_kl) nll_kl[v] = make_float2(nll, kl);
                 s_nll += nll * m;              // model.py:564
                 s_kl += m > 0.0f ? kl : 0.0f;  // model.py:661
                 s_m += m;
-            } else if (g == 1 && q_out) {
-#pragma unroll
-                for (int k = 0; k < 5; ++k) q_out[v * 5 + k] = qv[k];
             }
         }
     }
@@ -222,16 +241,16 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     // configuration); the literal and generic paths exist to reproduce float32 semantics
     QB_REQUIRE(!bf || qb::elbo_fast_path(ctx),
                "qbold_vi_fwd: QBOLD_ENC_BF16 needs the table-mode Gaussian fast path");
-#define QB_LAUNCH_VI(TT, NL, SE, FAST, LIT) QB_LAUNCH_VI_GT(TT, NL, SE, FAST, LIT, false)
-#define QB_LAUNCH_VI_GT(TT, NL, SE, FAST, LIT, GT)                                                   \
+#define QB_LAUNCH_VI(TT, NL, SE, FAST, LIT) QB_LAUNCH_VI_GT(TT, NL, SE, FAST, LIT, false, false)
+#define QB_LAUNCH_VI_GT(TT, NL, SE, FAST, LIT, GT, MIR)                                              \
     do {                                                                                          \
         using LdsT = typename ViLds<TT, SE, GT>::type;                                             \
         constexpr size_t smem = sizeof(float) * qb::make_enc_layout(TT, 64, NL).total + sizeof(LdsT) + \
                                 sizeof(double) * 3 * kWaves;                                       \
         static_assert(smem <= kLdsLimit, "weight image + sampling table exceed the LDS");          \
         const float4* tab = qb::IsGtLds<LdsT>::value ? ctx->d_gtab : ctx->d_tab;                    \
-        auto k = vi_fwd_kernel<TT, NL, SE, FAST, LIT, false, GT>;                                  \
-        if constexpr (FAST) { if (bf) k = vi_fwd_kernel<TT, NL, SE, FAST, LIT, true, GT>; }        \
+        auto k = vi_fwd_kernel<TT, NL, SE, FAST, LIT, false, GT, MIR>;                             \
+        if constexpr (FAST) { if (bf) k = vi_fwd_kernel<TT, NL, SE, FAST, LIT, true, GT, MIR>; }   \
         QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                              \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));       \
         hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), smem, s, ctx->dev, tab, packed,            \
@@ -241,17 +260,23 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     // SEC: the protocol's spin-echo index (tau = 0), folded at compile time when the context agrees
 #define QB_DISPATCH_VI(TT, NL, SEC)                                               \
     do {                                                                          \
-        if (qb::gtab_segs(TT) > 0 && fast && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm && !(ctx->kernel_sel & 4) && ctx->gtab_ok && !(ctx->kernel_sel & 8)) QB_LAUNCH_VI_GT(TT, NL, SEC, true, false, (qb::gtab_segs(TT) > 0));   \
+        if (qb::gtab_segs(TT) > 0 && fast && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm && !(ctx->kernel_sel & 4) && ctx->gtab_ok && !(ctx->kernel_sel & 8)) QB_LAUNCH_VI_GT(TT, NL, SEC, true, false, (qb::gtab_segs(TT) > 0), false);   \
+        else if (fast && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm && !(ctx->kernel_sel & 4) && ctx->grid_mirrors) QB_LAUNCH_VI_GT(TT, NL, SEC, true, false, false, true);   \
         else if (fast && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm && !(ctx->kernel_sel & 4)) QB_LAUNCH_VI(TT, NL, SEC, true, false);   \
         else if (fast) QB_LAUNCH_VI(TT, NL, -1, true, false);                     \
         else if (lit && ctx->dev.se_idx == SEC && !ctx->dev.multi_norm) QB_LAUNCH_VI(TT, NL, SEC, false, true);   \
         else if (lit) QB_LAUNCH_VI(TT, NL, -1, false, true);                      \
         else QB_LAUNCH_VI(TT, NL, -1, false, false);                              \
     } while (0)
+#ifdef QB_VI_PROBE   // scripts/dev/resources.sh: compile the optimal.yaml depth only (register / scratch reports in seconds)
+    if (shape->T == 11 && shape->L == 2) QB_DISPATCH_VI(11, 2, 2);
+    else if (shape->T == 24 && shape->L == 2) QB_DISPATCH_VI(24, 2, 7);
+#else
     if (shape->T == 11 && shape->L == 1) QB_DISPATCH_VI(11, 1, 2);
     else if (shape->T == 11 && shape->L == 2) QB_DISPATCH_VI(11, 2, 2);
     else if (shape->T == 24 && shape->L == 1) QB_DISPATCH_VI(24, 1, 7);
     else if (shape->T == 24 && shape->L == 2) QB_DISPATCH_VI(24, 2, 7);
+#endif
     else {
         qb::set_error("qbold_vi_fwd: kernels are built for T = 11 or 24 taus, L = 1 or 2");
         return QBOLD_ERR_UNSUPPORTED;

@@ -499,7 +499,7 @@ def test_full_size_properties_one_million_voxels(ctx, weights, oracle32, params)
     assert bool(torch.isfinite(nk).all()) and bool(torch.isfinite(sums).all())
     # sums are the masked checksum of the per-voxel outputs
     nkd, md = nk.double(), mask.double()
-    assert abs(float((nkd[:, 0] * md).sum()) / float(sums[0]) - 1) < 1e-9
+    assert abs(float((nkd[:, 0] * md).sum()) / float(sums[0]) - 1) < 1e-8    # float32 lane partials (16 tiles per lane)
     assert abs(float(nkd[:, 1][mask > 0].sum()) / float(sums[1]) - 1) < 1e-8    # float32 lane partials of a cancelling sum
     assert float(sums[2]) == float(md.sum())
     # four shards keyed by their first global voxel == the whole batch
@@ -785,7 +785,7 @@ def test_config3_full_size_properties(params):
     assert torch.equal(sums, sums2) and torch.equal(nk, nk2) and torch.equal(q, q2)   # bitwise repeatable
     assert bool(torch.isfinite(nk).all()) and bool(torch.isfinite(sums).all())
     nkd, md = nk.double(), mask.double()
-    assert abs(float((nkd[:, 0] * md).sum()) / float(sums[0]) - 1) < 1e-9
+    assert abs(float((nkd[:, 0] * md).sum()) / float(sums[0]) - 1) < 1e-8    # float32 lane partials (16 tiles per lane)
     assert abs(float(nkd[:, 1][mask > 0].sum()) / float(sums[1]) - 1) < 1e-8    # float32 lane partials of a cancelling sum
     assert float(sums[2]) == float(md.sum())
     parts, acc = [], torch.zeros_like(sums)
@@ -968,7 +968,7 @@ def test_whitened_kl_draws_against_the_general_form(ctx, oracle32):
     x = np.abs(rng.normal(0.4, 0.05, (n, 11))).astype(np.float32) + 0.1
     sigma = np.full((n, 11), 0.05, np.float32)
     z = oracle32.philox_normals(seed, 1, 0, n, K)
-    assert np.abs(z).max() < 6.7636
+    assert np.abs(z).max() <= 4.8549     # QB_Z_MAX: sqrt(-2 ln 2^-17), the stream's sixteen-bit radius
     want = oracle32.kl_samples(q, prior, z)
     white = ctx.kl_fwd(dev(q), dev(prior), K=K, seed=seed).cpu().numpy()                 # stand-alone KL kernel
     _, nk_w = ctx.elbo_fwd(dev(x), None, dev(q), dev(prior), dev(sigma), 2, K, seed=seed)            # whitened
@@ -995,7 +995,9 @@ def test_whitened_kl_draws_against_the_general_form(ctx, oracle32):
     # general form on both sides, KL up to ~1.6e4: float32 cancellation of the large logits on either side (the
     # whitened formula without the clip would be off by O(1) relative here)
     assert rel(nk_c[:, 1].cpu().numpy(), want_w, 1.0) < 5e-3
-    # an odd number of KL draws: the untaken second draw of the last pair
-    want_o = Oracle("f64").kl_samples(q, prior, oracle32.philox_normals(seed, 1, 0, n, 7))
-    _, nk_o = ctx.elbo_fwd(dev(x), None, dev(q), dev(prior), dev(sigma), 2, 7, seed=seed)
-    assert rel(nk_o[:, 1].cpu().numpy(), want_o, 1.0) < 2e-5
+    # draw counts that are no multiple of four: the untaken draws of the last Philox call (1, 2 and 3 of them), and
+    # fewer calls than lanes per voxel
+    for k_odd in (7, 6, 5, 70, 3, 1):
+        want_o = Oracle("f64").kl_samples(q, prior, oracle32.philox_normals(seed, 1, 0, n, k_odd))
+        _, nk_o = ctx.elbo_fwd(dev(x), None, dev(q), dev(prior), dev(sigma), 2, k_odd, seed=seed)
+        assert rel(nk_o[:, 1].cpu().numpy(), want_o, 1.0) < 2e-5, k_odd

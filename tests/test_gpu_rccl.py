@@ -173,7 +173,8 @@ def _run_shards(tmp_path, env, port):
                        capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
-    assert d["world"] == 2 and d["same"] and d["rel"] < 1e-12 and d["sum_mask"] == d["want_mask"]
+    # per-voxel outputs bit-equal; the sums differ by the float32 lane partials' order (another tile-to-lane dealing)
+    assert d["world"] == 2 and d["same"] and d["rel"] < 1e-8 and d["sum_mask"] == d["want_mask"]
     assert d["stats"]["allreduce_sums"] == 1
 
 

@@ -18,12 +18,21 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resta
 
 
 def test_philox_known_answer_vectors(oracle32):
-    # Random123 kat_vectors, philox4x32-10
+    # Random123 kat_vectors, philox4x32-10 (the noise model's uniform draw keeps ten rounds)
     assert oracle32.philox((0, 0, 0, 0), (0, 0)) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
     assert oracle32.philox((0xffffffff,) * 4, (0xffffffff,) * 2) == \
         (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
     assert oracle32.philox((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
                            (0xa4093822, 0x299f31d0)) == (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+
+
+def test_philox_seven_round_known_answer_vectors(oracle32):
+    # Random123 kat_vectors, philox4x32 with 7 rounds: the rounds the normal stream runs since round 4
+    assert oracle32.philox((0, 0, 0, 0), (0, 0), rounds=7) == (0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48)
+    assert oracle32.philox((0xffffffff,) * 4, (0xffffffff,) * 2, rounds=7) == \
+        (0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662)
+    assert oracle32.philox((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
+                           (0xa4093822, 0x299f31d0), rounds=7) == (0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a)
 
 
 def test_philox_normals_are_standard_normal(oracle32):
@@ -35,6 +44,48 @@ def test_philox_normals_are_standard_normal(oracle32):
     b = oracle32.philox_normals(7, 1, 0, 110, 5)[100:]
     assert np.array_equal(a, b)
     assert not np.array_equal(a, oracle32.philox_normals(8, 1, 100, 10, 5))
+    # the first draws of a longer request are the draws of a shorter one (draw i = word i & 3 of call i >> 2)
+    assert np.array_equal(oracle32.philox_normals(7, 1, 0, 10, 70)[:, :5], oracle32.philox_normals(7, 1, 0, 10, 5))
+
+
+def test_philox_normal_stream_definition(oracle32):
+    """The stream as qbold_dev.h defines it, recomputed here from the Philox words: sixteen bits of radius, sixteen of
+    angle, four draws per Philox4x32-7 call keyed (voxel, call index, stream id; seed)."""
+    seed, stream, vox = 0x123456789, 1, (1 << 33) + 17
+    z = oracle32.philox_normals(seed, stream, vox, 1, 11)[0].astype(np.float64)
+    for i in range(11):
+        w = oracle32.philox((vox & 0xffffffff, vox >> 32, i >> 2, stream), (seed & 0xffffffff, seed >> 32), rounds=7)[i & 3]
+        r = np.sqrt(-2.0 * np.log(((w >> 16) + 0.5) / 65536.0))
+        th = 2.0 * np.pi * (w & 0xffff) / 65536.0
+        assert abs(z[i, 0] - r * np.cos(th)) < 1e-6 and abs(z[i, 1] - r * np.sin(th)) < 1e-6
+
+
+def test_philox_normals_moments_and_tails(oracle32):
+    """Sixteen-bit radius and angle put the normals on a polar lattice; its moments, tails and independence against
+    the Gaussian's on 3.2 M draws (tolerances: four standard errors of each estimator)."""
+    z = oracle32.philox_normals(11, 0, 0, 400000, 8).astype(np.float64)
+    n = z.size
+    f = z.ravel()
+    assert abs(f.mean()) < 4 / np.sqrt(n)
+    assert abs(f.var() - 1.0) < 4 * np.sqrt(2.0 / n)
+    assert abs((f ** 3).mean()) < 4 * np.sqrt(15.0 / n)
+    assert abs((f ** 4).mean() - 3.0) < 4 * np.sqrt(96.0 / n)
+    assert abs((f ** 6).mean() - 15.0) < 4 * np.sqrt((10395.0 - 225.0) / n)
+    for t in (1.0, 2.0, 3.0, 4.0):
+        p = 2.0 * st.norm.sf(t)
+        assert abs(np.mean(np.abs(f) > t) - p) < 4 * np.sqrt(p / n), t
+    assert np.abs(f).max() <= 4.8549 and np.abs(f).max() > 4.5      # |z| <= sqrt(-2 ln 2^-17)
+    # the two normals of a draw, and consecutive draws of a voxel, are uncorrelated (also in their squares)
+    a, b = z[..., 0].ravel(), z[..., 1].ravel()
+    m = a.size
+    assert abs(np.mean(a * b)) < 4 / np.sqrt(m) and abs(np.mean((a * a - 1) * (b * b - 1))) < 4 * 2 / np.sqrt(m)
+    c, d = z[:, :-1, 0].ravel(), z[:, 1:, 0].ravel()
+    assert abs(np.mean(c * d)) < 4 / np.sqrt(c.size) and abs(np.mean((c * c - 1) * (d * d - 1))) < 4 * 2 / np.sqrt(c.size)
+    # radius^2 / 2 is exponential, the angle uniform
+    r2 = 0.5 * (a * a + b * b)
+    assert st.kstest(r2[::5], "expon").pvalue > 1e-3
+    ang = np.arctan2(b, a) / (2 * np.pi) % 1.0
+    assert st.kstest(ang[::5], "uniform").pvalue > 1e-3
 
 
 def test_bessel_j0_is_cephes_single(oracle32, oracle64):
