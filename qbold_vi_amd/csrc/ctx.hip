@@ -177,6 +177,15 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
                           td * td;
         d.ngk_l2e = (float)(-gk * 1.4426950408889634);
     }
+    {   // FwdFast's factors as affine functions of sigmoid(b) (qbold_dev.h, fwd_fast_sig); float64 here, rounded once
+        const double l2e = 1.4426950408889634, e = (double)d.e_te_r2t, bw = (double)d.bw_coef, bwe = (double)d.bwe_coef;
+        d.nd_a = (float)(-l2e * 0.2);
+        d.nd_b = (float)(-l2e * 0.001);
+        d.tw_a = (float)(-bw * 0.2 * e);
+        d.tw_b = (float)((1.0 - bw * 0.001) * e);
+        d.bv_a = (float)(bw * 0.2 * bwe);
+        d.bv_b = (float)(bw * 0.001 * bwe);
+    }
     static const Simpson simpson;
     d.dF_node0 = (float)simpson.node0_slope();
     ctx->dF_node0_ref = d.dF_node0;

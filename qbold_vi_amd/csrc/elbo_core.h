@@ -184,19 +184,21 @@ struct IsGtLds<GtLds<T, SE>> { static constexpr bool value = true; };
 
 // The same with the per-tau OEF-indexed table (GtLds; qbold_dev.h): the host dispatches here only for protocols with
 // tau = 0 at the compile-time spin-echo index and a table built for them (qbold_ctx::gtab_ok).
+// sa, sb: the draw's two sigmoids (OEF = 0.8 sa + 0.04, DBV = 0.2 sb + 0.001, model.py:299-305).
 template <int T, int SE>
 __device__ __forceinline__ float sample_sq_fast(const GtLds<T, SE>* L, const QbDev& c, const VoxelLik<T>& k,
-                                                float oef, float dbv) {
+                                                float sa, float sb) {
     static_assert(SE >= 0 && gtab_segs(T) > 0, "built for compile-time spin-echo protocols");
     constexpr int NSEG = gtab_segs(T);
-    const FwdFast fv = fwd_fast(c, oef, dbv);
+    const FwdFast fv = fwd_fast_sig(c, sa, sb);
     float acc = 0.0f;
     const float s_se = fmaf(fv.tissue_w, 1.0f, fv.blood_w * exp2f_(fv.ng * L->blood_B[SE]));   // F(0) = 0
     const float inv_np = rcpf_(s_se + 1e-3f);
     const float lt = log2f_(fv.tissue_w * inv_np), lb = log2f_(fv.blood_w * inv_np);
-    // one coordinate per draw: OEF in [0.04, 0.84] -> segment index and fraction shared by every tau
-    constexpr float kScale = (float)NSEG / QB_GT_OEF_RANGE;
-    const float cg = clampf_(fmaf(oef, kScale, -QB_GT_OEF_MIN * kScale), 0.0f, (float)NSEG - 0.0009765625f);
+    // one coordinate per draw: OEF in [0.04, 0.84] -> segment index and fraction shared by every tau.  The table's
+    // grid is OEF = 0.04 + 0.8 i / NSEG, so the coordinate is NSEG sa (sa in [0, 1]; 1 only by rounding: clamped)
+    static_assert(QB_GT_OEF_MIN == QB_MIN_OEF && QB_GT_OEF_RANGE == QB_OEF_RANGE, "the table spans forward_transform's range");
+    const float cg = fminf(sa * (float)NSEG, (float)NSEG - 0.0009765625f);
     const float f = __builtin_amdgcn_fractf(cg);
     const float4* row = L->gtab + (int)cg;
     {
@@ -409,43 +411,29 @@ __device__ __forceinline__ float kl_draws_fast(const LogitMvn& q, const LogitMvn
         const float d0 = dmu_o * prior.i_so, m00 = q.e_so * prior.i_so;
         const float d1 = fmaf(dmu_d, prior.i_sd, dmu_o * prior.i_bl);
         const float m10 = fmaf(q.c, prior.i_sd, q.e_so * prior.i_bl), m11 = q.e_sd * prior.i_sd;
-        float sp = 0.0f, sq = 0.0f;
-        int untaken = 0;
-#ifdef QB_EXP_KL_SERIAL
-        for (int g = part; 4 * g < K; g += QB_LANES_PER_VOXEL) {
-            const int cnt = K - 4 * g < 4 ? K - 4 * g : 4;
-            n_kl += cnt;
-            DrawQuad dq;
-            dq.load(seed, vox, (uint32_t)g, STREAM_KL);
-#pragma unroll 1
-            for (int d = 0; d < cnt; ++d) {
-                float z0, z1;
-                dq.next(z0, z1);
-                const float w0 = fmaf(m00, z0, d0), w1 = fmaf(m11, z1, fmaf(m10, z0, d1));
-                sp = fmaf(w0, w0, sp);
-                sp = fmaf(w1, w1, sp);
-                sq = fmaf(z0, z0, sq);
-                sq = fmaf(z1, z1, sq);
-            }
-        }
-#else
+        // |d + M z|^2 - |z|^2 is quadratic in z with coefficients fixed per voxel, so the loop only gathers the draws'
+        // five moments (sum z0, z1, z0^2, z1^2, z0 z1: five instructions per draw beside its normals) and the sum is
+        // assembled once; a draw beyond K comes out of normals8 as z = 0 and adds nothing to any moment.
+        float s0 = 0.0f, s1 = 0.0f, s00 = 0.0f, s11 = 0.0f, s01 = 0.0f;
         for (int g = part; 4 * g < K; g += QB_LANES_PER_VOXEL) {
             float z[8];
             const int cnt = K - 4 * g < 4 ? K - 4 * g : 4;
             n_kl += cnt;
-            untaken += 4 - cnt;
-            normals8(seed, vox, (uint32_t)g, STREAM_KL, cnt, z);   // draws beyond K: z = 0, each adds |d|^2 (removed below)
+            normals8(seed, vox, (uint32_t)g, STREAM_KL, cnt, z);
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const float w0 = fmaf(m00, z[2 * d], d0), w1 = fmaf(m11, z[2 * d + 1], fmaf(m10, z[2 * d], d1));
-                sp = fmaf(w0, w0, sp);
-                sp = fmaf(w1, w1, sp);
-                sq = fmaf(z[2 * d], z[2 * d], sq);
-                sq = fmaf(z[2 * d + 1], z[2 * d + 1], sq);
+                s0 += z[2 * d];
+                s1 += z[2 * d + 1];
+                s00 = fmaf(z[2 * d], z[2 * d], s00);
+                s11 = fmaf(z[2 * d + 1], z[2 * d + 1], s11);
+                s01 = fmaf(z[2 * d], z[2 * d + 1], s01);
             }
         }
-#endif
-        return fmaf(-(float)untaken, fmaf(d0, d0, d1 * d1), sp) - sq;
+        // sum_k (d0 + m00 z0)^2 + (d1 + m10 z0 + m11 z1)^2 - z0^2 - z1^2
+        const float nk = (float)n_kl;
+        const float quad = fmaf(fmaf(m00, m00, m10 * m10) - 1.0f, s00, fmaf(fmaf(m11, m11, -1.0f), s11, 2.0f * m10 * m11 * s01));
+        const float lin = 2.0f * fmaf(fmaf(d0, m00, d1 * m10), s0, d1 * m11 * s1);
+        return fmaf(nk, fmaf(d0, d0, d1 * d1), lin + quad);
     }
     for (int g = part; 4 * g < K; g += QB_LANES_PER_VOXEL) {
         const int cnt = K - 4 * g < 4 ? K - 4 * g : 4;
@@ -489,23 +477,6 @@ __device__ __forceinline__ void voxel_mc_sums(const LDS* L, const QbDev& c,
     // through the loop that owns the register budget).
     const float q_s_sum = q.s_o + q.s_d;
     __builtin_amdgcn_s_setprio(QB_PRIO_LIK);
-#ifdef QB_EXP_PAIR_LIK
-    for (int j = part; 2 * j < S; j += QB_LANES_PER_VOXEL) {
-        float z[4];
-        const bool two = 2 * j + 1 < S;
-        n_lik += two ? 2 : 1;
-        normals4(seed, vox, (uint32_t)j, STREAM_LIK, z);
-#pragma unroll 1
-        for (int d = 0; d < (two ? 2 : 1); ++d) {
-            float a, b, oef, dbv;
-            reparam_logits(q, d ? z[2] : z[0], d ? z[3] : z[1], a, b);
-            forward_transform(a, b, oef, dbv);
-            if constexpr (FAST && IsGtLds<LDS>::value) nll_sum += sample_sq_fast<T, SE>(L, c, lik, oef, dbv);
-            else if constexpr (FAST) nll_sum += sample_sq_fast<T, SE, MIR>(L, c, lik, oef, dbv);
-            else nll_sum += sample_nll<T, SE, LITERAL>(L, c, lik, oef, dbv);
-        }
-    }
-#else
     // This lane's draws: Philox calls part, part + 4, ... -> draws 4 g .. 4 g + 3 each, the last call possibly short.
     // ONE loop over them (a call's words are refilled every fourth trip): nested as calls x draws the register
     // allocator split far more live ranges around the inner loop (612 against 88 bytes of scratch at T = 24).
@@ -529,12 +500,12 @@ __device__ __forceinline__ void voxel_mc_sums(const LDS* L, const QbDev& c,
                 }
                 dq.next(z0, z1);
             }
-            float a, b, oef, dbv;
+            float a, b, oef = 0.0f, dbv = 0.0f;
             reparam_logits(q, z0, z1, a, b);
-            forward_transform(a, b, oef, dbv);
+            if constexpr (!(FAST && IsGtLds<LDS>::value)) forward_transform(a, b, oef, dbv);
             if constexpr (FAST && IsGtLds<LDS>::value) {
                 static_assert(!IsGtLds<LDS>::value || MIR, "the per-tau table scores merged mirror pairs");
-                nll_sum += sample_sq_fast<T, SE>(L, c, lik, oef, dbv);
+                nll_sum += sample_sq_fast<T, SE>(L, c, lik, sigmoidf_(a), sigmoidf_(b));
             } else if constexpr (FAST) {
                 nll_sum += sample_sq_fast<T, SE, MIR>(L, c, lik, oef, dbv);
             } else {
@@ -542,7 +513,6 @@ __device__ __forceinline__ void voxel_mc_sums(const LDS* L, const QbDev& c,
             }
         }
     }
-#endif
     if (FAST) {  // sum_d [0.5 sum_t r^2 + sum_t log sigma + T log sqrt(2 pi)] over this lane's draws
         nll_sum = fmaf(0.5f, nll_sum, (float)n_lik * lik.log_s_sum);
     }

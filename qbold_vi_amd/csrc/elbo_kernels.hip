@@ -282,7 +282,24 @@ __global__ __launch_bounds__(kLdsBlock) void elbo_fwd_lds_kernel(
                 my[((T / 4) * part + 4 * k4 + e) * kLdsVox] = make_float2(xa[e] * inv_nt * is, is);
             }
         }
-        const float log_s_sum = qb::voxel_sum(ls) + (float)T * 0.9189385332046727f;  // + T log sqrt(2 pi)
+        __syncthreads();
+        // Mirrored pairs as one data point (elbo_core.h, prepare_lik<.., MIR>): the signal is even in tau, so tau_{SE+j}
+        // and tau_{SE-j} share one prediction; their two residuals are (Q - yh P)^2 + D with the merged point (Q, P)
+        // stored at SE + j and D, which no draw changes, added to the per-draw constant.  A voxel's four lanes take
+        // the pairs j = part + 1, part + 5, ... ; one ds_read_b64 and two FMAs less per pair and draw.
+        float dsum = 0.0f;
+#pragma unroll
+        for (int j = 1; j <= SE && SE + j < T; ++j) {
+            if (((j - 1) & 3) == part) {
+                const float2 p1 = my[(SE + j) * kLdsVox], p2 = my[(SE - j) * kLdsVox];
+                const float pp = fmaf(p1.y, p1.y, p2.y * p2.y);
+                const float ip = __builtin_amdgcn_rsqf(pp);
+                const float cr = fmaf(p1.x, p2.y, -(p2.x * p1.y)) * ip;
+                my[(SE + j) * kLdsVox] = make_float2(fmaf(p1.x, p1.y, p2.x * p2.y) * ip, pp * ip);
+                dsum = fmaf(cr, cr, dsum);
+            }
+        }
+        const float log_s_sum = qb::voxel_sum(fmaf(0.5f, dsum, ls)) + (float)T * 0.9189385332046727f;  // + T log sqrt(2 pi)
         __syncthreads();
         if (live) {
             float qv[5];
@@ -328,7 +345,7 @@ __global__ __launch_bounds__(kLdsBlock) void elbo_fwd_lds_kernel(
                     struct Stage {
                         float4 kk;
                         float f, bb;
-                        float2 d0, d1;
+                        float2 d0;
                     };
                     auto issue = [&](int t) -> Stage {
                         Stage st;
@@ -336,8 +353,7 @@ __global__ __launch_bounds__(kLdsBlock) void elbo_fwd_lds_kernel(
                         st.kk = L.tab[(int)u];
                         st.f = __builtin_amdgcn_fractf(u);
                         st.bb = L.blood_B[t];
-                        st.d0 = my[t * kLdsVox];
-                        st.d1 = 2 * SE - t >= 0 ? my[(2 * SE - t) * kLdsVox] : make_float2(0.0f, 0.0f);
+                        st.d0 = my[t * kLdsVox];     // t <= 2 SE: the merged pair (tau_t, tau_{2 SE - t})
                         return st;
                     };
                     auto finish = [&](int t, const Stage& st) {
@@ -345,10 +361,6 @@ __global__ __launch_bounds__(kLdsBlock) void elbo_fwd_lds_kernel(
                         const float yh = qb::exp2f_(fmaf(fv.nd, F, lt)) + qb::exp2f_(fmaf(fv.ng, st.bb, lb));
                         const float r = fmaf(-yh, st.d0.y, st.d0.x);
                         acc = fmaf(r, r, acc);
-                        if (2 * SE - t >= 0) {
-                            const float r1 = fmaf(-yh, st.d1.y, st.d1.x);
-                            acc = fmaf(r1, r1, acc);
-                        }
                     };
                     {
                         const float2 dd = my[SE * kLdsVox];
@@ -387,9 +399,7 @@ __global__ __launch_bounds__(kLdsBlock) void elbo_fwd_lds_kernel(
                     residual(SE, s_se * inv_np);
 #pragma unroll
                     for (int t = SE + 1; t < T; ++t) {
-                        const float yh = signal(t);
-                        residual(t, yh);
-                        if (2 * SE - t >= 0) residual(2 * SE - t, yh);
+                        residual(t, signal(t));      // t <= 2 SE: against the merged pair
                         if (((t - SE) % QB_LIK_BARRIER) == 0) asm volatile("" ::: "memory");
                     }
 #pragma unroll

@@ -109,9 +109,7 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
         // instead of being hoisted out of the tile loop as 20-70 loop-invariant registers that the sampling phase
         // (which needs none of them) has to spill and reload around itself.
         int lane = lane0;
-#ifndef QB_EXP_NO_LANE_LAUNDER
         asm volatile("" : "+v"(lane));
-#endif
         const int g = lane >> 4, i = lane & 15;
         const int64_t v = tile * 16 + i;
         const int64_t vc = v < N ? v : N - 1;
