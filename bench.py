@@ -436,7 +436,7 @@ def run_workload(spec, args, steps, warmup, rank, device, use_pg, world, S, K):
                 step_kernel_ms=step_kernel_ms, enc_kernel_ms=enc_kernel_ms, sums=s, n_allreduce=n_allreduce)
 
 
-# Issue cost of one wave64 vector instruction on gfx950, cycles, measured with scripts/ubench/ubench*.hip:
+# Issue cost of one wave64 vector instruction on gfx950, cycles, measured with scripts/ubench/ubench*.hip (MEASUREMENTS.md 4.4):
 # the class counters of rocprofv3 (SQ_INSTS_VALU_*) x these costs / SIMD-cycles = roofline.issue.model_frac
 ISSUE_COST = {"SQ_INSTS_VALU_TRANS_F32": 8.45, "SQ_INSTS_VALU_CVT": 4.6, "SQ_INSTS_VALU_INT32": 4.0,
               "SQ_INSTS_VALU_FMA_F32": 2.9, "SQ_INSTS_VALU_MUL_F32": 2.9, "SQ_INSTS_VALU_ADD_F32": 2.9}
@@ -519,14 +519,14 @@ def roofline_of(spec, m, S, K, step_kernel_ms, kernel_ms):
         note = ("dominant kernel = the one-launch wide encoder (activations in registers, weights streamed L2 -> LDS): "
                 "'achieved' = SURVEY 8(d)'s encoder flops per voxel x voxels / its launch duration (HIP events inside "
                 "the timed region) against the guide's dense f16 MFMA peak; under this kernel's matrix load the chip "
-                "holds ~1.6-2.0 GHz, not the 2.4 GHz the peak assumes (DESIGN 4.7); the second launch "
+                "holds ~1.6-2.0 GHz, not the 2.4 GHz the peak assumes (MEASUREMENTS.md 4.7); the second launch "
                 "(elbo_fwd_lds_kernel, vector-issue-bound) is in 'two_pipe' / 'hbm', which cover the whole step")
     else:
         if spec.exact:
             kname = "xw64_kernel / xw64_fork_kernel / xw64_gate_kernel / xw64_heads_kernel + elbo_fwd_kernel"
             note = ("the strictly-float32 encoder (v_mfma_f32_16x16x4_f32 GEMMs, one launch per layer, float32 activations "
                     "through HBM) + the ELBO kernel; the layer GEMMs are HBM-bound on their activation traffic "
-                    "(DESIGN 4.5), which the algorithmic-byte figure here does not count")
+                    "(MEASUREMENTS.md 4.5), which the algorithmic-byte figure here does not count")
         else:
             kname = "vi_fwd_kernel"
             pmc_name = {(11, "f32"): "_vi_fwd_pmc.json", (24, "f32"): "_p24_vi_fwd_pmc.json",
@@ -628,7 +628,7 @@ def main():
     if os.environ.get("QBOLD_DEBUG_SKIP", "0") not in ("", "0"):
         # The default build of the library has no ablation hook at all (they compile in only with -DQBOLD_ABLATION,
         # scripts/dev/build_ablation.sh); with such a build loaded, the run is marked so that the phases switched
-        # off for timing experiments never reach a reported number.
+        # off for timing experiments (MEASUREMENTS.md 4.4 / 4.7) never reach a reported number.
         os.environ["QBOLD_ALLOW_ABLATION"] = "1"
         print("bench.py: QBOLD_DEBUG_SKIP is set -- an ablation build of the library would skip work; this run is an "
               "ablation, not a benchmark", file=sys.stderr)

@@ -300,8 +300,8 @@ int qbold_kl_diag(const qbold_ctx* ctx, const float* q, const float* prior, cons
  * voxel0 .. voxel0+N-1; stream_id 0 = likelihood draws, 1 = KL draws, 2 = moments, 3 = noise.
  * Replaces tf.random.normal at model.py:25 with a reproducible, sharding-invariant generator
  * (Random123 Philox4x32-7, four draws per call: draw i = word i & 3 of call i >> 2 keyed (voxel, call, stream_id; seed);
- * Box-Muller on the word's high sixteen bits (radius, u1 = (hi + 0.5) 2^-16, so |z| <= 4.8549) and low sixteen bits
- * (angle, lo 2^-16 revolutions).  The definition is this library's; oracle/qbold_oracle.c restates it. */
+ * Box-Muller on the word's low sixteen bits (radius, u1 = (lo + 0.5) 2^-16, so |z| <= 4.8549) and top 23 bits (angle,
+ * (w >> 9) 2^-23 revolutions).  The definition is this library's; oracle/qbold_oracle.c restates it. */
 int qbold_normals(const qbold_ctx* ctx, uint64_t seed, uint32_t stream_id, int64_t voxel0, int n,
                   float* z, int64_t N, void* stream);
 

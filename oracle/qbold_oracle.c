@@ -947,7 +947,7 @@ void qbo_elbo(const qbo_phys *P, const qbo_loss_cfg *C, const real *x, const rea
  * The stream is the LIBRARY's definition, not the reference's (tf.random.normal cannot be reproduced); this
  * is its restatement, word for word (qbold_vi_amd/csrc/qbold_dev.h).  Round 4:
  *   draw i of (seed, voxel, stream) = word (i & 3) of Philox4x32-7(ctr = (voxel_lo, voxel_hi, i >> 2, stream), key = seed)
- *   word w: u1 = ((w >> 16) + 0.5) 2^-16, r = sqrt(-2 ln u1); theta = (w & 0xffff) 2^-16 revolutions;
+ *   word w: u1 = ((w & 0xffff) + 0.5) 2^-16, r = sqrt(-2 ln u1); theta = (w >> 9) 2^-23 revolutions;
  *           (z0, z1) = r (cos 2 pi theta, sin 2 pi theta), everything in double, rounded once.
  * ---------------------------------------------------------------------------------------- */
 static void philox4x32_rounds(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
@@ -974,8 +974,8 @@ void qbo_philox4x32_7(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
 }
 
 static inline void box_muller16(uint32_t w, real *z0, real *z1) {
-    double u1 = ((double)(w >> 16) + 0.5) * 0x1p-16;       /* in (0, 1): |z| <= sqrt(-2 ln 2^-17) = 4.8549 */
-    double th = (double)(w & 0xffffu) * 0x1p-16;            /* revolutions */
+    double u1 = ((double)(w & 0xffffu) + 0.5) * 0x1p-16;   /* in (0, 1): |z| <= sqrt(-2 ln 2^-17) = 4.8549 */
+    double th = (double)(w >> 9) * 0x1p-23;                 /* revolutions: the high half's sixteen bits lead */
     double rr = sqrt(-2.0 * log(u1));
     *z0 = R(rr * cos(2.0 * M_PI * th));
     *z1 = R(rr * sin(2.0 * M_PI * th));

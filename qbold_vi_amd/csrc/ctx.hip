@@ -113,7 +113,7 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
     d.tissue_mode = QBOLD_TISSUE_TABLE;
 #ifdef QBOLD_ABLATION
     // Ablation build only (scripts/dev/build_ablation.sh; never the library the tests, the driver or bench.py load):
-    // QBOLD_DEBUG_SKIP switches phases of the kernels off for the timing experiments of DESIGN 4.4 / 4.5 / 4.7 and
+    // QBOLD_DEBUG_SKIP switches phases of the kernels off for the timing experiments of MEASUREMENTS.md 4.4 / 4.5 / 4.7 and
     // selects among equivalent kernels; honoured only together with QBOLD_ALLOW_ABLATION=1.
     if (const char* dbg = getenv("QBOLD_DEBUG_SKIP")) {
         const char* allow = getenv("QBOLD_ALLOW_ABLATION");

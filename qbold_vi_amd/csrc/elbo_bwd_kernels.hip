@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void elbo_bwd_kernel(
                 for (int g = part; 4 * g < K; g += LPV) {
                     float z[8];
                     const int cnt = K - 4 * g < 4 ? K - 4 * g : 4;
-                    qb::normals8(seed, vox, (uint32_t)g, qb::STREAM_KL, cnt, z);   // beyond K: z = 0, adds nothing to any moment
+                    qb::normals8_unscaled(seed, vox, (uint32_t)g, qb::STREAM_KL, cnt, z);   // beyond K: z = 0, adds nothing to any moment
                     n_kl += cnt;
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
@@ -214,6 +214,12 @@ __global__ __launch_bounds__(kBlock) void elbo_bwd_kernel(
                         s01 = fmaf(z0, z1, s01);
                     }
                 }
+                // the normals' common factor sqrt(2 ln 2) (normals8_unscaled), applied to the moments
+                s0 *= QB_BM_K;
+                s1 *= QB_BM_K;
+                s00 *= QB_BM_K * QB_BM_K;
+                s11 *= QB_BM_K * QB_BM_K;
+                s01 *= QB_BM_K * QB_BM_K;
                 const float nk = (float)n_kl;
                 const float dmu_o = qm.mu_o - pm.mu_o, dmu_d = qm.mu_d - pm.mu_d;
                 const float d0 = dmu_o * pm.i_so, m00 = qm.e_so * pm.i_so;

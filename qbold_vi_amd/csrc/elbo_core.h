@@ -419,7 +419,7 @@ __device__ __forceinline__ float kl_draws_fast(const LogitMvn& q, const LogitMvn
             float z[8];
             const int cnt = K - 4 * g < 4 ? K - 4 * g : 4;
             n_kl += cnt;
-            normals8(seed, vox, (uint32_t)g, STREAM_KL, cnt, z);
+            normals8_unscaled(seed, vox, (uint32_t)g, STREAM_KL, cnt, z);
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 s0 += z[2 * d];
@@ -429,6 +429,12 @@ __device__ __forceinline__ float kl_draws_fast(const LogitMvn& q, const LogitMvn
                 s01 = fmaf(z[2 * d], z[2 * d + 1], s01);
             }
         }
+        // the normals' common factor sqrt(2 ln 2) (normals8_unscaled), applied to the moments
+        s0 *= QB_BM_K;
+        s1 *= QB_BM_K;
+        s00 *= QB_BM_K * QB_BM_K;
+        s11 *= QB_BM_K * QB_BM_K;
+        s01 *= QB_BM_K * QB_BM_K;
         // sum_k (d0 + m00 z0)^2 + (d1 + m10 z0 + m11 z1)^2 - z0^2 - z1^2
         const float nk = (float)n_kl;
         const float quad = fmaf(fmaf(m00, m00, m10 * m10) - 1.0f, s00, fmaf(fmaf(m11, m11, -1.0f), s11, 2.0f * m10 * m11 * s01));

@@ -24,7 +24,7 @@
 // relative error <= ~3 * 2^-22 (7e-7), i.e. float32-grade, at 3/16 of the cycles of the exact
 // v_mfma_f32_16x16x4_f32 path.  The motive is not only the cycles: on gfx950 the f32-input MFMA runs
 // at the vector rate and, measured here, does NOT overlap with f32 VALU work from other waves
-// (profiles/), while the f16 matrix pipe does.
+// (profiles/, MEASUREMENTS.md 4.4), while the f16 matrix pipe does.
 //
 // LDS weight image (built by pack_kernel in encoder_kernels.hip), per dense op:
 //   A[kstep s][m_out][part = hi, lo][lane 0..63][j = 0..7] f16  (one ds_read_b128 per fragment,

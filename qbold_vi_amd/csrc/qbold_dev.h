@@ -48,7 +48,7 @@ struct QbDev {
     float blood_B[QB_MAX_T];  // bracket of signals.py:242-247 per tau
 };
 
-// Work-skipping hooks of the timing experiments.  They exist only in builds made with
+// Work-skipping hooks of the timing experiments (MEASUREMENTS.md 4.4 / 4.7).  They exist only in builds made with
 // -DQBOLD_ABLATION (scripts/dev/build_ablation.sh); in the library the driver, the tests and bench.py load they are
 // the constant 0 and the guarded code is unconditional.
 #ifdef QBOLD_ABLATION
@@ -171,11 +171,15 @@ __device__ __forceinline__ float nlogp(const LogitObs& o, const LogitMvn& m) {
 // The stream is this library's own definition (the reference's tf.random.normal stream is irreproducible);
 // the oracle restates it word for word (oracle/qbold_oracle.c, qbo_philox_normals).  Round 4:
 //   draw i of (seed, voxel, stream) = word (i & 3) of Philox4x32-7(ctr = (voxel_lo, voxel_hi, i >> 2, stream), key = seed)
-//   word w -> radius  r = sqrt(-2 ln u1),  u1 = ((w >> 16) + 0.5) 2^-16   (u1 in (0, 1): |z| <= 4.8549)
-//             angle   theta = (w & 0xffff) 2^-16 revolutions
+//   word w -> radius  r = sqrt(-2 ln u1),  u1 = ((w & 0xffff) + 0.5) 2^-16   (u1 in (0, 1): |z| <= 4.8549)
+//             angle   theta = (w >> 9) 2^-23 revolutions: its sixteen leading bits are the word's high half, independent
+//                     of the radius; the seven bits below them (w[15:9], shared with the radius) move the angle by less
+//                     than 2^-16 of a revolution -- a dither under the lattice's own resolution.  In this form the angle
+//                     is ONE instruction: v_alignbit_b32(127, w, 9) = 0x3f800000 | (w >> 9) is the float 1 + theta, and
+//                     v_sin_f32 / v_cos_f32 take revolutions, for which 1 + theta is theta.
 //             (z0, z1) = r (cos 2 pi theta, sin 2 pi theta)
 // i.e. one Philox call serves FOUR draws (rounds 1-3: two, with 32-bit uniforms and ten rounds) and a draw costs
-// 7 + 11 vector instructions instead of 20 + 11.  Seven rounds are the Crush-resistant minimum Random123 publishes for
+// 7 + 10 vector instructions instead of 20 + 11.  Seven rounds are the Crush-resistant minimum Random123 publishes for
 // Philox4x32 (Salmon et al., SC'11, table 2; known-answer vectors for 7 rounds: tests/test_oracle.py); sixteen-bit
 // radius and angle put the normals on a 65,536 x 65,536 polar lattice (radial step at the mode 2.6e-5), whose moments
 // tests/test_oracle.py holds against the Gaussian's.
@@ -201,15 +205,20 @@ __device__ __forceinline__ uint4 philox4x32_7(uint4 c, uint2 k) { return philox4
 
 #define QB_Z_MAX 4.8549f   // sqrt(-2 ln 2^-17) = 4.85487: the largest |z| the stream can produce
 
+// 1 + theta as a float in [1, 2): the word's top 23 bits as the mantissa
+__device__ __forceinline__ float bm_angle(uint32_t w) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_alignbit(127u, w, 9u));
+}
 // one word -> the two normals of one draw
 __device__ __forceinline__ void box_muller16(uint32_t w, float& z0, float& z1) {
-    const float u1 = fmaf((float)(w >> 16), 0x1p-16f, 0x1p-17f);   // exact in float32
-    const float th = (float)(w & 0xffffu) * 0x1p-16f;             // revolutions, exact
+    const float u1 = fmaf((float)(w & 0xffffu), 0x1p-16f, 0x1p-17f);   // exact in float32
+    const float th = bm_angle(w);
     // r = sqrt(-2 ln u1) via v_log_f32 (log2) and v_sqrt_f32; v_sin/v_cos take revolutions
     const float r = __builtin_amdgcn_sqrtf((-2.0f * QB_LN2) * log2f_(u1));
     z0 = r * __builtin_amdgcn_cosf(th);
     z1 = r * __builtin_amdgcn_sinf(th);
 }
+#define QB_BM_K 1.1774100225154747f   // sqrt(2 ln 2): z = QB_BM_K sqrt(-log2 u1) (cos, sin)
 
 enum { STREAM_LIK = 0, STREAM_KL = 1, STREAM_MOMENTS = 2, STREAM_R2P = 3 };
 
@@ -228,21 +237,28 @@ struct DrawQuad {
     }
 };
 
-// normals of draws (4 quad .. 4 quad + 3): z[2 d], z[2 d + 1] for draw 4 quad + d; the draws d >= cnt (beyond the
+// normals of draws (4 quad .. 4 quad + 3), UNSCALED: z[2 d], z[2 d + 1] = z / QB_BM_K for draw 4 quad + d (a caller that
+// only gathers moments of the draws scales the moments, once, instead of every normal); the draws d >= cnt (beyond the
 // number asked for) come out as exact zeros -- one select on the radius each
-__device__ __forceinline__ void normals8(uint64_t seed, uint64_t vox, uint32_t quad, uint32_t stream, int cnt, float z[8]) {
+__device__ __forceinline__ void normals8_unscaled(uint64_t seed, uint64_t vox, uint32_t quad, uint32_t stream, int cnt,
+                                                  float z[8]) {
     const uint4 o = philox4x32_7(make_uint4((uint32_t)vox, (uint32_t)(vox >> 32), quad, stream),
                                  make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
     const uint32_t w[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        const float u1 = fmaf((float)(w[d] >> 16), 0x1p-16f, 0x1p-17f);
-        const float th = (float)(w[d] & 0xffffu) * 0x1p-16f;
-        float r = __builtin_amdgcn_sqrtf((-2.0f * QB_LN2) * log2f_(u1));
+        const float u1 = fmaf((float)(w[d] & 0xffffu), 0x1p-16f, 0x1p-17f);
+        const float th = bm_angle(w[d]);
+        float r = __builtin_amdgcn_sqrtf(-log2f_(u1));
         if (d > 0) r = d < cnt ? r : 0.0f;
         z[2 * d] = r * __builtin_amdgcn_cosf(th);
         z[2 * d + 1] = r * __builtin_amdgcn_sinf(th);
     }
+}
+__device__ __forceinline__ void normals8(uint64_t seed, uint64_t vox, uint32_t quad, uint32_t stream, int cnt, float z[8]) {
+    normals8_unscaled(seed, vox, quad, stream, cnt, z);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] *= QB_BM_K;
 }
 
 // normals of draws (2*pair, 2*pair+1) of `stream` for global voxel `vox`: half a Philox call's words (the kernels off

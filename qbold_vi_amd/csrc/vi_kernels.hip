@@ -12,7 +12,7 @@
 // HBM traffic per voxel (T = 11): read x 44 + mask 4 + prior 20, write q 20 + (nll, kl) 8 = 96 B; the weight
 // image (~145 KB of split-f16 fragments), the F(x) table (4 KB) and constants are LDS / SGPR resident.  Work per
 // voxel at S = 32, K = 70: 60.8 kFLOP of encoder products (x 3 passes on the matrix pipe) and ~30 kFLOP of
-// sampling: compute-bound by the vector pipe's issue rate, ~900 flop/B against a machine balance
+// sampling: compute-bound by the vector pipe's issue rate (MEASUREMENTS.md 4.4), ~900 flop/B against a machine balance
 // of ~20 flop/B.
 //
 // One 1024-thread workgroup per CU (the weight image takes ~145 KB of the 160 KB LDS), 128 VGPRs, so four waves

@@ -65,7 +65,8 @@ for name in sorted(os.listdir(src)):
         copied.append(name)
 fa, fb = sha("a"), sha("b")
 if fa and os.path.exists(os.path.join(src, f"{tag}_vi_fwd_summary.json")):
-    put(f"{tag}_vi_fwd_pmc.json", pmc_file(f"{tag}_vi_fwd_summary.json", "vi_fwd_kernel<11,2,2,true,false,false" + (",true>" if tag >= "r03" else ">"), n, 96 * n, fa))
+    kname = "vi_fwd_kernel<11,2,2,true,false,false" + (",true,false>" if tag >= "r04" else ",true>" if tag >= "r03" else ">")
+    put(f"{tag}_vi_fwd_pmc.json", pmc_file(f"{tag}_vi_fwd_summary.json", kname, n, 96 * n, fa))
 if fb:
     if os.path.exists(os.path.join(src, f"{tag}_config3_wide_fused_summary.json")):
         T = 64
@@ -82,8 +83,8 @@ if fb:
                                    "out; the two-launch path also writes and re-reads log sigma (2 x 4T B) and q, and reads "
                                    "the signals twice: its own floor is the sum of the two kernels' algorithmic bytes"}
         put(f"{tag}_config3_pmc.json", enc)
-    for t, kernel, alg in (("p24", "vi_fwd_kernel<24,2,7,true,false,false>", (4 * 24 + 52) * n),
-                           ("bf16", "vi_fwd_kernel<11,2,2,true,false,true" + (",true>" if tag >= "r03" else ">"), 96 * n)):
+    for t, kernel, alg in (("p24", "vi_fwd_kernel<24,2,7,true,false,false" + (",true,false>" if tag >= "r04" else ">"), (4 * 24 + 52) * n),
+                           ("bf16", "vi_fwd_kernel<11,2,2,true,false,true" + (",true,false>" if tag >= "r04" else ",true>" if tag >= "r03" else ">"), 96 * n)):
         if os.path.exists(os.path.join(src, f"{tag}_{t}_vi_fwd_summary.json")):
             put(f"{tag}_{t}_vi_fwd_pmc.json", pmc_file(f"{tag}_{t}_vi_fwd_summary.json", kernel, n, alg, fb))
 fc = sha("c")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds an ABLATION copy of the library: -DQBOLD_ABLATION compiles the work-skipping hooks of the timing
-# experiments in, which then honour QBOLD_DEBUG_SKIP together with
+# experiments (MEASUREMENTS.md 4.4 / 4.5 / 4.7) in, which then honour QBOLD_DEBUG_SKIP together with
 # QBOLD_ALLOW_ABLATION=1.  Never what the tests, the driver or a user load: the default build has no such hook.
 # It is written to its own object directory and library file (qbold_vi_amd/libqbold_hip_var_<tag>.so, printed below)
 # and is loaded only when QBOLD_LIB names it; qbold_vi_amd/libqbold_hip.so is never touched:

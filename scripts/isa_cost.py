@@ -2,7 +2,7 @@
 """Issue-cycle model of a gfx950 ISA listing (hipcc --save-temps .s), per line range.
 
 Costs per wave64 instruction are the ones measured by scripts/ubench/ubench*.hip on an MI355X at
-4 waves/SIMD: simple f32 / logic ops with VGPR operands ~2.9 cycles, with an SGPR or literal
+4 waves/SIMD (MEASUREMENTS.md 4.4): simple f32 / logic ops with VGPR operands ~2.9 cycles, with an SGPR or literal
 operand 4.4-5.5, conversions / integer multiplies / packed ops ~4.6, transcendentals ~8.45.
 Usage: isa_cost.py file.s start:end[:label[:weight]] ...
 """

@@ -116,7 +116,7 @@ def test_eight_shards_of_4m_voxels_equal_the_32m_voxel_job(job, oracle32, precis
 
 
 def test_bf16_job_stays_within_its_restated_tolerance_of_the_f32_job(job):
-    """Config 5 against config 4 on the whole 32 M-voxel job: -ELBO within 1e-3 relative."""
+    """Config 5 against config 4 on the whole 32 M-voxel job: -ELBO within 1e-3 relative (MEASUREMENTS.md §6, row config 5)."""
     ctx, w, ews, x, mask, prior = job
     s32, _, _ = ctx.vi_fwd(ews["f32"], x, mask, prior, S, K, seed=SEED, want_q=False, per_voxel=False)
     s16, _, _ = ctx.vi_fwd(ews["bf16"], x, mask, prior, S, K, seed=SEED, want_q=False, per_voxel=False)

@@ -911,7 +911,7 @@ def test_one_launch_wide_encoder_on_partly_filled_tau_tiles(params, T):
 
 def test_per_tau_table_against_the_x_indexed_table(ctx, weights, oracle32, params):
     """The sampling fast path reads the tissue integral from a per-tau OEF-indexed table (one segment index per DRAW,
-    DESIGN 4.3); QBOLD_KSEL_X_TABLE selects the round-1/2 form with one x-indexed lookup per (draw, tau).  Both against
+    MEASUREMENTS.md 4.3); QBOLD_KSEL_X_TABLE selects the round-1/2 form with one x-indexed lookup per (draw, tau).  Both against
     the oracle on the same Philox stream, fused and unfused, 11 and 24 taus."""
     from oracle.oracle import Oracle, init_weights, synth_inputs
     from qbold_vi_amd.ops import Context, EncoderWeights

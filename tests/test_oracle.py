@@ -49,14 +49,15 @@ def test_philox_normals_are_standard_normal(oracle32):
 
 
 def test_philox_normal_stream_definition(oracle32):
-    """The stream as qbold_dev.h defines it, recomputed here from the Philox words: sixteen bits of radius, sixteen of
-    angle, four draws per Philox4x32-7 call keyed (voxel, call index, stream id; seed)."""
+    """The stream as qbold_dev.h defines it, recomputed here from the Philox words: the low sixteen bits give the radius,
+    the top 23 the angle (its sixteen leading bits independent of the radius), four draws per Philox4x32-7 call keyed
+    (voxel, call index, stream id; seed)."""
     seed, stream, vox = 0x123456789, 1, (1 << 33) + 17
     z = oracle32.philox_normals(seed, stream, vox, 1, 11)[0].astype(np.float64)
     for i in range(11):
         w = oracle32.philox((vox & 0xffffffff, vox >> 32, i >> 2, stream), (seed & 0xffffffff, seed >> 32), rounds=7)[i & 3]
-        r = np.sqrt(-2.0 * np.log(((w >> 16) + 0.5) / 65536.0))
-        th = 2.0 * np.pi * (w & 0xffff) / 65536.0
+        r = np.sqrt(-2.0 * np.log(((w & 0xffff) + 0.5) / 65536.0))
+        th = 2.0 * np.pi * (w >> 9) / 2.0 ** 23
         assert abs(z[i, 0] - r * np.cos(th)) < 1e-6 and abs(z[i, 1] - r * np.sin(th)) < 1e-6
 
 
