@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define QBOLD_MAX_T 64
-#define QBOLD_ABI_VERSION 4
+#define QBOLD_ABI_VERSION 5
 
 typedef enum {
     QBOLD_OK = 0,
@@ -107,6 +107,18 @@ typedef struct {
                                    QBOLD_ACT_GELU runs on the layer-wise entry points (qbold_encoder_train_fwd / _bwd,
                                    qbold_encoder_spatial_fwd / _bwd: general kernels, pre-activations recomputed in the
                                    backward); the fused / wide entry points return QBOLD_ERR_UNSUPPORTED for it (ABI v4) */
+    int32_t layer_norm;         /* EncoderTrainer's use_layer_norm (model.py:133-140): tfa GroupNormalization(groups = 1,
+                                   axis = -1) in front of both activations of a block's residual path -- mean and biased
+                                   variance over ALL positions and channels of one batch element (a voxel of a voxel batch,
+                                   a whole crop of a crop batch), epsilon 1e-3, per-channel gamma / beta: 4 U more
+                                   parameters per block behind the heads (qbold_encoder_num_params).  Layer-wise entry
+                                   points only, like gelu (ABI v5) */
+    float dropout_rate;         /* EncoderTrainer's dropout_rate: keras Dropout in front of each GroupNormalization (or
+                                   activation).  Active in the TRAINING forward / backward when dropout_seed != 0: an
+                                   element is dropped iff its 16-bit uniform of the library's Philox stream 5, keyed
+                                   (dropout_seed; row, normalizer, column), is below rate 2^16; kept ones scale by
+                                   1 / (1 - rate).  Inference (dropout_seed = 0) is the identity, as in Keras */
+    uint64_t dropout_seed;      /* per-step seed, the same for a step's forward and backward; 0 = inference */
 } qbold_encoder_shape;
 
 /* Image-crop geometry of a [B][X][Y][Z][C] batch (train.py:17-72): voxel v = ((b X + x) Y + y) Z + z.

@@ -245,16 +245,24 @@ class Oracle:
         del keep
         return o1, o2, sg
 
-    def encoder_fwd_spatial(self, w, x):
-        """x [B, X, Y, Z, T] -> (out2 [B,X,Y,Z,5], sigma [B,X,Y,Z,T]); needs 9-tap weights."""
+    def encoder_fwd_spatial(self, w, x, ln=None, dropout_rate=0.0, dropout_seed=0):
+        """x [B, X, Y, Z, T] -> (out2 [B,X,Y,Z,5], sigma [B,X,Y,Z,T]); needs 9-tap weights.
+        ln [L, 4, U] (gamma1, beta1, gamma2, beta2 per block): use_layer_norm; dropout_rate / dropout_seed: a
+        training-mode forward under the library's dropout stream (model.py:131-140)."""
         x = self._a(x)
         B, X, Y, Z, T = x.shape
         ws, keep = self._weights(w)
         assert ws.taps == 9 and T == ws.T
         o2 = np.empty((B, X, Y, Z, 5), self.dtype)
         sg = np.empty((B, X, Y, Z, T), self.dtype)
-        self.lib.qbo_encoder_fwd_spatial(C.byref(ws), C.byref(self.cfg), self._p(x), B, X, Y, Z,
-                                         self._p(o2), self._p(sg))
+        lnp = None if ln is None else self._a(ln)
+        self.lib.qbo_set_normalizer(self._p(lnp) if lnp is not None else None, C.c_double(dropout_rate),
+                                    C.c_uint64(dropout_seed))
+        try:
+            self.lib.qbo_encoder_fwd_spatial(C.byref(ws), C.byref(self.cfg), self._p(x), B, X, Y, Z,
+                                             self._p(o2), self._p(sg))
+        finally:
+            self.lib.qbo_set_normalizer(None, C.c_double(0.0), C.c_uint64(0))
         del keep
         return o2, sg
 

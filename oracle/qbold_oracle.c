@@ -534,6 +534,58 @@ static void conv3x3(const real *in, const real *K /*[3][3][U][U]*/, const real *
                 }
 }
 
+/* add_normalizer (model.py:131-140) in front of the residual path's two activations (model.py:150-151, 154-155):
+ * keras Dropout (training; the LIBRARY's mask stream, include/qbold_hip.h: element (row, c) of normalizer `layer` is
+ * dropped iff half-word c & 7 of Philox4x32-7(ctr = (row_lo, row_hi, (c >> 3) | layer << 16, 5), key = seed) is below
+ * rate 2^16), then tfa GroupNormalization(groups = 1, axis = -1): mean and biased variance over all positions and
+ * channels of one batch element, epsilon 1e-3, per-channel gamma / beta.  Test hook like the activation's. */
+static const real *g_ln = NULL;      /* [L][4][U]: gamma1, beta1, gamma2, beta2 per block */
+static double g_drop_rate = 0.0;
+static uint64_t g_drop_seed = 0;
+void qbo_set_normalizer(const real *ln, double dropout_rate, uint64_t dropout_seed) {
+    g_ln = ln;
+    g_drop_rate = dropout_rate;
+    g_drop_seed = dropout_seed;
+}
+void qbo_philox4x32_7(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+static real drop_factor(int64_t row, int col, int layer) {
+    if (!(g_drop_rate > 0.0) || g_drop_seed == 0) return R(1.0);
+    double rate = g_drop_rate < 0.999 ? g_drop_rate : 0.999;
+    uint32_t thresh = (uint32_t)lrintf((float)rate * 65536.0f);
+    uint32_t ctr[4] = {(uint32_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)(col >> 3) | ((uint32_t)layer << 16), 5u};
+    uint32_t key[2] = {(uint32_t)g_drop_seed, (uint32_t)(g_drop_seed >> 32)}, o[4];
+    qbo_philox4x32_7(ctr, key, o);
+    uint32_t w = o[(col >> 1) & 3];
+    uint32_t hw = (col & 1) ? (w >> 16) : (w & 0xffffu);
+    return hw < thresh ? R(0.0) : R(1.0 / (1.0 - (double)thresh / 65536.0));
+}
+/* out = act(LN(Dropout(in))) for a [B][rows_per_b][U] tensor */
+static void normalizer(const real *in, real *out, int B, int64_t rows_per_b, int U, int layer, int l, int which) {
+    for (int b = 0; b < B; ++b) {
+        const int64_t r0 = (int64_t)b * rows_per_b, n = rows_per_b * U;
+        double mean = 0, var = 0;
+        if (g_ln) {
+            for (int64_t i = 0; i < n; ++i) mean += (double)(in[r0 * U + i] * drop_factor(r0 + i / U, (int)(i % U), layer));
+            mean /= (double)n;
+            for (int64_t i = 0; i < n; ++i) {
+                double u = (double)(in[r0 * U + i] * drop_factor(r0 + i / U, (int)(i % U), layer)) - mean;
+                var += u * u;
+            }
+            var /= (double)n;
+        }
+        const real rstd = R(1.0 / sqrt(var + 1e-3));
+        for (int64_t i = 0; i < n; ++i) {
+            const int c = (int)(i % U);
+            real v = in[r0 * U + i] * drop_factor(r0 + i / U, c, layer);
+            if (g_ln) {
+                const real *gb = g_ln + ((int64_t)l * 4 + 2 * which) * U;
+                v = (v - R(mean)) * rstd * gb[c] + gb[U + c];
+            }
+            out[r0 * U + i] = activate(v);
+        }
+    }
+}
+
 void qbo_encoder_fwd_spatial(const qbo_weights *W, const qbo_loss_cfg *C, const real *x, int B, int X,
                              int Y, int Z, real *out2, real *sigma) {
     const int T = W->T, U = W->U, L = W->L;
@@ -550,8 +602,9 @@ void qbo_encoder_fwd_spatial(const qbo_weights *W, const qbo_loss_cfg *C, const 
     for (int l = 0; l < L; ++l) {
         const real *Wc = W->Wc + (int64_t)l * U * U, *bc = W->bc + l * U;
         for (int64_t v = 0; v < V; ++v) dense(b + v * U, Wc, bc, skip + v * U, U, U, 1); /* :148 */
-        for (int64_t e = 0; e < V * U; ++e) r[e] = activate(b[e]);                       /* :151 */
-        conv3x3(r, W->Wr1 + (int64_t)l * 9 * U * U, W->br1 + l * U, t1, B, X, Y, Z, U, 1); /* :152,155 */
+        normalizer(b, r, B, (int64_t)X * Y * Z, U, 2 * l, l, 0);                          /* :150-151 */
+        conv3x3(r, W->Wr1 + (int64_t)l * 9 * U * U, W->br1 + l * U, t1, B, X, Y, Z, U, 0); /* :152 */
+        normalizer(t1, t1, B, (int64_t)X * Y * Z, U, 2 * l + 1, l, 1);                    /* :154-155 */
         conv3x3(t1, W->Wr2 + (int64_t)l * 9 * U * U, W->br2 + l * U, r, B, X, Y, Z, U, 0); /* :156 */
         for (int64_t v = 0; v < V; ++v) {
             real gt[256];

@@ -75,6 +75,9 @@ void qbo_set_node0_zero(int on);
 
 /* test hook: round both operands of every encoder dense product to bfloat16 (voxel-wise encoder). */
 void qbo_set_encoder_bf16(int on);
+/* test hook: add_normalizer (model.py:131-140) in qbo_encoder_fwd_spatial: GroupNormalization parameters ln [L][4][U]
+ * (gamma1, beta1, gamma2, beta2 per block; NULL = off) and a training-mode dropout (rate, seed; seed 0 = inference) */
+void qbo_set_normalizer(const real *ln, double dropout_rate, uint64_t dropout_seed);
 /* test hook: 'gelu' (Keras exact form) instead of 'relu' in the encoder restatements (model.py:60, 115-120) */
 void qbo_set_activation_gelu(int on);
 

@@ -36,7 +36,8 @@ class LossCfg(C.Structure):
 class EncoderShape(C.Structure):
     _fields_ = [("T", C.c_int32), ("U", C.c_int32), ("L", C.c_int32),
                 ("channelwise_gating", C.c_int32), ("gate_offset", C.c_float),
-                ("spatial_taps", C.c_int32), ("precision", C.c_int32), ("activation", C.c_int32)]
+                ("spatial_taps", C.c_int32), ("precision", C.c_int32), ("activation", C.c_int32),
+                ("layer_norm", C.c_int32), ("dropout_rate", C.c_float), ("dropout_seed", C.c_uint64)]
 
 
 class Geometry(C.Structure):

@@ -10,10 +10,11 @@ namespace qb {
 struct CanonLayout {
     int T, U, L, G, taps;
     int W0, b0, blk0, blk_stride, Wf, bf, Ws, bs, total;
+    int ln;   // GroupNormalization parameters behind the heads: [L][4][U] = gamma1, beta1, gamma2, beta2 per block (0: none)
     // inside a block
     int Wc, bc, Wr1, br1, Wr2, br2, Wg, bg;
 };
-__host__ __device__ inline CanonLayout make_canon(int T, int U, int L, int cw, int taps = 1) {
+__host__ __device__ inline CanonLayout make_canon(int T, int U, int L, int cw, int taps = 1, int layer_norm = 0) {
     CanonLayout c;
     c.T = T; c.U = U; c.L = L; c.G = cw ? U : 1;
     c.taps = taps == 9 ? 9 : 1;
@@ -34,6 +35,11 @@ __host__ __device__ inline CanonLayout make_canon(int T, int U, int L, int cw, i
     c.Ws = c.bf + 5;
     c.bs = c.Ws + U * T;
     c.total = c.bs + T;
+    c.ln = 0;
+    if (layer_norm) {   // model.py:139: two normalizers per block (model.py:150, 154), per-channel scale and offset
+        c.ln = c.total;
+        c.total += L * 4 * U;
+    }
     return c;
 }
 

@@ -321,7 +321,7 @@ int check_encoder_shape(const qbold_ctx* ctx, const qbold_encoder_shape* s) {
 
 extern "C" int64_t qbold_encoder_num_params(const qbold_encoder_shape* s) {
     if (!s) return QBOLD_ERR_INVALID;
-    return qb::make_canon(s->T, s->U, s->L, s->channelwise_gating, s->spatial_taps).total;
+    return qb::make_canon(s->T, s->U, s->L, s->channelwise_gating, s->spatial_taps, s->layer_norm).total;
 }
 
 extern "C" int64_t qbold_encoder_packed_floats(const qbold_encoder_shape* s) {

@@ -48,9 +48,9 @@ int hip_fail(hipError_t e, const char* what);
 // entry points whose kernels implement relu only (gelu: the layer-wise forward, include/qbold_hip.h)
 #define QB_RELU_ONLY(shape, what)                                                                      \
     do {                                                                                               \
-        if ((shape) && (shape)->activation != QBOLD_ACT_RELU) {                                        \
-            qb::set_error(what ": activation 'gelu' runs through the layer-wise entry points "        \
-                               "(qbold_encoder_train_fwd / _bwd, qbold_encoder_spatial_fwd / _bwd)");   \
+        if ((shape) && ((shape)->activation != QBOLD_ACT_RELU || (shape)->layer_norm)) {               \
+            qb::set_error(what ": activation 'gelu' and use_layer_norm run through the layer-wise "    \
+                               "entry points (qbold_encoder_train_fwd / _bwd, qbold_encoder_spatial_fwd / _bwd)");   \
             return QBOLD_ERR_UNSUPPORTED;                                                              \
         }                                                                                              \
     } while (0)

@@ -2572,10 +2572,253 @@ constexpr int kSlabBlocks = 512;  // xtd partial slabs per launch: two 1024-thre
 //   0: n   1: h   then per block l (base 2 + 5 l): skip, t, r, gl (gate logits), bout
 //   stream 1 uses: 0: n, 1: h, 2 + l: a_l
 // ---------------------------------------------------------------------------------------------
+// ---- add_normalizer (model.py:131-140): Dropout, GroupNormalization(groups = 1, axis = -1), then the Activation --------
+// One "normalizer" sits in front of each of a residual path's two activations (model.py:150-151, 154-155):
+//   u = Dropout(x)         training only: u = x keep / (1 - rate), keep ~ Bernoulli(1 - rate) per element
+//   v = gamma (u - mean_g) rstd_g + beta    tfa GroupNormalization, groups = 1: mean and biased variance over ALL
+//                          positions and channels of one batch element g (a voxel of an (N,1,1,1,C) batch, a whole crop
+//                          of a [B][X][Y][Z][C] batch), rstd = 1 / sqrt(var + 1e-3)
+//   a = act(v)
+// The library's own dropout stream (the reference's is TensorFlow's): element (row, column c) of normalizer `layer` is
+// dropped iff half-word c & 7 of Philox4x32-7(ctr = (row_lo, row_hi, (c >> 3) | layer << 16, 5), key = seed) is below
+// rate 2^16 -- regenerated from the same keys by the backward.  Off the hot path: general element-wise kernels.
+struct NormSpec {
+    int layer_norm;        // GroupNormalization on
+    int act;               // qbold_activation
+    uint32_t drop_thresh;  // 0: no dropout
+    float keep_scale;      // 1 / (1 - rate)
+    uint64_t seed;
+    uint32_t layer;
+    int64_t rows_per_group;
+};
+constexpr float kLnEps = 1e-3f;   // tfa GroupNormalization's default epsilon
+
+__device__ __forceinline__ float drop_factor(const NormSpec& sp, int64_t row, int col) {
+    if (sp.drop_thresh == 0u) return 1.0f;
+    const uint4 o = qb::philox4x32_7(make_uint4((uint32_t)row, (uint32_t)((uint64_t)row >> 32),
+                                                (uint32_t)(col >> 3) | (sp.layer << 16), 5u),
+                                     make_uint2((uint32_t)sp.seed, (uint32_t)(sp.seed >> 32)));
+    const uint32_t w = ((col >> 1) & 3) == 0 ? o.x : ((col >> 1) & 3) == 1 ? o.y : ((col >> 1) & 3) == 2 ? o.z : o.w;
+    const uint32_t hw = (col & 1) ? (w >> 16) : (w & 0xffffu);
+    return hw < sp.drop_thresh ? 0.0f : sp.keep_scale;
+}
+__device__ __forceinline__ float act_of(int act, float v) {
+    return act == QBOLD_ACT_GELU ? 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)) : fmaxf(v, 0.0f);
+}
+__device__ __forceinline__ float dact_of(int act, float v) {
+    if (act != QBOLD_ACT_GELU) return v > 0.0f ? 1.0f : 0.0f;
+    return 0.5f * (1.0f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
+}
+
+// mean and rstd of u = Dropout(x) per group: one 256-thread block per group, two passes (mean, then the variance about it)
+__global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, int ld, int U, NormSpec sp,
+                                                         float2* __restrict__ stats) {
+    __shared__ double red[256];
+    const int64_t g = blockIdx.x, r0 = g * sp.rows_per_group;
+    const int64_t n = sp.rows_per_group * (int64_t)U;
+    double mean = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        double acc = 0.0;
+        for (int64_t i = threadIdx.x; i < n; i += 256) {
+            const int64_t row = r0 + i / U;
+            const int col = (int)(i % U);
+            const double u = (double)(x[row * ld + col] * drop_factor(sp, row, col));
+            acc += pass == 0 ? u : (u - mean) * (u - mean);
+        }
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        const double tot = red[0] / (double)n;
+        __syncthreads();
+        if (pass == 0) mean = tot;
+        else if (threadIdx.x == 0) stats[g] = make_float2((float)mean, 1.0f / sqrtf((float)tot + kLnEps));
+    }
+}
+// the same for groups of one row (voxel batches): a wave per row
+__global__ __launch_bounds__(256) void norm_stats_rows_kernel(const float* __restrict__ x, int ld, int U, NormSpec sp,
+                                                              float2* __restrict__ stats, int64_t N) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6); row < N; row += (int64_t)gridDim.x * 4) {
+        float u[4] = {0.0f, 0.0f, 0.0f, 0.0f}, acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int col = lane + 64 * k;
+            if (col < U) u[k] = x[row * ld + col] * drop_factor(sp, row, col);
+            acc += u[k];
+        }
+        const float mean = qb::wave_sum(acc) / (float)U;
+        acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (lane + 64 * k < U) acc += (u[k] - mean) * (u[k] - mean);
+        const float var = qb::wave_sum(acc) / (float)U;
+        if (lane == 0) stats[row] = make_float2(mean, 1.0f / sqrtf(var + kLnEps));
+    }
+}
+// a = act(LN(Dropout(x)));  gb: gamma [U], beta [U] (layer_norm) or null
+__global__ void norm_act_fwd_kernel(const float* __restrict__ x, int ld, int U, NormSpec sp,
+                                    const float2* __restrict__ stats, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, float* __restrict__ out, int64_t N) {
+    const int64_t n = N * (int64_t)U;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / U;
+        const int col = (int)(i % U);
+        float v = x[row * ld + col] * drop_factor(sp, row, col);
+        if (sp.layer_norm) {
+            const float2 st = stats[row / sp.rows_per_group];
+            v = fmaf((v - st.x) * st.y, gamma[col], beta[col]);
+        }
+        out[row * ld + col] = act_of(sp.act, v);
+    }
+}
+// Backward, step 1 (layer_norm): per group S1 = sum dxh, S2 = sum dxh xh with dxh = d_a act'(v) gamma; one block per group
+__global__ __launch_bounds__(256) void norm_bwd_group_sums_kernel(const float* __restrict__ x, const float* __restrict__ d,
+                                                                  int ld, int U, NormSpec sp,
+                                                                  const float2* __restrict__ stats,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
+                                                                  float2* __restrict__ gsum) {
+    __shared__ double red[2][256];
+    const int64_t g = blockIdx.x, r0 = g * sp.rows_per_group;
+    const int64_t n = sp.rows_per_group * (int64_t)U;
+    const float2 st = stats[g];
+    double a1 = 0.0, a2 = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int64_t row = r0 + i / U;
+        const int col = (int)(i % U);
+        const float xh = (x[row * ld + col] * drop_factor(sp, row, col) - st.x) * st.y;
+        const float v = fmaf(xh, gamma[col], beta[col]);
+        const float dxh = d[row * ld + col] * dact_of(sp.act, v) * gamma[col];
+        a1 += (double)dxh;
+        a2 += (double)(dxh * xh);
+    }
+    red[0][threadIdx.x] = a1;
+    red[1][threadIdx.x] = a2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) gsum[g] = make_float2((float)(red[0][0] / (double)n), (float)(red[1][0] / (double)n));
+}
+// the same for groups of one row (voxel batches): a wave per row
+__global__ __launch_bounds__(256) void norm_bwd_row_sums_kernel(const float* __restrict__ x, const float* __restrict__ d,
+                                                                int ld, int U, NormSpec sp, const float2* __restrict__ stats,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float2* __restrict__ gsum, int64_t N) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6); row < N; row += (int64_t)gridDim.x * 4) {
+        const float2 st = stats[row];
+        float a1 = 0.0f, a2 = 0.0f;
+        for (int col = lane; col < U; col += 64) {
+            const float xh = (x[row * ld + col] * drop_factor(sp, row, col) - st.x) * st.y;
+            const float dxh = d[row * ld + col] * dact_of(sp.act, fmaf(xh, gamma[col], beta[col])) * gamma[col];
+            a1 += dxh;
+            a2 = fmaf(dxh, xh, a2);
+        }
+        a1 = qb::wave_sum(a1);
+        a2 = qb::wave_sum(a2);
+        if (lane == 0) gsum[row] = make_float2(a1 / (float)U, a2 / (float)U);
+    }
+}
+// Backward, step 2 (layer_norm): d gamma[c] = sum_rows d_v xh, d beta[c] = sum_rows d_v, d_v = d_a act'(v).  A block owns
+// a contiguous row range, a thread a column; partial [block][2 U] doubles, added in block order by the kernel below
+// (bitwise reproducible like every other weight gradient).
+constexpr int kNormBlocks = 256;
+__global__ __launch_bounds__(256) void norm_bwd_param_partial_kernel(const float* __restrict__ x, const float* __restrict__ d,
+                                                                     int ld, int U, NormSpec sp,
+                                                                     const float2* __restrict__ stats,
+                                                                     const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta,
+                                                                     double* __restrict__ partial, int64_t N) {
+    const int col = threadIdx.x;
+    const int64_t per = (N + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = r0 + per < N ? r0 + per : N;
+    double ag = 0.0, ab = 0.0;
+    if (col < U)
+        for (int64_t row = r0; row < r1; ++row) {
+            const float2 st = stats[row / sp.rows_per_group];
+            const float xh = (x[row * ld + col] * drop_factor(sp, row, col) - st.x) * st.y;
+            const float dv = d[row * ld + col] * dact_of(sp.act, fmaf(xh, gamma[col], beta[col]));
+            ag += (double)(dv * xh);
+            ab += (double)dv;
+        }
+    if (col < U) {
+        partial[(int64_t)blockIdx.x * 2 * U + col] = ag;
+        partial[(int64_t)blockIdx.x * 2 * U + U + col] = ab;
+    }
+}
+__global__ void norm_bwd_param_reduce_kernel(const double* __restrict__ partial, int nblk, int U,
+                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * U) return;
+    double a = 0.0;
+    for (int b = 0; b < nblk; ++b) a += partial[(int64_t)b * 2 * U + c];
+    (c < U ? dgamma[c] : dbeta[c - U]) = (float)a;
+}
+// Backward, step 3: d_x in place of d_a.  layer_norm: d_u = rstd (dxh - S1 - xh S2); then through the dropout
+__global__ void norm_act_bwd_kernel(const float* __restrict__ x, float* __restrict__ d, int ld, int U, NormSpec sp,
+                                    const float2* __restrict__ stats, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float2* __restrict__ gsum, int64_t N) {
+    const int64_t n = N * (int64_t)U;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / U;
+        const int col = (int)(i % U);
+        const float keep = drop_factor(sp, row, col);
+        const float u = x[row * ld + col] * keep;
+        float du;
+        if (sp.layer_norm) {
+            const int64_t g = row / sp.rows_per_group;
+            const float2 st = stats[g], gs = gsum[g];
+            const float xh = (u - st.x) * st.y;
+            const float dxh = d[row * ld + col] * dact_of(sp.act, fmaf(xh, gamma[col], beta[col])) * gamma[col];
+            du = st.y * (dxh - gs.x - xh * gs.y);
+        } else {
+            du = d[row * ld + col] * dact_of(sp.act, u);
+        }
+        d[row * ld + col] = du * keep;
+    }
+}
+// d *= act'(z) over the live columns (the skip path's activation)
+__global__ void dact_mul_kernel(float* d, const float* __restrict__ z, int act, int64_t rows, int ld, int U) {
+    const int64_t n = rows * (int64_t)U;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = (i / U) * ld + (i % U);
+        d[e] *= dact_of(act, z[e]);
+    }
+}
+
+static bool norm_mode(const qbold_encoder_shape* s) {
+    return s->layer_norm || (s->dropout_rate > 0.0f && s->dropout_seed != 0);
+}
+static NormSpec norm_spec(const qbold_encoder_shape* s, int layer, const qbold_geometry* gm) {
+    NormSpec sp;
+    sp.layer_norm = s->layer_norm ? 1 : 0;
+    sp.act = s->activation;
+    const bool drop = s->dropout_rate > 0.0f && s->dropout_seed != 0;
+    const float rate = s->dropout_rate < 0.999f ? s->dropout_rate : 0.999f;
+    sp.drop_thresh = drop ? (uint32_t)lrintf(rate * 65536.0f) : 0u;
+    sp.keep_scale = drop ? 1.0f / (1.0f - (float)sp.drop_thresh / 65536.0f) : 1.0f;
+    sp.seed = s->dropout_seed;
+    sp.layer = (uint32_t)layer;
+    sp.rows_per_group = gm ? (int64_t)gm->X * gm->Y * gm->Z : 1;
+    return sp;
+}
+// scratch behind the slabs: group statistics and backward sums (float2 per group each), parameter partials
+static int64_t norm_scratch_floats(const qbold_encoder_shape* s, int64_t N) {
+    return s && (s->layer_norm || s->dropout_rate > 0.0f) ? 4 * N + 2 * (int64_t)kNormBlocks * 2 * 256 + 16 : 0;
+}
+
 extern "C" int64_t qbold_train_workspace_floats(const qbold_encoder_shape* shape, int64_t N) {
     if (!shape || N < 0) return QBOLD_ERR_INVALID;
     const int64_t slots = 2 + 5 * (int64_t)shape->L + 5;  // activations + 5 delta scratch tensors
-    return slots * N * train_ld(shape->U) + (int64_t)9 * kSlabBlocks * (64 * 64 + 64);  // 9: taps of a 3x3x1 kernel
+    return slots * N * train_ld(shape->U) + (int64_t)9 * kSlabBlocks * (64 * 64 + 64)   // 9: taps of a 3x3x1 kernel
+           + norm_scratch_floats(shape, N);
 }
 
 static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* w,
@@ -2591,7 +2834,7 @@ static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
         QB_REQUIRE(stream_sel == 2, "only stream 2 has spatial convolutions");
     }
     QB_REQUIRE(stream_sel == 1 || stream_sel == 2, "qbold_encoder_train_fwd: stream must be 1 or 2");
-    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating, shape->spatial_taps);
+    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating, shape->spatial_taps, shape->layer_norm);
     const int T = c.T, U = c.U, L = c.L, G = c.G;
     const int ld = train_ld(U);
     Launcher k{ctx, (hipStream_t)stream, N, ld};
@@ -2615,6 +2858,42 @@ static int train_fwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             const float* wb = w + c.blk0 + l * c.blk_stride;
             float* skip = slot(2 + 5 * l), *t = slot(3 + 5 * l), *r = slot(4 + 5 * l);
             float* gl = slot(5 + 5 * l), *bout = slot(6 + 5 * l);
+            if (norm_mode(shape)) {
+                // model.py:147-157 with add_normalizer live: skip as ever; the residual path goes
+                //   a1 = act(LN1(D1(b)))  ->  p = conv1(a1)  [kept in the `t` slot, pre-normalizer]  ->
+                //   a2 = act(LN2(D2(p)))  ->  r = conv2(a2)
+                // a1 / a2 live in the backward's scratch slots (free during the forward; the backward recomputes them)
+                const int ctr = (!gm && c.taps == 9) ? 4 * U * U : 0;
+                float* a1 = slot(2 + 5 * L), *a2 = slot(2 + 5 * L + 1);
+                float2* stats = reinterpret_cast<float2*>(ws + ((int64_t)(2 + 5 * L + 5) * N * ld +
+                                                                (int64_t)9 * kSlabBlocks * (64 * 64 + 64)));
+                const float* lnp = c.ln ? w + c.ln + (int64_t)l * 4 * U : nullptr;
+                auto normalizer = [&](const float* xin, int which, float* out) {
+                    const NormSpec sp = norm_spec(shape, 2 * l + which, gm);
+                    if (sp.layer_norm) {
+                        if (sp.rows_per_group == 1)
+                            hipLaunchKernelGGL(norm_stats_rows_kernel, dim3((unsigned)((N + 3) / 4 < 4096 ? (N + 3) / 4 : 4096)),
+                                               dim3(256), 0, k.s, xin, ld, U, sp, stats, N);
+                        else
+                            hipLaunchKernelGGL(norm_stats_kernel, dim3((unsigned)(N / sp.rows_per_group)), dim3(256), 0, k.s,
+                                               xin, ld, U, sp, stats);
+                    }
+                    hipLaunchKernelGGL(norm_act_fwd_kernel, dim3(k.ew()), dim3(256), 0, k.s, xin, ld, U, sp, stats,
+                                       lnp ? lnp + 2 * which * U : nullptr, lnp ? lnp + (2 * which + 1) * U : nullptr, out, N);
+                };
+                k.xw(cur, ld, U, wb + c.Wc, U, 0, wb + c.bc, skip, U, A_OUT, 0, nullptr);
+                normalizer(cur, 0, a1);
+                if (gm) k.conv3x3(a1, wb + c.Wr1, U, wb + c.br1, t, ACT_NONE, 0, nullptr, *gm);
+                else k.xw(a1, ld, U, wb + c.Wr1 + ctr, U, 0, wb + c.br1, t, U, ACT_NONE, 0, nullptr);
+                normalizer(t, 1, a2);
+                if (gm) k.conv3x3(a2, wb + c.Wr2, U, wb + c.br2, r, ACT_NONE, 0, nullptr, *gm);
+                else k.xw(a2, ld, U, wb + c.Wr2 + ctr, U, 0, wb + c.br2, r, U, ACT_NONE, 0, nullptr);
+                k.xw(r, ld, U, wb + c.Wg, G, 0, wb + c.bg, gl, G, ACT_NONE, 0, nullptr);
+                hipLaunchKernelGGL(gate_fwd_kernel, dim3(k.ew()), dim3(256), 0, k.s, gl, skip, r, bout,
+                                   shape->gate_offset, U, G, ld, N);
+                cur = bout;
+                continue;
+            }
             const bool fork = !gm && U <= 64 && ld == kLd && !(ctx->kernel_sel & 8192) && !gelu;
             if (!fork) k.xw(cur, ld, U, wb + c.Wc, U, 0, wb + c.bc, skip, U, A_OUT, 0, nullptr);
             // relu(b) feeds the first residual conv (model.py:151): applied to the rows as they are loaded
@@ -2680,7 +2959,8 @@ extern "C" int qbold_encoder_spatial_fwd(const qbold_ctx* ctx, const qbold_encod
 // the condition under which a stream-2 voxel-batch backward runs block_bwd_kernel (one definition: the forward
 // leaves out what that kernel recomputes only if this says so)
 static bool block_bwd_applies(const qbold_ctx* ctx, const qbold_encoder_shape* s, int64_t N) {
-    return ctx && s && s->activation == QBOLD_ACT_RELU && s->U >= 1 && s->U <= 64 && s->channelwise_gating && s->L >= 1 && s->L <= 2 && s->T <= 27 &&
+    return ctx && s && s->activation == QBOLD_ACT_RELU && !s->layer_norm && !(s->dropout_rate > 0.0f) && s->U >= 1 && s->U <= 64 &&
+           s->channelwise_gating && s->L >= 1 && s->L <= 2 && s->T <= 27 &&
            s->T == ctx->dev.T && s->precision == QBOLD_ENC_F32 && N > 0 && N < ((int64_t)1 << 23) &&
            !(ctx->kernel_sel & 131072);
 }
@@ -2706,7 +2986,7 @@ extern "C" int qbold_encoder_train_bwd_recomputes(const qbold_ctx* ctx, const qb
 static int train_bwd_gelu(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* w, int stream_sel,
                           float* ws, const float* g_q, const float* g_ls, const double* sums, float* grad, int64_t N,
                           void* stream, const qbold_geometry* gm) {
-    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating, shape->spatial_taps);
+    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating, shape->spatial_taps, shape->layer_norm);
     const int T = c.T, U = c.U, L = c.L, G = c.G;
     const int ld = train_ld(shape->U);
     Launcher k{ctx, (hipStream_t)stream, N, ld};
@@ -2796,6 +3076,128 @@ static int train_bwd_gelu(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     return QBOLD_OK;
 }
 
+// The backward of stream 2 with add_normalizer live (use_layer_norm and / or dropout in a training step), relu or gelu:
+// the structure of train_bwd_gelu -- every pre-activation where its derivative is needed -- with each residual
+// activation's normalizer differentiated in front of it (norm_act_bwd_kernel) and the GroupNormalization parameters'
+// gradients beside the kernels' (behind the heads in the canonical blob).
+static int train_bwd_norm(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* w, float* ws,
+                          const float* g_q, const float* g_ls, const double* sums, float* grad, int64_t N, void* stream,
+                          const qbold_geometry* gm) {
+    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating, shape->spatial_taps, shape->layer_norm);
+    const int T = c.T, U = c.U, L = c.L, G = c.G;
+    const int ld = train_ld(shape->U), act = shape->activation;
+    const int A_OUT = act == QBOLD_ACT_GELU ? ACT_GELU : ACT_RELU;
+    (void)A_OUT;
+    Launcher k{ctx, (hipStream_t)stream, N, ld};
+    auto slot = [&](int i) { return ws + (int64_t)i * N * ld; };
+    const int base = 2 + 5 * L;
+    float* dA = slot(base), *dB = slot(base + 1), *dC = slot(base + 2), *dD = slot(base + 3), *dE = slot(base + 4);
+    float* partial = ws + (int64_t)(base + 5) * N * ld;
+    float* nscratch = partial + (int64_t)9 * kSlabBlocks * (64 * 64 + 64);
+    float2* stats = reinterpret_cast<float2*>(nscratch);
+    float2* gsum = reinterpret_cast<float2*>(nscratch + 2 * N);
+    double* ppart = reinterpret_cast<double*>(nscratch + 4 * N);
+    QB_HIP(hipMemsetAsync(grad, 0, sizeof(float) * c.total, k.s));
+    hipLaunchKernelGGL(head_delta_kernel, dim3(k.ew()), dim3(256), 0, k.s, g_q, g_ls, T, sums, dA, ld, N);
+    const float* last = slot(6 + 5 * (L - 1));
+    int64_t nb = N / (16 * 16 * 4);
+    const int64_t cap = ctx->num_cus < kSlabBlocks ? ctx->num_cus : kSlabBlocks;
+    const int slabs = (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
+    const int slabs9 = (int)((N + 511) / 512 < ctx->num_cus ? ((N + 511) / 512 > 0 ? (N + 511) / 512 : 1)
+                                                           : (ctx->num_cus < kSlabBlocks ? ctx->num_cus : kSlabBlocks));
+    auto times_dact = [&](float* d, const float* z) {
+        hipLaunchKernelGGL(dact_mul_kernel, dim3(k.ew()), dim3(256), 0, k.s, d, z, act, N, ld, U);
+    };
+    k.xtd(last, U, dA, 5, partial, slabs, grad + c.Wf, 5, grad + c.bf, 0);
+    k.xw(dA, ld, 5, w + c.Wf, 5, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
+    if (g_ls) {
+        k.xtd(last, U, dA + 5, T, partial, slabs, grad + c.Ws, T, grad + c.bs, 0);
+        k.xw(dA + 5, ld, T, w + c.Ws, T, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);
+    }
+    float* Z = dA;   // the head delta has been consumed: scratch
+    for (int l = L - 1; l >= 0; --l) {
+        const float* wb = w + c.blk0 + l * c.blk_stride;
+        float* gb = grad + c.blk0 + l * c.blk_stride;
+        float* skip = slot(2 + 5 * l);
+        const float* p = slot(3 + 5 * l), *r = slot(4 + 5 * l), *gl = slot(5 + 5 * l);
+        const float* b_in = l == 0 ? slot(1) : slot(6 + 5 * (l - 1));
+        const int ctr = (!gm && c.taps == 9) ? 4 * U * U : 0;
+        const float* lnp = c.ln ? w + c.ln + (int64_t)l * 4 * U : nullptr;
+        float* lng = c.ln ? grad + c.ln + (int64_t)l * 4 * U : nullptr;
+        // recompute a = act(LN(D(x))) of normalizer `which` into `out`
+        auto normalizer = [&](const float* xin, int which, float* out) {
+            const NormSpec sp = norm_spec(shape, 2 * l + which, gm);
+            if (sp.layer_norm) {
+                if (sp.rows_per_group == 1)
+                    hipLaunchKernelGGL(norm_stats_rows_kernel, dim3((unsigned)((N + 3) / 4 < 4096 ? (N + 3) / 4 : 4096)), dim3(256),
+                                       0, k.s, xin, ld, U, sp, stats, N);
+                else
+                    hipLaunchKernelGGL(norm_stats_kernel, dim3((unsigned)(N / sp.rows_per_group)), dim3(256), 0, k.s, xin, ld,
+                                       U, sp, stats);
+            }
+            hipLaunchKernelGGL(norm_act_fwd_kernel, dim3(k.ew()), dim3(256), 0, k.s, xin, ld, U, sp, stats,
+                               lnp ? lnp + 2 * which * U : nullptr, lnp ? lnp + (2 * which + 1) * U : nullptr, out, N);
+        };
+        // d (in: d a, out: d x) through normalizer `which` applied to xin; `stats` must hold xin's statistics
+        auto normalizer_bwd = [&](const float* xin, int which, float* d) {
+            const NormSpec sp = norm_spec(shape, 2 * l + which, gm);
+            const float* ga = lnp ? lnp + 2 * which * U : nullptr, *be = lnp ? lnp + (2 * which + 1) * U : nullptr;
+            if (sp.layer_norm) {
+                const int64_t groups = N / sp.rows_per_group;
+                if (sp.rows_per_group == 1)
+                    hipLaunchKernelGGL(norm_bwd_row_sums_kernel, dim3((unsigned)((N + 3) / 4 < 4096 ? (N + 3) / 4 : 4096)), dim3(256),
+                                       0, k.s, xin, d, ld, U, sp, stats, ga, be, gsum, N);
+                else
+                    hipLaunchKernelGGL(norm_bwd_group_sums_kernel, dim3((unsigned)groups), dim3(256), 0, k.s, xin, d, ld, U, sp,
+                                       stats, ga, be, gsum);
+                const int nblk = (int)(N < kNormBlocks ? N : kNormBlocks);
+                hipLaunchKernelGGL(norm_bwd_param_partial_kernel, dim3(nblk), dim3(256), 0, k.s, xin, d, ld, U, sp, stats, ga,
+                                   be, ppart, N);
+                hipLaunchKernelGGL(norm_bwd_param_reduce_kernel, dim3((2 * U + 255) / 256), dim3(256), 0, k.s, ppart, nblk, U,
+                                   lng + 2 * which * U, lng + (2 * which + 1) * U);
+            }
+            hipLaunchKernelGGL(norm_act_bwd_kernel, dim3(k.ew()), dim3(256), 0, k.s, xin, d, ld, U, sp, stats, ga, be, gsum, N);
+        };
+        // dB = d b_out  ->  dC = d skip (post-activation), dD = d r, dE = d gate logits
+        hipLaunchKernelGGL(gate_bwd_kernel, dim3(k.grid()), dim3(256), 0, k.s, dB, gl, skip, r, dC, dD, dE,
+                           shape->gate_offset, U, G, ld, N, 0);
+        k.xtd(r, U, dE, G, partial, slabs, gb + c.Wg, G, gb + c.bg, 0);
+        k.xw(dE, ld, G, wb + c.Wg, G, 1, nullptr, dD, U, ACT_NONE, 1, nullptr);       // d r += d gl Wg^T
+        // second convolution: input a2 = act(LN2(D2(p)))
+        normalizer(p, 1, Z);                                                          // a2 (and p's statistics)
+        if (gm) {
+            k.xtd9(Z, U, dD, partial, slabs9, gb + c.Wr2, gb + c.br2, *gm);
+            k.conv3x3(dD, wb + c.Wr2, U, nullptr, dE, ACT_NONE, 1, nullptr, *gm);     // d a2
+        } else {
+            k.xtd(Z, U, dD, U, partial, slabs, gb + c.Wr2 + ctr, U, gb + c.br2, 0);
+            k.xw(dD, ld, U, wb + c.Wr2 + ctr, U, 1, nullptr, dE, U, ACT_NONE, 0, nullptr);
+        }
+        normalizer_bwd(p, 1, dE);                                                     // d p
+        // first convolution: input a1 = act(LN1(D1(b_in)))
+        float* A1 = skip;                                                             // the skip slot is free from here
+        normalizer(b_in, 0, A1);
+        if (gm) {
+            k.xtd9(A1, U, dE, partial, slabs9, gb + c.Wr1, gb + c.br1, *gm, 0);
+            k.conv3x3(dE, wb + c.Wr1, U, nullptr, dB, ACT_NONE, 1, nullptr, *gm);     // d a1
+        } else {
+            k.xtd(A1, U, dE, U, partial, slabs, gb + c.Wr1 + ctr, U, gb + c.br1, 0, 0);
+            k.xw(dE, ld, U, wb + c.Wr1 + ctr, U, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
+        }
+        normalizer_bwd(b_in, 0, dB);                                                  // d b_in, residual path
+        // skip path: z = b_in Wc + bc, d z = d skip act'(z)
+        k.xw(b_in, ld, U, wb + c.Wc, U, 0, wb + c.bc, Z, U, ACT_NONE, 0, nullptr);
+        times_dact(dC, Z);
+        k.xtd(b_in, U, dC, U, partial, slabs, gb + c.Wc, U, gb + c.bc, 0);
+        k.xw(dC, ld, U, wb + c.Wc, U, 1, nullptr, dB, U, ACT_NONE, 1, nullptr);       // d b_in += d z Wc^T
+    }
+    // first layer: z_0 = n W0 + b0; dW0 = n^T (dB act'(z_0))
+    k.xw(slot(0), ld, T, w + c.W0, U, 0, w + c.b0, Z, U, ACT_NONE, 0, nullptr);
+    times_dact(dB, Z);
+    k.xtd(slot(0), T, dB, U, partial, slabs, grad + c.W0, U, grad + c.b0, 0);
+    QB_HIP(hipGetLastError());
+    return QBOLD_OK;
+}
+
 // g_head_q [N][5], g_head_ls [N][T] (stream 2 only; may be NULL), sums: device double[3] whose
 // third entry is sum(mask) (NULL = gradients already normalised).  grad: canonical layout, overwritten.
 static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* w,
@@ -2812,10 +3214,12 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     }
     QB_REQUIRE(N > 0 && w && ws && g_q && grad, "qbold_encoder_train_bwd: bad argument");
     QB_REQUIRE(stream_sel == 1 || stream_sel == 2, "qbold_encoder_train_bwd: stream must be 1 or 2");
-    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating, shape->spatial_taps);
+    const qb::CanonLayout c = qb::make_canon(shape->T, shape->U, shape->L, shape->channelwise_gating, shape->spatial_taps, shape->layer_norm);
     const int T = c.T, U = c.U, L = c.L, G = c.G;
     const int ld = train_ld(shape->U);
     QB_REQUIRE(5 + shape->T <= ld, "qbold_encoder_train_bwd: the head delta (5 + T columns) exceeds the row stride");
+    if (stream_sel == 2 && norm_mode(shape))
+        return train_bwd_norm(ctx, shape, w, ws, g_q, g_ls, sums, grad, N, stream, gm);
     if (shape->activation == QBOLD_ACT_GELU)
         return train_bwd_gelu(ctx, shape, w, stream_sel, ws, g_q, g_ls, sums, grad, N, stream, gm);
     Launcher k{ctx, (hipStream_t)stream, N, ld};

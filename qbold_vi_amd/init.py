@@ -29,7 +29,7 @@ def _he_normal(rng, shape, fan_in):
 
 
 def init_encoder_weights(T=11, U=60, L=2, channelwise_gating=True, resid_init_std=0.05,
-                         im_loss_sigma=0.05, seed=1, spatial_taps=1):
+                         im_loss_sigma=0.05, seed=1, spatial_taps=1, layer_norm=False):
     rng = np.random.default_rng(seed)
     sh = weight_shapes(T, U, L, channelwise_gating, spatial_taps)
     w = {"W0": _he_normal(rng, sh["W0"], T), "Wc": _he_normal(rng, sh["Wc"], U),
@@ -39,4 +39,6 @@ def init_encoder_weights(T=11, U=60, L=2, channelwise_gating=True, resid_init_st
     for n in ("b0", "bc", "br1", "br2", "bg", "bf"):
         w[n] = np.zeros(sh[n], np.float32)
     w["bs"] = np.full(sh["bs"], np.log(im_loss_sigma), np.float32)
+    if layer_norm:   # tfa GroupNormalization: gamma 'ones', beta 'zeros'; [L][gamma1, beta1, gamma2, beta2][U]
+        w["ln"] = np.tile(np.array([1.0, 0.0, 1.0, 0.0], np.float32)[None, :, None], (L, 1, U))
     return w

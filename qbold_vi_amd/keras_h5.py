@@ -119,10 +119,34 @@ def _by_roles(layers):
     return out + [final[0], last]
 
 
+def _split_group_norm(named):
+    """use_layer_norm=True (model.py:139): tfa GroupNormalization layers hold two rank-1 variables, gamma and beta,
+    created in block order -- two layers per block (model.py:150, 154).  Taken out before the Conv3D layers are paired;
+    returned as [L][4][U] (gamma1, beta1, gamma2, beta2), the canonical 'ln' tensor."""
+    import re
+    gn = [(n, a) for n, a in named if "group_normalization" in n]
+    if not gn:
+        return named, None
+    layers = {}
+    for n, a in gn:
+        key = n.rsplit("/", 1)[0]
+        m = re.search(r"group_normalization(?:_(\d+))?$", key)
+        layers.setdefault((int(m.group(1)) if m and m.group(1) else 0, key), {})["gamma" if "gamma" in n else "beta"] = a
+    ordered = [layers[k] for k in sorted(layers)]
+    if len(ordered) % 2 or any(set(d) != {"gamma", "beta"} for d in ordered):
+        raise ValueError("GroupNormalization layers do not come as (gamma, beta), two layers per block")
+    ln = np.stack([np.stack([ordered[2 * l]["gamma"], ordered[2 * l]["beta"], ordered[2 * l + 1]["gamma"],
+                             ordered[2 * l + 1]["beta"]]) for l in range(len(ordered) // 2)]).astype(np.float32)
+    return [(n, a) for n, a in named if "group_normalization" not in n], ln
+
+
 def flatten_variables(f):
     """All variables of a Keras weights file (an open h5py.File or anything with the same mapping /
     .attrs interface) as float32 arrays in the reference's layer CREATION order, kernel before bias."""
-    named, hyper = _split_hyper_prior(_named_variables(f))
+    named, ln = _split_group_norm(_named_variables(f))
+    named, hyper = _split_hyper_prior(named)
+    if ln is not None:
+        flatten_variables.last_ln = ln    # picked up by load_keras_h5 (the flattened list keeps its documented shape)
     layers = _pair_layers(named)
     numbers = [_creation_number(key + "/kernel:0") for key, _, _ in layers]
     if all(n is not None for n in numbers) and len(set(numbers)) == len(numbers):
@@ -186,7 +210,11 @@ def variables_to_canonical(variables):
 def load_keras_h5(path):
     """-> canonical weight dict from a Keras `.h5` weights file of the reference's encoder."""
     with _h5py().File(path, "r") as f:
-        return variables_to_canonical(flatten_variables(f))
+        flatten_variables.last_ln = None
+        w = variables_to_canonical(flatten_variables(f))
+        if flatten_variables.last_ln is not None:
+            w["ln"] = flatten_variables.last_ln
+        return w
 
 
 def canonical_to_variables(w):
@@ -204,6 +232,13 @@ def canonical_to_variables(w):
     out += [(f"conv3d_{n}/kernel:0", k1(w["Wf"])), (f"conv3d_{n}/bias:0", np.asarray(w["bf"], np.float32))]
     n += 1
     out += [(f"conv3d_{n}/kernel:0", k1(w["Ws"])), (f"conv3d_{n}/bias:0", np.asarray(w["bs"], np.float32))]
+    if w.get("ln") is not None:              # tfa GroupNormalization layers, two per block: gamma, beta
+        ln = np.asarray(w["ln"], np.float32)
+        for l in range(ln.shape[0]):
+            for j in range(2):
+                name = "group_normalization" + ("" if 2 * l + j == 0 else f"_{2 * l + j}")
+                out.append((f"{name}/gamma:0", ln[l, 2 * j]))
+                out.append((f"{name}/beta:0", ln[l, 2 * j + 1]))
     if w.get("hyper_prior") is not None:     # tfp.layers.VariableLayer names its variable 'constant:0'
         out.append(("variable_layer/constant:0", np.asarray(w["hyper_prior"], np.float32)))
     return out
@@ -214,8 +249,11 @@ def save_keras_h5(path, w):
     h5py = _h5py()
     var = canonical_to_variables(w)
     hyper = [var.pop()] if var[-1][0].startswith("variable_layer/") else []
-    # the hyper-prior layer is created inside the inner model, after the final layer (model.py:196-205)
-    groups = [("conv3d", var[:2]), ("model", var[2:-2] + hyper), (var[-2][0].split("/")[0], var[-2:])]
+    norms = [v for v in var if v[0].startswith("group_normalization")]
+    var = [v for v in var if not v[0].startswith("group_normalization")]
+    # the hyper-prior layer is created inside the inner model, after the final layer (model.py:196-205); the
+    # GroupNormalization layers belong to the inner model's blocks
+    groups = [("conv3d", var[:2]), ("model", var[2:-2] + norms + hyper), (var[-2][0].split("/")[0], var[-2:])]
     with h5py.File(path, "w") as f:
         f.attrs["layer_names"] = [g.encode("utf8") for g, _ in groups]
         f.attrs["backend"] = b"tensorflow"

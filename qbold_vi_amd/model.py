@@ -7,9 +7,9 @@ exactly as Keras hands them to the reference's loss callables.  Voxel batches ma
 shape; the reference's 5-D (B, X, Y, Z, C) layout is accepted as is.  Arithmetic is done by
 libqbold_hip.so; torch provides memory, reshapes and trivial reductions of kernel outputs.
 
-Scope: the branches optimal.yaml disables -- population prior / MoG / inverse-gamma
-(model.py:252-271, 492-507, 666-716), non-MVG 4-parameter posteriors, dropout / GroupNorm -- raise
-NotImplementedError instead of silently computing something else.  Image crops [B, X, Y, Z, C]
+Scope: the branches optimal.yaml disables are built where the reference itself can run them (population
+prior / MoG / inverse-gamma with the diagonal family, dropout and GroupNorm on the layer-wise kernels); the pairs the
+reference cannot evaluate raise NotImplementedError instead of silently computing something else.  Image crops [B, X, Y, Z, C]
  take the layer-wise spatial kernels; voxel batches the fused ones.
 """
 import math
@@ -297,8 +297,6 @@ class EncoderTrainer:
         self._se_idx = int(abs(float(system_params['tau_start']) / float(system_params['tau_step'])))
         self._seed = int(seed)
         unsupported = []
-        if use_layer_norm or dropout_rate > 0.0:
-            unsupported.append("use_layer_norm / dropout_rate (model.py:133-140)")
         if activation_type not in ('relu', 'gelu'):
             unsupported.append(f"activation_type={activation_type!r} (kernels implement 'relu' and 'gelu')")
         if infer_inv_gamma and use_mvg:
@@ -353,13 +351,14 @@ class EncoderTrainer:
         w = init_encoder_weights(T=no_ip_images, U=self._no_units, L=self._no_intermediate_layers,
                                  channelwise_gating=self._channelwise_gating,
                                  resid_init_std=resid_init_std, im_loss_sigma=self._initial_im_sigma,
-                                 seed=self._seed, spatial_taps=9)
+                                 seed=self._seed, spatial_taps=9, layer_norm=self._use_layer_norm)
         if not self._use_mvg:  # 4 outputs: the Cholesky column of the 5-wide head stays exactly zero
             w["Wf"][:, 4] = 0.0
             w["bf"][4] = 0.0
         ew = EncoderWeights(self._ctx, no_ip_images, self._no_units, self._no_intermediate_layers,
                             self._channelwise_gating, gate_offset, spatial_taps=9,
-                            activation=self._activation_type).set_from_arrays(w)
+                            activation=self._activation_type, layer_norm=self._use_layer_norm,
+                            dropout_rate=self._dropout_rate).set_from_arrays(w)
         return EncoderModel(self, ew), _InnerModel()
 
     def build_fine_tuner(self, encoder_model, signal_generation_layer, input_im=None, input_mask=None):

@@ -58,13 +58,18 @@ class EncoderWeights:
     ACTIVATIONS = {"relu": 0, "gelu": 1}  # qbold_activation
 
     def __init__(self, ctx, T, U, L, channelwise_gating=True, gate_offset=0.0, spatial_taps=1,
-                 precision="f32", activation="relu"):
+                 precision="f32", activation="relu", layer_norm=False, dropout_rate=0.0):
         self.ctx = ctx
         if activation not in self.ACTIVATIONS:
             raise ValueError(f"activation {activation!r}: the kernels implement 'relu' and 'gelu'")
+        if not 0.0 <= float(dropout_rate) < 1.0:
+            raise ValueError("dropout_rate must lie in [0, 1)")
+        # layer_norm / dropout_rate: EncoderTrainer's use_layer_norm / dropout_rate (model.py:131-140); dropout_seed is
+        # set per training step by TrainState and stays 0 (inference: identity) everywhere else
         self.shape = EncoderShape(int(T), int(U), int(L), int(bool(channelwise_gating)),
                                   float(gate_offset), 9 if spatial_taps == 9 else 1,
-                                  self.PRECISIONS[precision], self.ACTIVATIONS[activation])
+                                  self.PRECISIONS[precision], self.ACTIVATIONS[activation],
+                                  int(bool(layer_norm)), float(dropout_rate), 0)
         if precision != "f32" and not Context.fits_fused(self.shape):
             raise ValueError("precision='bf16' exists for the fused voxel kernels (U <= 64, L <= 2, T in {11, 24})")
         lib = _lib.load()
@@ -76,7 +81,8 @@ class EncoderWeights:
         # weight-streaming image for widths beyond the LDS-resident kernels (U = 128 / 256)
         n_wide = int(lib.qbold_encoder_wide_packed_floats(C.byref(self.shape)))
         # gelu runs on the general layer-wise kernels only (include/qbold_hip.h, qbold_activation)
-        self.wide = n_wide > 0 and not Context.fits_fused(self.shape) and self.shape.activation == 0
+        self.wide = (n_wide > 0 and not Context.fits_fused(self.shape) and self.shape.activation == 0
+                     and not self.shape.layer_norm)
         self.wide_packed = (torch.zeros(n_wide, dtype=torch.float32, device=ctx.device)
                             if self.wide else None)
         self._wide_ws = None
@@ -104,6 +110,9 @@ class EncoderWeights:
             take("Wc", U, U); take("bc", U); take("Wr1", *rs); take("br1", U)
             take("Wr2", *rs); take("br2", U); take("Wg", U, G); take("bg", G)
         take("Wf", U, 5); take("bf", 5); take("Ws", U, T); take("bs", T)
+        if self.shape.layer_norm:   # GroupNormalization gamma1, beta1, gamma2, beta2 per block, behind the heads
+            for _ in range(L):
+                take("ln", 4, U)
         assert off == self.num_params
         return out
 
@@ -112,6 +121,9 @@ class EncoderWeights:
         sl = self._slices()
         flat = torch.empty(self.num_params, dtype=torch.float32)
         for name, pieces in sl.items():
+            if name == "ln" and name not in w:   # gamma = 1, beta = 0: GroupNormalization's initialisers
+                w = dict(w, ln=np.tile(np.array([1.0, 0.0, 1.0, 0.0], np.float32)[None, :, None],
+                                       (self.shape.L, 1, self.shape.U)))
             arr = torch.as_tensor(np.asarray(w[name], dtype=np.float32))
             for l, (off, shape) in enumerate(pieces):
                 src = arr[l] if len(pieces) > 1 or arr.dim() == len(shape) + 1 else arr
@@ -126,7 +138,7 @@ class EncoderWeights:
         out = {}
         for name, pieces in sl.items():
             arrs = [flat[off:off + int(np.prod(shape))].reshape(shape) for off, shape in pieces]
-            out[name] = np.stack(arrs) if name in ("Wc", "bc", "Wr1", "br1", "Wr2", "br2", "Wg", "bg") \
+            out[name] = np.stack(arrs) if name in ("Wc", "bc", "Wr1", "br1", "Wr2", "br2", "Wg", "bg", "ln") \
                 else arrs[0]
         return out
 
@@ -298,7 +310,8 @@ class Context:
     def fits_fused(shape):
         """The LDS-resident fused kernels cover U <= 64, L <= 2, T in {11, 24}; anything else (e.g.
         BASELINE config 3: U = 256, T = 64) takes the layer-wise GEMM path."""
-        return shape.U <= 64 and shape.L <= 2 and shape.T in (11, 24) and shape.activation == 0   # gelu: layer-wise
+        return (shape.U <= 64 and shape.L <= 2 and shape.T in (11, 24) and shape.activation == 0   # gelu: layer-wise
+                and not shape.layer_norm)                                                        # and so is GroupNorm
 
     def encoder_fwd(self, weights, x, want=("out1", "out2", "sigma")):
         x = _f32(x, "x", self.T)
@@ -705,6 +718,8 @@ class TrainState:
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step = 0
+        self.training = bool(optimiser_state)   # a training state runs Dropout (model.py:136); inference is the identity
+        self.dropout_base = 0x5eed0000          # the per-step dropout seed is dropout_base + step + 1
         self._ws = None
         self._ws_n = 0
         # stream-2 voxel batches of the LDS-resident shapes: forward with saved activations in one launch
@@ -726,8 +741,9 @@ class TrainState:
         q = torch.empty((N, 5), dtype=torch.float32, device=x.device)
         ls = torch.empty((N, ctx.T), dtype=torch.float32, device=x.device) if stream_sel == 2 else None
         sh = self.weights.shape
+        self._set_dropout_seed()
         if (stream_sel == 2 and self.fused_forward and Context.fits_fused(sh) and sh.channelwise_gating
-                and sh.precision == 0 and 0 < N < (1 << 23)):
+                and sh.precision == 0 and 0 < N < (1 << 23) and not (self.training and sh.dropout_rate > 0.0)):
             # one launch, every saved tensor written once (encoder_kernels.hip, encoder_train_fwd_kernel); the two
             # tensors per block that the backward will recompute (it says which) are left out
             save_all = 2 - max(0, min(2, int(ctx.lib.qbold_encoder_train_bwd_recomputes(ctx.handle, C.byref(sh), N))))
@@ -742,9 +758,16 @@ class TrainState:
         self._n = N
         return q, ls
 
+    def _set_dropout_seed(self):
+        """Keras runs Dropout in training only: a training state's forward draws the step's mask (and its backward
+        regenerates it from the same seed); any other forward sees seed 0, the identity."""
+        sh = self.weights.shape
+        sh.dropout_seed = (self.dropout_base + self.step + 1) if (self.training and sh.dropout_rate > 0.0) else 0
+
     def backward(self, stream_sel, g_q, g_ls=None, sums=None):
         """Fills self.grad (canonical layout) from the head gradients of the last forward()."""
         ctx = self.ctx
+        self._set_dropout_seed()
         _lib.check(ctx.lib.qbold_encoder_train_bwd(ctx.handle, C.byref(self.weights.shape),
                                                    _ptr(self.weights.flat), int(stream_sel),
                                                    _ptr(self._ws), _ptr(g_q), _ptr(g_ls), _ptr(sums),
@@ -761,6 +784,7 @@ class TrainState:
             raise ValueError("forward_spatial expects [B, X, Y, Z, T]")
         B, X, Y, Z, _ = x.shape
         self._geom = Geometry(B, X, Y, Z)
+        self._set_dropout_seed()
         N = B * X * Y * Z
         q = torch.empty((N, 5), dtype=torch.float32, device=x.device)
         ls = torch.empty((N, ctx.T), dtype=torch.float32, device=x.device)
@@ -773,6 +797,7 @@ class TrainState:
 
     def backward_spatial(self, g_q, g_ls, sums=None):
         ctx = self.ctx
+        self._set_dropout_seed()
         _lib.check(ctx.lib.qbold_encoder_spatial_bwd(ctx.handle, C.byref(self.weights.shape),
                                                      _ptr(self.weights.flat), C.byref(self._geom),
                                                      _ptr(self._ws), _ptr(g_q), _ptr(g_ls), _ptr(sums),

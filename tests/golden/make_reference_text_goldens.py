@@ -367,5 +367,38 @@ put("fine_tuner_homoscedastic", data=noisy[:64], zs=draws("normal")[0].reshape(6
     nll=eh.fine_tune_loss_fn(T_(np.concatenate([xh, mh], -1)), full_h.outputs["predicted_images"]))
 
 out = os.path.join(HERE, "reference_text_goldens.npz")
+# use_layer_norm + dropout_rate (model.py:131-140): add_normalizer in front of both activations of the residual path --
+# keras Dropout (the models are called outside fit: the identity) and tfa GroupNormalization(groups = 1, axis = -1).
+# gamma / beta leave their initialisers (ones / zeros) so that both are seen; two GroupNormalization layers per block,
+# in creation order.
+import tensorflow_addons as tfa   # noqa: E402  (the stand-in)
+for case, U, L, act in (("encoder_layer_norm_relu", 12, 2, "relu"), ("encoder_layer_norm_gelu", 8, 1, "gelu")):
+    tf.Conv3D.CREATED.clear()
+    tfa.layers.GroupNormalization.CREATED.clear()
+    e = ref_model.EncoderTrainer(P, no_intermediate_layers=L, no_units=U, use_layer_norm=True, dropout_rate=0.2,
+                                 activation_type=act, student_t_df=200, initial_im_sigma=0.05,
+                                 multi_image_normalisation=False, channelwise_gating=True, use_mvg=True,
+                                 use_population_prior=False, no_samples=1, heteroscedastic_noise=True,
+                                 predict_log_data=False)
+    outer, inner = e.create_encoder(gate_offset=-2.0, resid_init_std=0.05, no_ip_images=11)
+    convs, norms = list(tf.Conv3D.CREATED), list(tfa.layers.GroupNormalization.CREATED)
+    assert len(convs) == 3 + 4 * L and len(norms) == 2 * L
+    outer(T_(noisy[:4].reshape(4, 1, 1, 1, 11)))     # builds the kernels and the normalisation parameters
+    for c in convs:
+        c.bias = (c.bias + rng.normal(0, 0.1, c.bias.shape)).astype(np.float32)
+    for g in norms:
+        g.gamma = (g.gamma + rng.normal(0, 0.3, g.gamma.shape)).astype(np.float32)
+        g.beta = (g.beta + rng.normal(0, 0.2, g.beta.shape)).astype(np.float32)
+    ln = np.stack([np.stack([norms[2 * l].gamma, norms[2 * l].beta, norms[2 * l + 1].gamma, norms[2 * l + 1].beta])
+                   for l in range(L)])
+    put(f"{case}/weights", **export_weights(convs, L), ln=ln, gate_offset=np.float32(-2.0), U=np.int32(U), L=np.int32(L),
+        channelwise_gating=np.int32(1))
+    xv = noisy[:64].reshape(64, 1, 1, 1, 11)
+    o1, o2, sg = outer(T_(xv))
+    put(f"{case}/voxels", x=noisy[:64], out1=o1.a.reshape(64, 5), out2=o2.a.reshape(64, 5), sigma=sg.a.reshape(64, 11))
+    xc = noisy[:2 * 6 * 5 * 2].reshape(2, 6, 5, 2, 11)
+    o1, o2, sg = outer(T_(xc))
+    put(f"{case}/crops", x=xc, out1=o1, out2=o2, sigma=sg)
+
 np.savez_compressed(out, **G)
 print(f"wrote {out}: {len(G)} arrays, {os.path.getsize(out) / 1024:.0f} KiB")

@@ -207,8 +207,8 @@ def test_disabled_branches_fail_loudly(params):
         EncoderTrainer(params, use_population_prior=False, use_mvg=True, infer_inv_gamma=True, activation_type='relu')
     with pytest.raises(NotImplementedError, match="activation_type"):
         EncoderTrainer(params, use_population_prior=False, activation_type='selu')
-    with pytest.raises(NotImplementedError, match="dropout"):
-        EncoderTrainer(params, use_population_prior=False, activation_type='relu', dropout_rate=0.1)
+    # built since round 4: dropout and GroupNormalization (tests/test_gpu_normalizer.py)
+    EncoderTrainer(params, use_population_prior=False, activation_type='relu', dropout_rate=0.1, use_layer_norm=True)
     # built since round 3: gelu, the homoscedastic sigma, the population prior with the diagonal family
     EncoderTrainer(params, use_population_prior=False, activation_type='gelu')
     EncoderTrainer(params, use_population_prior=False, activation_type='relu', heteroscedastic_noise=False)

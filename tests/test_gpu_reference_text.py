@@ -221,6 +221,29 @@ def test_two_stream_encoder(params, case):
     close(ssg, cs, rtol=5e-5)
 
 
+@pytest.mark.parametrize("case,act", [("encoder_layer_norm_relu", "relu"), ("encoder_layer_norm_gelu", "gelu")])
+def test_encoder_with_layer_norm_and_dropout(params, case, act):
+    """EncoderTrainer(use_layer_norm=True, dropout_rate=0.2) through the reference-shaped API against what the
+    reference text computed (model.py:131-140): GroupNormalization over a voxel's channels on (N,1,1,1,T) batches and over
+    a whole crop on crops, Dropout the identity outside training."""
+    from oracle.oracle import WEIGHT_NAMES
+    U, L = int(G[f"{case}/weights/U"]), int(G[f"{case}/weights/L"])
+    tr = trainer(params, no_units=U, no_intermediate_layers=L, channelwise_gating=True, use_layer_norm=True,
+                 dropout_rate=0.2, activation_type=act)
+    model, _ = tr.create_encoder(gate_offset=float(G[f"{case}/weights/gate_offset"]), resid_init_std=0.05, no_ip_images=11)
+    model.set_weights(dict({n: G[f"{case}/weights/{n}"] for n in WEIGHT_NAMES}, ln=G[f"{case}/weights/ln"]))
+    x, o1, o2, sg = g(f"{case}/voxels", "x", "out1", "out2", "sigma")
+    g1, g2, gs = model(dev(x.reshape(-1, 1, 1, 1, 11)))
+    close(g1.reshape(o1.shape), o1, rtol=2e-5, atol=2e-5)
+    close(g2.reshape(o2.shape), o2, rtol=3e-5, atol=3e-5)
+    close(gs.reshape(sg.shape), sg, rtol=1e-4)
+    xc, c1, c2, cs = g(f"{case}/crops", "x", "out1", "out2", "sigma")
+    s1, s2, ssg = model(dev(xc))
+    close(s1, c1, rtol=2e-5, atol=2e-5)
+    close(s2, c2, rtol=3e-5, atol=3e-5)
+    close(ssg, cs, rtol=1e-4)
+
+
 def test_fine_tuner_elbo_from_the_reference_text(params):
     """build_fine_tuner on a crop batch with S = 2, then fine_tune_loss_fn + kl_loss (train.py:315-320): encoder with
     3x3x1 context -> draws -> forward model -> NLL + KL, on the reference's own normals."""

@@ -67,7 +67,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/qbold_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().qbold_abi_version() == 4      # v4: qbold_encoder_shape.activation
+    assert _lib.load().qbold_abi_version() == 5      # v5: qbold_encoder_shape.layer_norm, dropout_rate, dropout_seed
 
 
 def test_host_only_context_tau_grid_and_table(params, oracle32, oracle64):

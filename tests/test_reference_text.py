@@ -223,6 +223,33 @@ def test_two_stream_encoder(oracle32, case):
     close(p1.reshape(c1.shape), c1, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("case,gelu", [("encoder_layer_norm_relu", False), ("encoder_layer_norm_gelu", True)])
+def test_encoder_with_layer_norm_and_dropout(oracle32, case, gelu):
+    """use_layer_norm=True, dropout_rate=0.2 (model.py:131-140): the reference text's add_normalizer puts Dropout (the
+    identity outside fit) and GroupNormalization(groups = 1, axis = -1) in front of BOTH activations of the residual
+    path -- statistics over a voxel's channels for (N,1,1,1,T) batches, over a whole crop and its channels for crops;
+    stream 1 and the skip path carry no normalisation."""
+    w = weights_of(case)
+    ln = g(f"{case}/weights", "ln")
+    oracle32.lib.qbo_set_activation_gelu(1 if gelu else 0)
+    try:
+        x, o1, o2, sg = g(f"{case}/voxels", "x", "out1", "out2", "sigma")
+        n = x.shape[0]
+        s2, ssg = oracle32.encoder_fwd_spatial(w, x.reshape(n, 1, 1, 1, 11), ln=ln)
+        close(s2.reshape(n, 5), o2, rtol=3e-5, atol=3e-5)
+        close(ssg.reshape(n, 11), sg, rtol=1e-4)
+        p1, _, _ = oracle32.encoder_fwd(centre_taps(w), x)
+        close(p1, o1, rtol=2e-5, atol=2e-5)                                   # stream 1: no normalizer
+        xc, c1, c2, cs = g(f"{case}/crops", "x", "out1", "out2", "sigma")
+        s2, ssg = oracle32.encoder_fwd_spatial(w, xc, ln=ln)
+        close(s2, c2, rtol=3e-5, atol=3e-5)
+        close(ssg, cs, rtol=1e-4)
+        plain, _ = oracle32.encoder_fwd_spatial(w, xc)
+        assert np.max(np.abs(plain - c2)) > 1e-2                              # the layers are live in the fixture
+    finally:
+        oracle32.lib.qbo_set_activation_gelu(0)
+
+
 def test_fine_tuner_elbo_from_the_reference_text(oracle32):
     """build_fine_tuner on a crop batch with S = 2 copies, then fine_tune_loss_fn + kl_loss on its outputs
     (train.py:315-320): the whole voxel-ELBO evaluation as the reference text computes it."""
