@@ -520,7 +520,7 @@ def roofline_of(spec, m, S, K, step_kernel_ms, kernel_ms):
                 "'achieved' = SURVEY 8(d)'s encoder flops per voxel x voxels / its launch duration (HIP events inside "
                 "the timed region) against the guide's dense f16 MFMA peak; under this kernel's matrix load the chip "
                 "holds ~1.6-2.0 GHz, not the 2.4 GHz the peak assumes (MEASUREMENTS.md 4.7); the second launch "
-                "(elbo_fwd_lds_kernel, vector-issue-bound) is in 'two_pipe' / 'hbm', which cover the whole step")
+                "(elbo_fwd_gt64_kernel, vector-issue-bound) is in 'two_pipe' / 'hbm', which cover the whole step")
     else:
         if spec.exact:
             kname = "xw64_kernel / xw64_fork_kernel / xw64_gate_kernel / xw64_heads_kernel + elbo_fwd_kernel"
@@ -551,7 +551,7 @@ def roofline_of(spec, m, S, K, step_kernel_ms, kernel_ms):
                         else "vector issue"),
             "hbm": hbm, "issue": issue, "two_pipe": two_pipe,
             **({"counters": counters} if counters else {}),
-            "step": {"launches": (["wide_fused_kernel", "elbo_fwd_lds_kernel", "reduce_partials_kernel"] if two_launch
+            "step": {"launches": (["wide_fused_kernel", "elbo_fwd_gt64_kernel", "reduce_partials_kernel"] if two_launch
                                   else ["layer-wise encoder (9 launches)", "elbo_fwd_kernel", "reduce_partials_kernel"]
                                   if spec.exact else ["vi_fwd_kernel", "reduce_partials_kernel"]),
                      "kernel_ms": step_kernel_ms,

@@ -208,12 +208,15 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
     // reference's float32 grid start + i step mirrors to an ulp, not exactly (-8 / +8 ms differ by one), so the test
     // is relative, at the level of that rounding.
     {
+        // (tolerances in units of the grid step: start + i step in float32 puts the spin echo of the 64-tau grid
+        // -0.015 + 12 x 0.00125 at 1e-9 s instead of 0, and mirrored taus a few 1e-9 s apart)
         const int se = d.se_idx;
-        bool mirrors = se >= 0 && se < T && d.taus[se] == 0.0f;
+        const float tol = 4e-6f * fabsf(tstep);
+        bool mirrors = se >= 0 && se < T && fabsf(d.taus[se]) <= tol;
         for (int j = 1; mirrors && se - j >= 0 && se + j < T; ++j) {
             const float ta = fabsf(d.taus[se - j]), tb = fabsf(d.taus[se + j]);
             const float ba = d.blood_B[se - j], bb = d.blood_B[se + j];
-            mirrors = fabsf(ta - tb) <= 1e-6f * fmaxf(ta, tb) && fabsf(ba - bb) <= 4e-6f * fmaxf(fabsf(ba), fabsf(bb));
+            mirrors = fabsf(ta - tb) <= tol && fabsf(ba - bb) <= 4e-6f * fmaxf(fabsf(ba), fabsf(bb));
         }
         ctx->grid_mirrors = mirrors;
     }
@@ -223,7 +226,7 @@ extern "C" int qbold_ctx_create(const qbold_consts* P, const qbold_loss_cfg* los
     // protocols whose spin-echo image sits at tau = 0 exactly (both of the reference's, signals.py:117-121).
     {
         const int nseg = qb::gtab_segs(T), se = d.se_idx;
-        const bool proto = (T == 11 && se == 2) || (T == 24 && se == 7);   // the protocols the table-driven kernels are instantiated for
+        const bool proto = (T == 11 && se == 2) || (T == 24 && se == 7) || (T == 64 && se == 12);   // the protocols the table-driven kernels are instantiated for
         if (nseg > 0 && proto && ctx->grid_mirrors && P->full_model) {
             const int J = qb::gtab_taus(T, se);
             ctx->h_gtab.resize((size_t)4 * J * nseg);

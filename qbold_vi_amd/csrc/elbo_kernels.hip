@@ -430,6 +430,201 @@ __global__ __launch_bounds__(kLdsBlock) void elbo_fwd_lds_kernel(
     qb::block_partials(red, s_nll, s_kl, s_m, partials);
 }
 
+// The same protocol on the per-tau OEF-indexed tissue table (qbold_dev.h, GtLds): the table coordinate -- segment index
+// and fraction of NSEG sigmoid(a) -- is formed ONCE PER DRAW and serves all 51 evaluated taus, whose rows sit at immediate
+// offsets from one address register: the coordinate FMA, v_cvt_i32, v_fract and address shift of the x-indexed table
+// leave every (draw, tau) (4 of its 14 vector instructions).  The table (51 taus x 68 segments x 16 B = 54 KiB) is shared
+// by ONE 1,024-thread workgroup per CU whose 256 voxels' merged data rows (52 x 256 x 8 B = 104 KiB; the mirrored pairs
+// as one data point, elbo_core.h) fill the rest of the LDS.  A lane prepares the 16 taus it owns and merges its pairs in
+// registers: pairs (13, 11) .. (15, 9) lie inside lane group 0's taus, pairs (16, 8) .. (24, 0) join group 1's taus with
+// group 0's, which group 1 reads for itself (the same cache lines) -- no exchange, one barrier per tile and side.
+constexpr int kGtBlock = 1024;
+constexpr int kGtVox = kGtBlock / QB_LANES_PER_VOXEL;
+
+template <int T, int SE, bool LOGSIG>
+__global__ __launch_bounds__(kGtBlock) void elbo_fwd_gt64_kernel(
+    QbDev c, const float4* __restrict__ g_gtab, const float* __restrict__ x,
+    const float* __restrict__ mask, const float* __restrict__ q, const float* __restrict__ prior,
+    const float* __restrict__ sigma, int S, int K, uint64_t seed, int64_t voxel0, float2* __restrict__ nll_kl,
+    double* __restrict__ partials, int64_t N) {
+    static_assert(T == 64 && SE == 12, "lane ownership of the taus below is written out for the 64-tau protocol");
+    constexpr int NSEG = qb::gtab_segs(T), J = qb::gtab_taus(T, SE), NROW = T - SE;   // rows e = t - SE = 0 .. 51
+    static_assert(J == NROW - 1 && NSEG > 0, "one table row set per evaluated tau above the spin echo");
+    extern __shared__ __align__(16) unsigned char smem[];
+    float4* gtab = reinterpret_cast<float4*>(smem);                                   // [J][NSEG]
+    float* bloodB = reinterpret_cast<float*>(smem + sizeof(float4) * J * NSEG);       // [T]
+    float2* dat = reinterpret_cast<float2*>(smem + sizeof(float4) * J * NSEG + sizeof(float) * T);   // [NROW][kGtVox]
+    double* red = reinterpret_cast<double*>(smem + sizeof(float4) * J * NSEG + sizeof(float) * T +
+                                            sizeof(float2) * NROW * kGtVox);
+    for (int i = threadIdx.x; i < J * NSEG; i += kGtBlock) gtab[i] = g_gtab[i];
+    if (threadIdx.x < T) bloodB[threadIdx.x] = c.blood_B[threadIdx.x];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int part = lane >> 4;
+    const int vl = wave * QB_VOX_PER_WAVE + (lane & 15);
+    float2* my = dat + vl;
+    float s_nll = 0.0f, s_kl = 0.0f, s_m = 0.0f;
+    const int64_t ntile = (N + kGtVox - 1) / kGtVox;
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int64_t v = tile * kGtVox + vl;
+        const bool live = v < N;
+        const int64_t vc = live ? v : N - 1;
+        const float inv_nt = qb::rcpf_(x[vc * T + SE] + 1e-3f);  // model.py:545
+        // this lane's sixteen taus t = 16 part .. 16 part + 15 as (a, s) = (y / sigma, 1 / sigma)
+        float a[16], sg[16], ls = 0.0f;
+        {
+            const float4* xq = reinterpret_cast<const float4*>(x + vc * T) + 4 * part;
+            const float4* sq = reinterpret_cast<const float4*>(sigma + vc * T) + 4 * part;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const float4 xx = xq[k4], ss = sq[k4];
+                const float xa[4] = {xx.x, xx.y, xx.z, xx.w}, sa[4] = {ss.x, ss.y, ss.z, ss.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float is;
+                    if (LOGSIG) {
+                        is = qb::exp2f_(-QB_LOG2E * sa[e]);
+                        ls += sa[e];
+                    } else {
+                        is = qb::rcpf_(sa[e]);
+                        ls += QB_LN2 * qb::log2f_(sa[e]);
+                    }
+                    a[4 * k4 + e] = xa[e] * inv_nt * is;
+                    sg[4 * k4 + e] = is;
+                }
+            }
+        }
+        // lane group 1 fetches taus 0 .. 8 (group 0's) once more for its pairs (16, 8) .. (24, 0)
+        float am[9], sm[9];
+        if (part == 1) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float sv = sigma[vc * T + t];
+                const float is = LOGSIG ? qb::exp2f_(-QB_LOG2E * sv) : qb::rcpf_(sv);
+                am[t] = x[vc * T + t] * inv_nt * is;
+                sm[t] = is;
+            }
+        }
+        __syncthreads();  // the previous tile's draws are done with dat (first trip: the table is filled)
+        float dsum = 0.0f;
+        auto merged = [&](float a1, float s1, float a2, float s2) {   // elbo_core.h, prepare_lik<.., MIR>
+            const float pp = fmaf(s1, s1, s2 * s2);
+            const float ip = __builtin_amdgcn_rsqf(pp);
+            const float cr = fmaf(a1, s2, -(a2 * s1)) * ip;
+            dsum = fmaf(cr, cr, dsum);
+            return make_float2(fmaf(a1, s1, a2 * s2) * ip, pp * ip);
+        };
+        if (part == 0) {          // t = 12 (the spin echo) plain; (13, 11), (14, 10), (15, 9) merged
+            my[0 * kGtVox] = make_float2(a[12], sg[12]);
+#pragma unroll
+            for (int j = 1; j <= 3; ++j) my[j * kGtVox] = merged(a[12 + j], sg[12 + j], a[12 - j], sg[12 - j]);
+        } else if (part == 1) {   // t = 16 .. 24 merged with 8 .. 0; t = 25 .. 31 plain
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int t = 16 + k;
+                my[(t - SE) * kGtVox] = t <= 2 * SE ? merged(a[k], sg[k], am[2 * SE - t >= 0 && 2 * SE - t < 9 ? 2 * SE - t : 0],
+                                                             sm[2 * SE - t >= 0 && 2 * SE - t < 9 ? 2 * SE - t : 0])
+                                                    : make_float2(a[k], sg[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) my[(16 * part + k - SE) * kGtVox] = make_float2(a[k], sg[k]);
+        }
+        const float log_s_sum = qb::voxel_sum(fmaf(0.5f, dsum, ls)) + (float)T * 0.9189385332046727f;  // + T log sqrt(2 pi)
+        __syncthreads();
+        if (live) {
+            float qv[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) qv[i] = q[v * 5 + i];
+            const qb::LogitMvn qm = qb::make_mvn(qv);
+            const uint64_t vox = (uint64_t)(voxel0 + v);
+            float nll_sum = 0.0f, kl_sum = 0.0f;
+            int n_kl = 0;
+            __builtin_amdgcn_s_setprio(QB_PRIO_LIK);
+            const int calls = S > 4 * part ? (S - 4 * part + 15) / 16 : 0;
+            const int last = calls > 0 ? S - 4 * (part + 4 * (calls - 1)) : 0;
+            const int n_lik = calls > 0 ? 4 * (calls - 1) + (last < 4 ? last : 4) : 0;
+            qb::DrawQuad dq;
+            uint32_t g = (uint32_t)part;
+#pragma unroll 1
+            for (int i = 0; i < n_lik; ++i) {
+                if ((i & 3) == 0) {
+                    dq.load(seed, vox, g, qb::STREAM_LIK);
+                    g += QB_LANES_PER_VOXEL;
+                }
+                float z0, z1, la, lb_;
+                dq.next(z0, z1);
+                qb::reparam_logits(qm, z0, z1, la, lb_);
+                const float sa = qb::sigmoidf_(la), sb = qb::sigmoidf_(lb_);
+                const qb::FwdFast fv = qb::fwd_fast_sig(c, sa, sb);
+                const float s_se = fmaf(fv.tissue_w, 1.0f, fv.blood_w * qb::exp2f_(fv.ng * bloodB[SE]));   // F(0) = 0
+                const float inv_np = qb::rcpf_(s_se + 1e-3f);
+                const float lt = qb::log2f_(fv.tissue_w * inv_np), lb = qb::log2f_(fv.blood_w * inv_np);
+                const float cg = fminf(sa * (float)NSEG, (float)NSEG - 0.0009765625f);
+                const float f = __builtin_amdgcn_fractf(cg);
+                const float4* row = gtab + (int)cg;
+                float acc;
+                {
+                    const float2 dd = my[0];
+                    const float r = fmaf(-(s_se * inv_np), dd.y, dd.x);
+                    acc = r * r;
+                }
+                struct Stage {
+                    float4 kk;
+                    float bb;
+                    float2 d0;
+                };
+                auto issue = [&](int e) -> Stage {   // e = t - SE = 1 .. 51
+                    Stage st;
+                    st.kk = row[(e - 1) * NSEG];
+                    st.bb = bloodB[SE + e];
+                    st.d0 = my[e * kGtVox];
+                    return st;
+                };
+                auto finish = [&](const Stage& st) {
+                    const float F = fmaf(fmaf(fmaf(st.kk.w, f, st.kk.z), f, st.kk.y), f, st.kk.x);
+                    const float yh = qb::exp2f_(fmaf(fv.nd, F, lt)) + qb::exp2f_(fmaf(fv.ng, st.bb, lb));
+                    const float r = fmaf(-yh, st.d0.y, st.d0.x);
+                    acc = fmaf(r, r, acc);
+                };
+                if (qb_phase_fence()) {   // the tau loop as a basic block of its own (elbo_core.h)
+                    constexpr int D = QB_LDS_DEPTH;
+                    Stage ring[D + 1];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) ring[k] = issue(1 + k);
+#pragma unroll
+                    for (int e = 1; e < NROW; ++e) {
+                        if (e + D < NROW) ring[(e - 1 + D) % (D + 1)] = issue(e + D);
+                        __builtin_amdgcn_sched_barrier(0);
+                        finish(ring[(e - 1) % (D + 1)]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                nll_sum += acc;
+            }
+            nll_sum = fmaf(0.5f, nll_sum, (float)n_lik * log_s_sum);
+            float pv[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) pv[i] = prior[v * 5 + i];
+            const qb::LogitMvn pm = qb::make_mvn(pv);
+            __builtin_amdgcn_s_setprio(QB_PRIO_KL);
+            kl_sum = qb::kl_draws_fast(qm, pm, K, nullptr, seed, vox, part, n_kl);
+            __builtin_amdgcn_s_setprio(QB_PRIO_AFTER);
+            kl_sum = fmaf(0.5f, kl_sum, (float)n_kl * ((pm.s_o + pm.s_d) - (qm.s_o + qm.s_d)));
+            const float nll = qb::voxel_sum(nll_sum) / (float)S;
+            const float kl = K > 0 ? qb::voxel_sum(kl_sum) / (float)K : 0.0f;
+            if (part == 0) {
+                const float m = mask ? mask[v] : 1.0f;
+                if (nll_kl) nll_kl[v] = make_float2(nll, kl);
+                s_nll += nll * m;
+                s_kl += m > 0.0f ? kl : 0.0f;
+                s_m += m;
+            }
+        }
+    }
+    qb::block_partials(red, s_nll, s_kl, s_m, partials);
+}
+
 __global__ void reparam_kernel(const float* __restrict__ q, const float2* __restrict__ z,
                                float2* __restrict__ out, int64_t N) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N;
@@ -679,6 +874,24 @@ int elbo_fwd_launch(const qbold_ctx* ctx, const float* x, const float* mask, con
         // elbo_fwd_lds_kernel reads the x and sigma rows as float4: 256-byte rows, so the bases decide
         QB_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(sigma) % 16 == 0,
                    "qbold_elbo_fwd (64-tau protocol): x and sigma must be 16-byte aligned");
+        if (ctx->gtab_ok && qb::gtab_segs(64) > 0 && !(ctx->kernel_sel & 8) && !zs && !zk) {
+            // per-tau OEF-indexed table, one 1,024-thread workgroup per CU (elbo_fwd_gt64_kernel); explicit normals and
+            // QBOLD_KSEL_X_TABLE keep the x-indexed kernel below
+            constexpr size_t smem = sizeof(float4) * qb::gtab_taus(64, 12) * qb::gtab_segs(64) + sizeof(float) * 64 +
+                                    sizeof(float2) * (64 - 12) * kGtVox + sizeof(double) * 3 * (kGtBlock / 64);
+            static_assert(smem <= 160 * 1024, "table + data rows exceed the LDS");
+            const int64_t nt = (N + kGtVox - 1) / kGtVox;
+            grid = (int)(nt < ctx->num_cus ? (nt > 0 ? nt : 1) : ctx->num_cus);
+            auto kern = sigma_is_log ? elbo_fwd_gt64_kernel<64, 12, true> : elbo_fwd_gt64_kernel<64, 12, false>;
+            QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)smem));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kGtBlock), smem, s, ctx->dev, ctx->d_gtab, x, mask, q, prior, sigma,
+                               S, K, seed, voxel0, out, partials, N);
+            QB_HIP(hipGetLastError());
+            hipLaunchKernelGGL(qb::reduce_partials_kernel, dim3(1), dim3(192), 0, s, partials, grid, sums);
+            QB_HIP(hipGetLastError());
+            return QBOLD_OK;
+        }
         const int64_t gt = (N + kLdsVox - 1) / kLdsVox;
         grid = (int)(gt < qb::elbo_grid(ctx) ? (gt > 0 ? gt : 1) : qb::elbo_grid(ctx));
         if (sigma_is_log)

@@ -377,7 +377,14 @@ __host__ __device__ constexpr int gtab_taus(int T, int SE) { return SE > T - 1 -
 #ifndef QB_GT_SEGS_24
 #define QB_GT_SEGS_24 52
 #endif
-__host__ __device__ constexpr int gtab_segs(int T) { return T == 11 ? QB_GT_SEGS_11 : (T == 24 ? QB_GT_SEGS_24 : 0); }
+// T = 64 (BASELINE config 3, spin echo at index 12): 51 taus x 68 segments = 54 KiB beside the 104 KiB of a 256-voxel
+// tile's data rows (elbo_fwd_gt64_kernel); max |G - F| = 8e-6 at 65 ms, i.e. <= 1.6e-6 of the signal at DBV = 0.2.
+#ifndef QB_GT_SEGS_64
+#define QB_GT_SEGS_64 68
+#endif
+__host__ __device__ constexpr int gtab_segs(int T) {
+    return T == 11 ? QB_GT_SEGS_11 : (T == 24 ? QB_GT_SEGS_24 : (T == 64 ? QB_GT_SEGS_64 : 0));
+}
 // Pair-interleaved rows (QB_GT_PAIRS): when every evaluated tau lies above the spin echo and they come in pairs, rows
 // 2p and 2p + 1 of the table hold (c0a, c0b, c1a, c1b) and (c2a, c2b, c3a, c3b) of taus j = 2p + 1 (a) and 2p + 2 (b),
 // so that a row read delivers aligned float32 pairs for v_pk_fma_f32 (elbo_core.h).  Measured and NOT adopted: 137

@@ -71,10 +71,10 @@ if fb:
     if os.path.exists(os.path.join(src, f"{tag}_config3_wide_fused_summary.json")):
         T = 64
         enc = pmc_file(f"{tag}_config3_wide_fused_summary.json", "wide_fused_kernel<4, 2, true>", n, (4 * T + 4 * T + 20) * n, fb)
-        elbo = pmc_file(f"{tag}_config3_elbo_summary.json", "elbo_fwd_lds_kernel<64, 12, true>", n,
+        elbo = pmc_file(f"{tag}_config3_elbo_summary.json", ("elbo_fwd_gt64_kernel" if tag >= "r04" else "elbo_fwd_lds_kernel") + "<64, 12, true>", n,
                         (4 * T + 4 * T + 20 + 4 + 20 + 8) * n, fb)
         if enc and elbo:
-            enc["step"] = {"launches": ["wide_fused_kernel", "elbo_fwd_lds_kernel"],
+            enc["step"] = {"launches": ["wide_fused_kernel", "elbo_fwd_gt64_kernel" if tag >= "r04" else "elbo_fwd_lds_kernel"],
                            "hbm_bytes": enc["hbm_bytes_per_launch"] + elbo["hbm_bytes_per_launch"],
                            "algorithmic_bytes": (4 * T + 4 + 20 + 20 + 8) * n,
                            "elbo_kernel": {k: elbo[k] for k in ("kernel", "FETCH_SIZE_KB", "WRITE_SIZE_KB", "hbm_bytes_per_launch",

@@ -36,7 +36,11 @@ def timeit(f, reps=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
 print(f"encoder alone {timeit(lambda: enc(0, n)):.4f} ms   elbo alone {timeit(lambda: elbo(0, n, 0)):.4f} ms")
-for chunks in (1, 2, 4, 8, 16):
+for sel in [int(a) for a in sys.argv[1:] if a.isdigit()]:   # e.g. 8 = QBOLD_KSEL_X_TABLE: the x-indexed ELBO kernel
+    ctx.set_kernel_selection(sel)
+    print(f"kernel selection {sel}: elbo alone {timeit(lambda: elbo(0, n, 0)):.4f} ms")
+    ctx.set_kernel_selection(0)
+for chunks in ((1,) if len(sys.argv) > 1 else (1, 2, 4, 8, 16)):
     m = n // chunks
     def both():
         for c in range(chunks):

@@ -59,7 +59,7 @@ else
     prof $D/pmc_write --pmc WRITE_SIZE -- $S
     cp $D/trace/*/*_kernel_stats.csv $P/r04_config3_kernel_stats.csv
     python3 scripts/summarise_prof.py $D wide_fused > $P/r04_config3_wide_fused_summary.json
-    python3 scripts/summarise_prof.py $D elbo_fwd_lds > $P/r04_config3_elbo_summary.json
+    python3 scripts/summarise_prof.py $D elbo_fwd_gt64 > $P/r04_config3_elbo_summary.json
     grep -h '"metric"' $D/trace/bench.log | tail -1 > $P/r04_bench_config3_under_rocprof.json
     for v in p24:"--protocol 24" bf16:"--encoder_precision bf16"; do
         tag=${v%%:*}; args=${v#*:}

@@ -331,6 +331,48 @@ def test_finetune_weight_gradient_directional(ctx, oracle32, oracle64, U, L, cw)
         assert abs(got - fd) < 1e-2 * (abs(fd) + 0.05), (trial, got, fd)
 
 
+def test_block_backward_kernel_against_the_float64_oracle(ctx, oracle32, oracle64):
+    """block_bwd_dw_kernel -- one gated block's whole backward, its four weight gradients accumulated in registers --
+    DIRECTLY against central differences of the float64 oracle at the training shape (U = 60, L = 2, 4,096 voxels,
+    S = 1, K = 70): one direction per block matrix (Wc, Wr1, Wr2, Wg of either block) and their biases, so that each
+    of the kernel's accumulators is held to the oracle on its own, not only to the layer-wise HIP path."""
+    import ctypes as C
+    from oracle.oracle import WEIGHT_NAMES, synth_inputs
+    from qbold_vi_amd.ops import EncoderWeights, TrainState
+    U, L = 60, 2
+    w, ew = _weights(ctx, U, L, True)
+    n, S, K, seed = 4096, 1, 70, 33
+    assert int(ctx.lib.qbold_encoder_train_bwd_recomputes(ctx.handle, C.byref(ew.shape), n)) == 2   # the kernel under test runs
+    x, _ = synth_inputs(n, seed=8, oracle=oracle32)
+    rng = np.random.default_rng(2)
+    mask = (rng.uniform(size=n) > 0.1).astype(np.float32)
+    prior = oracle32.encoder_fwd(w, x)[0]
+    st = TrainState(ctx, ew)
+    q2, ls = st.forward(dev(x), 2)
+    sums, gq, gls, _ = ctx.elbo_bwd(dev(x), dev(mask), q2, dev(prior), ls, S, K, seed=seed)
+    grad = st.backward(2, gq, gls, sums).cpu().numpy().astype(np.float64)
+    zs = oracle32.philox_normals(seed, 0, 0, n, S)
+    zk = oracle32.philox_normals(seed, 1, 0, n, K)
+    q_fixed = oracle64.encoder_fwd(w, x)[1]
+
+    def loss(ww):
+        _, qq, sg = oracle64.encoder_fwd(ww, x)
+        e = oracle64.elbo(x, mask, qq, prior, sg, zs, zk)
+        kl = kl_stopgrad(oracle64, qq, q_fixed, prior, zk)
+        return ((e["nll_v"] * mask).sum() + np.where(mask > 0, kl, 0).sum()) / mask.sum()
+
+    for name in ("Wc", "Wr1", "Wr2", "Wg", "bc", "br1", "br2", "bg"):
+        for blk in range(L):
+            direction = {k: np.zeros(w[k].shape) for k in WEIGHT_NAMES}
+            direction[name][blk] = rng.standard_normal(w[name][blk].shape)
+            dflat = EncoderWeights(ctx, 11, U, L, True, -1.0).set_from_arrays(
+                {k: direction[k].astype(np.float32) for k in WEIGHT_NAMES}).flat.cpu().numpy().astype(np.float64)
+            eps = 2e-6
+            fd = (loss(_perturbed(w, direction, eps)) - loss(_perturbed(w, direction, -eps))) / (2 * eps)
+            got = float(grad @ dflat)
+            assert abs(got - fd) < 5e-3 * (abs(fd) + 0.02), (name, blk, got, fd)
+
+
 def test_adamw_matches_numpy(ctx):
     from qbold_vi_amd.ops import TrainState
     _, ew = _weights(ctx, 24, 1, True)
