@@ -59,7 +59,12 @@ using qb::EncLayout;
 using qb::f32x4;
 
 constexpr int kBlock = 1024;
-constexpr int kWaves = kBlock / 64;
+// threads per workgroup of the 24-tau instantiations: with 1,024 (128 VGPRs) that protocol's 34 data registers leave the
+// kernel ~35 registers short around its sampling phase (140 bytes of scratch per lane, re-read every tile: 4.5 x the
+// algorithmic HBM bytes); 768 threads get 168 VGPRs and three waves per SIMD
+#ifndef QB_VI_BLOCK_24
+#define QB_VI_BLOCK_24 768
+#endif
 
 template <int T, int SE, bool GT>
 struct ViLds { using type = qb::FwdLds; };
@@ -71,8 +76,8 @@ constexpr size_t kLdsLimit = 160 * 1024;   // gfx950: LDS per workgroup
 // requires FAST and a compile-time spin-echo index.
 // MIR: the protocol mirrors about the spin echo (qbold_ctx::grid_mirrors): mirrored tau pairs are evaluated once and
 // scored as one merged data point (elbo_core.h, prepare_lik); GT implies it.
-template <int T, int NL, int SE, bool FAST, bool LITERAL, bool BF, bool GT = false, bool MIR = false>
-__global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
+template <int T, int NL, int SE, bool FAST, bool LITERAL, bool BF, bool GT = false, bool MIR = false, int BLK = kBlock>
+__global__ __launch_bounds__(BLK) void vi_fwd_kernel(
     QbDev c, const float4* __restrict__ g_tab, const float* __restrict__ packed,
     const float* __restrict__ x, const float* __restrict__ mask, const float* __restrict__ prior,
     int S, int K, uint64_t seed, int64_t voxel0, float* __restrict__ q_out,
@@ -89,7 +94,8 @@ __global__ __launch_bounds__(kBlock) void vi_fwd_kernel(
     float* lds_w = reinterpret_cast<float*>(smem);
     Lds* L = reinterpret_cast<Lds*>(smem + sizeof(float) * e.total);
     double* red = reinterpret_cast<double*>(smem + sizeof(float) * e.total + sizeof(Lds));
-    qb::copy_to_lds<kBlock>(lds_w, packed, e.total / 4);
+    constexpr int kWaves = BLK / 64;
+    qb::copy_to_lds<BLK>(lds_w, packed, e.total / 4);
     if constexpr (qb::IsGtLds<Lds>::value) {
         qb::gt_lds_fill(L, g_tab, c);
     } else {
@@ -230,7 +236,8 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     hipStream_t s = (hipStream_t)stream;
     double* partials = reinterpret_cast<double*>(workspace);
     const int64_t ntile = (N + 15) / 16;
-    const int64_t nblk = (ntile + kWaves - 1) / kWaves;
+    const int blk = shape->T == 24 ? QB_VI_BLOCK_24 : kBlock, waves = blk / 64;
+    const int64_t nblk = (ntile + waves - 1) / waves;
     const int grid = (int)(nblk < ctx->num_cus ? (nblk > 0 ? nblk : 1) : ctx->num_cus);
     const bool lit = ctx->dev.tissue_mode == QBOLD_TISSUE_LITERAL;
     float2* out = reinterpret_cast<float2*>(nll_kl);
@@ -244,14 +251,15 @@ extern "C" int qbold_vi_fwd(const qbold_ctx* ctx, const qbold_encoder_shape* sha
     do {                                                                                          \
         using LdsT = typename ViLds<TT, SE, GT>::type;                                             \
         constexpr size_t smem = sizeof(float) * qb::make_enc_layout(TT, 64, NL).total + sizeof(LdsT) + \
-                                sizeof(double) * 3 * kWaves;                                       \
+                                sizeof(double) * 3 * (kBlock / 64);                                \
         static_assert(smem <= kLdsLimit, "weight image + sampling table exceed the LDS");          \
         const float4* tab = qb::IsGtLds<LdsT>::value ? ctx->d_gtab : ctx->d_tab;                    \
-        auto k = vi_fwd_kernel<TT, NL, SE, FAST, LIT, false, GT, MIR>;                             \
-        if constexpr (FAST) { if (bf) k = vi_fwd_kernel<TT, NL, SE, FAST, LIT, true, GT, MIR>; }   \
+        constexpr int BLKT = TT == 24 ? QB_VI_BLOCK_24 : kBlock;                                   \
+        auto k = vi_fwd_kernel<TT, NL, SE, FAST, LIT, false, GT, MIR, BLKT>;                       \
+        if constexpr (FAST) { if (bf) k = vi_fwd_kernel<TT, NL, SE, FAST, LIT, true, GT, MIR, BLKT>; }   \
         QB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                              \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));       \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), smem, s, ctx->dev, tab, packed,            \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(BLKT), smem, s, ctx->dev, tab, packed,              \
                            x, mask, prior, S, K, seed, voxel0, q_out, out, partials, N);          \
     } while (0)
     const bool fast = qb::elbo_fast_path(ctx);
