@@ -1650,6 +1650,42 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
     }
 }
 
+// The same sums for a QUEUE of slabs in one launch (blockIdx.y = job): a crop step's thirteen weight-gradient kernels
+// each left a reduction of their own behind (65 blocks, ~8 us, mostly launch and latency); queued, they run as a few
+// launches of hundreds of blocks.  Same order of additions per element as slab_reduce_kernel: bitwise the same sums.
+struct SlabJob {
+    const float* partial;
+    float* dW;
+    float* db;
+    int nblk, ldw, kdim, ndim, j0;
+};
+constexpr int kMaxSlabJobs = 40;
+struct SlabJobs {
+    SlabJob job[kMaxSlabJobs];
+};
+__global__ __launch_bounds__(1024) void slab_reduce_jobs_kernel(SlabJobs jobs) {
+    constexpr int kParts = 16;
+    __shared__ double part[kParts][64];
+    const SlabJob jb = jobs.job[blockIdx.y];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6;
+    double a = 0.0;
+    if (e < 64 * 64 + 64)
+        for (int bk = p; bk < jb.nblk; bk += kParts) a += (double)jb.partial[(int64_t)bk * (64 * 64 + 64) + e];
+    part[p][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (p != 0 || e >= 64 * 64 + 64) return;
+    a = 0.0;
+#pragma unroll
+    for (int q = 0; q < kParts; ++q) a += part[q][threadIdx.x];
+    if (e < 64 * 64) {
+        const int i = e >> 6, j = (e & 63) - jb.j0;
+        if (i < jb.kdim && j >= 0 && j < jb.ndim) jb.dW[i * jb.ldw + j] = (float)a;
+    } else {
+        const int j = e - 64 * 64 - jb.j0;
+        if (jb.db && j >= 0 && j < jb.ndim) jb.db[j] = (float)a;
+    }
+}
+
 // Stacked head weights for the backward-data GEMM of both heads in one pass: Wst[k][j] (k < 5 + T rows of
 // U columns) = Wf[j][k] for k < 5, Ws[j][k - 5] beyond -- d last = [g_q | g_ls] Wst.
 __global__ void stack_heads_kernel(const float* __restrict__ Wf, const float* __restrict__ Ws, int T, int U,
@@ -2393,6 +2429,34 @@ struct Launcher {
     int64_t N;
     int ld;  // row stride of the activation tensors (64, or U rounded up to 64 beyond that)
     Gather gather = make_gather(0, 0, 0, 0, 0);
+    // Deferred slab sums (slab_reduce_jobs_kernel): while `bump` is set, every weight-gradient kernel writes its slabs
+    // to a region of its own carved from [bump, bump_end) and queues its reduction instead of launching it; the queue
+    // is flushed when the region or the job table is full, and at the end of the backward.
+    mutable float* bump = nullptr;
+    mutable float* bump0 = nullptr;
+    mutable float* bump_end = nullptr;
+    mutable SlabJobs jobs{};
+    mutable int njobs = 0;
+    void defer_slabs(float* region, float* region_end) const { bump = bump0 = region; bump_end = region_end; njobs = 0; }
+    void flush_slabs() const {
+        if (njobs > 0)
+            hipLaunchKernelGGL(slab_reduce_jobs_kernel, dim3((64 * 64 + 64) / 64, njobs), dim3(1024), 0, s, jobs);
+        njobs = 0;
+        bump = bump0;
+    }
+    // a slab region for `count` groups of nblk slabs, or null when slabs are not deferred
+    float* slab_region(int nblk, int count, int jobs_needed) const {
+        if (!bump0) return nullptr;
+        const int64_t need = (int64_t)count * nblk * (64 * 64 + 64);
+        if (need > bump_end - bump0) return nullptr;          // larger than the whole region: the undeferred path
+        if (need > bump_end - bump || njobs + jobs_needed > kMaxSlabJobs) flush_slabs();
+        float* r = bump;
+        bump += need;
+        return r;
+    }
+    void queue_slab(const float* partial, int nblk, float* dW, int ldw, int kdim, int ndim, float* db, int j0) const {
+        jobs.job[njobs++] = SlabJob{partial, dW, db, nblk, ldw, kdim, ndim, j0};
+    }
     int grid() const {
         int64_t nb = (N + 63) / 64;
         int64_t cap = (int64_t)ctx->num_cus * 4;  // 256-thread blocks per CU; measured per 1 M-voxel step with the
@@ -2476,16 +2540,23 @@ struct Launcher {
                                  ((reinterpret_cast<uintptr_t>(Xa) | reinterpret_cast<uintptr_t>(Dc) |
                                    reinterpret_cast<uintptr_t>(Rc)) & 15) == 0;
                 const int kread = kzero > kdim && kdim <= 64 ? (kzero < 64 ? kzero : 64) : ka;
+                float* own = accum ? nullptr : slab_region(nblk, 1, 1);
+                if (!own && njobs > 0) flush_slabs();   // the shared region below may hold queued slabs
+                float* part = own ? own : partial;
                 if (pieces_ok(Xa, kread, Dc, nc, Rc)) {
-                    launch_xtdb(Xa, kread, Dc, nc, partial, nblk, relu_x, Rc);
+                    launch_xtdb(Xa, kread, Dc, nc, part, nblk, relu_x, Rc);
                 } else {
                     auto kern = vec ? xtd_kernel<true> : xtd_kernel<false>;
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXtdSmem);
-                    hipLaunchKernelGGL(kern, dim3(nblk), dim3(1024), kXtdSmem, s, Xa, ld, ka, Dc, ld, nc, partial, N,
+                    hipLaunchKernelGGL(kern, dim3(nblk), dim3(1024), kXtdSmem, s, Xa, ld, ka, Dc, ld, nc, part, N,
                                        gather, relu_x, Rc);
                 }
-                hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64), dim3(1024), 0, s, partial,
+                if (own) {
+                    queue_slab(part, nblk, dW + (int64_t)a * ldw + c, ldw, ka, nc, a == 0 && db ? db + c : nullptr, 0);
+                    continue;
+                }
+                hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64), dim3(1024), 0, s, part,
                                    nblk, dW + (int64_t)a * ldw + c, ldw, ka, nc, a == 0 && db ? db + c : nullptr, accum, 0);
             }
     }
@@ -2530,12 +2601,21 @@ struct Launcher {
         const bool pieces = U <= 64 && U % 4 == 0 && gm.Z % 4 == 0 && N % 4 == 0 && N >= 4 && N < (1 << 23) &&
                             gm.X <= 512 && gm.Y <= 512 && gm.Z <= 512 && !(ctx->kernel_sel & 524288) &&
                             ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(D)) & 7) == 0;
+        float* own = slab_region(nblk, 9, 9);
+        if (!own && njobs > 0) flush_slabs();
+        if (own) partial = own;
         if (pieces)
             hipLaunchKernelGGL(relu_x ? xtd9b_kernel<true> : xtd9b_kernel<false>, dim3(nblk), dim3(512), 0, s, X, D,
                                partial, N, make_gather(gm.X, gm.Y, gm.Z, 0, 0), U);
         else
             hipLaunchKernelGGL(xtd9_kernel, dim3(nblk), dim3(512), 0, s, X, kLd, U, D, kLd, U, partial, N,
                                make_gather(gm.X, gm.Y, gm.Z, 0, 0), relu_x);
+        if (own) {
+            for (int tap = 0; tap < 9; ++tap)
+                queue_slab(partial + (int64_t)tap * nblk * (64 * 64 + 64), nblk, dK9 + (int64_t)tap * U * U, U, U, U,
+                           tap == 0 ? db : nullptr, 0);
+            return;
+        }
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((64 * 64 + 64) / 64, 9), dim3(1024), 0, s, partial,
                            nblk, dK9, U, U, U, db, 0, 0);
     }
@@ -3244,6 +3324,8 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     // the nine-tap kernel runs one 512-thread block per CU (144 accumulator registers per lane)
     const int slabs9 = (int)((N + 511) / 512 < ctx->num_cus ? ((N + 511) / 512 > 0 ? (N + 511) / 512 : 1)
                                                            : (ctx->num_cus < kSlabBlocks ? ctx->num_cus : kSlabBlocks));
+    if (gm && !(ctx->kernel_sel & QBOLD_KSEL_SLAB_SUMS_SEPARATE))   // crop batches: the step's slab sums queued (QBOLD_KSEL bit QBOLD_KSEL_SLAB_SUMS_SEPARATE: one by one)
+        k.defer_slabs(partial, partial + (int64_t)9 * kSlabBlocks * (64 * 64 + 64));
     const bool heads_one_pass = stream_sel == 2 && g_ls && U <= 64 && U % 4 == 0 && ld == kLd && 5 + T <= 16 &&
                                 N < (1 << 23) && !(ctx->kernel_sel & (16384 | 1048576)) &&
                                 ((reinterpret_cast<uintptr_t>(last) | reinterpret_cast<uintptr_t>(dB)) & 15) == 0;
@@ -3252,10 +3334,16 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                            stream_sel == 2 ? g_ls : nullptr, T, sums, dA, ld, N);
     if (heads_one_pass) {
         // both heads' data and weight gradients in one pass over the rows (heads_bwd_kernel): no delta tensor
+        float* hp = k.slab_region(slabs, 1, 2);
         hipLaunchKernelGGL(heads_bwd_kernel, dim3(slabs), dim3(512), 0, k.s, g_q, g_ls, T, sums, last, w + c.Wf, w + c.Ws,
-                           U, dB, partial, N);
-        k.reduce_cols(partial, slabs, grad + c.Wf, 5, U, 5, grad + c.bf, 0);
-        k.reduce_cols(partial, slabs, grad + c.Ws, T, U, T, grad + c.bs, 5);
+                           U, dB, hp ? hp : partial, N);
+        if (hp) {
+            k.queue_slab(hp, slabs, grad + c.Wf, 5, U, 5, grad + c.bf, 0);
+            k.queue_slab(hp, slabs, grad + c.Ws, T, U, T, grad + c.bs, 5);
+        } else {
+            k.reduce_cols(partial, slabs, grad + c.Wf, 5, U, 5, grad + c.bf, 0);
+            k.reduce_cols(partial, slabs, grad + c.Ws, T, U, T, grad + c.bs, 5);
+        }
     } else if (stream_sel == 2 && g_ls && U <= 64 && ld == kLd && 5 + T <= 64 && !(ctx->kernel_sel & 16384)) {
         // both heads at once: one weight-gradient pass over the 5 + T delta columns (slab columns 0-4 -> Wf,
         // 5 .. -> Ws) and one backward-data GEMM with the stacked weights [Wf^T; Ws^T] -- instead of two
@@ -3394,6 +3482,7 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     // (Having block 0's one-launch backward apply the mask it holds anyway was measured and lost: 16 selects more and
     // the 512-register kernel spills 336 bytes per lane instead of 44, 1.00 ms against 0.78.)
     k.xtd(slot(0), T, dB, U, partial, slabs, grad + c.W0, U, grad + c.b0, 0, 0, slot(1), (T + 3) & ~3);
+    k.flush_slabs();
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }

@@ -673,3 +673,34 @@ def test_voxel_batch_weight_gradients_bf16_pieces_and_one_pass_heads_against_exa
                 ta, tb = a[off:off + cnt], b[off:off + cnt]
                 assert float((ta - tb).abs().max()) <= 3e-6 * float(ta.abs().max()) + 1e-30, \
                     (U, L, N, name, l, float((ta - tb).abs().max()), float(ta.abs().max()))
+
+
+def test_crop_weight_gradients_queued_slab_sums_equal_the_separate_launches(params):
+    """The crop backward queues its weight-gradient slab sums into a few launches (slab_reduce_jobs_kernel);
+    QBOLD_KSEL_SLAB_SUMS_SEPARATE sums every group of slabs with a launch of its own.  Both add the same slabs in the
+    same order: the gradients are equal bit for bit, for crops small enough to leave most slabs empty and for
+    batches that fill the slab region more than once."""
+    from qbold_vi_amd.init import init_encoder_weights
+    from qbold_vi_amd.ops import Context, EncoderWeights, TrainState
+    rng = np.random.default_rng(91)
+    separate = 2097152                      # QBOLD_KSEL_SLAB_SUMS_SEPARATE
+    for U, L, geometry, act in [(12, 1, (1, 3, 2, 1), "relu"), (40, 2, (3, 11, 9, 4), "gelu"),
+                                (64, 3, (6, 30, 20, 8), "gelu"), (64, 6, (2, 30, 20, 8), "relu")]:
+        B, X, Y, Z = geometry
+        N = B * X * Y * Z
+        w = init_encoder_weights(T=11, U=U, L=L, channelwise_gating=True, resid_init_std=0.05, im_loss_sigma=0.05,
+                                 seed=U + L, spatial_taps=9)
+        x = torch.as_tensor(rng.uniform(0.2, 1.0, (B, X, Y, Z, 11)).astype(np.float32), device="cuda")
+        g_q = torch.as_tensor(rng.normal(size=(N, 5)).astype(np.float32), device="cuda")
+        g_ls = torch.as_tensor(rng.normal(size=(N, 11)).astype(np.float32), device="cuda")
+        grads = {}
+        for sel in (0, separate):
+            ctx = Context(params, True, True)
+            ctx.set_kernel_selection(sel)
+            ew = EncoderWeights(ctx, 11, U, L, True, -3.0, spatial_taps=9, activation=act).set_from_arrays(w)
+            st = TrainState(ctx, ew)
+            st.forward_spatial(x)
+            grads[sel] = st.backward_spatial(g_q, g_ls, None).clone()
+        assert torch.isfinite(grads[0]).all() and float(grads[0].abs().max()) > 0, (U, L, geometry)
+        assert torch.equal(grads[0], grads[separate]), \
+            (U, L, geometry, float((grads[0] - grads[separate]).abs().max()))
