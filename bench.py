@@ -35,7 +35,7 @@ def measured_profile(name, kernel):
         d = json.load(open(path))
         d["_file"] = name
         from qbold_vi_amd.build import source_fingerprint
-        if d.get("source_sha256") != source_fingerprint() or kernel not in d.get("kernel", ""):
+        if d.get("source_sha256") != source_fingerprint(d.get("source_units")) or kernel not in d.get("kernel", ""):
             return None
         return d
     except Exception:

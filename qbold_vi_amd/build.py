@@ -21,14 +21,26 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
 
 
-def source_fingerprint():
-    """sha256 over the kernel sources and headers: profiles record it, bench.py drops counters measured on
-    other sources."""
+def file_digests():
+    """{file name: sha256 of its text} of every kernel source and header: what the profiling scripts record on the GPU box."""
     import hashlib
-    h = hashlib.sha256()
-    for name in sorted(SOURCES) + sorted(HEADERS):
+    d = {}
+    for name in SOURCES + HEADERS:
         with open(os.path.join(CSRC, name), "rb") as f:
-            h.update(name.encode() + b"\0" + f.read())
+            d[name] = hashlib.sha256(f.read()).hexdigest()
+    return d
+
+
+def source_fingerprint(units=None, digests=None):
+    """sha256 over the digests of kernel sources and of every header: profiles record it, bench.py drops counters
+    measured on other sources.  `units` = the translation units the profiled kernels live in (None: all of them) -- a
+    profile of vi_fwd_kernel stays valid while train_kernels.hip moves, and goes stale with any header.  `digests`: a
+    recorded file_digests() instead of the files here."""
+    import hashlib
+    d = digests or file_digests()
+    h = hashlib.sha256()
+    for name in sorted(SOURCES if units is None else units) + sorted(HEADERS):
+        h.update(name.encode() + b"\0" + d[name].encode() + b"\n")
     return h.hexdigest()
 
 

@@ -888,17 +888,26 @@ __global__ __launch_bounds__(1024) void conv9_kernel(const float* __restrict__ X
 // MFMAs; this one 9 x 24 x 16 = 3.5 k matrix-pipe cycles plus the operand splits.  The nine tap kernels are
 // converted once per workgroup into the weight image of encoder_core.h (9 x 16 KiB of LDS); a lane owns one
 // voxel: its crop coordinates are split once per tile, every tap reads the neighbour's row (or zeros).
+// SCALED (the backward-data launches): the rows are deltas that carry the loss's 1 / sum(mask) -- 1e-6 and below, where
+// an f16 high half is subnormal or zero.  They are multiplied by 2^floor(log2 sum(mask)) on arrival (in place of the
+// forward's relu-on-arrival: the same instruction count) and the outputs by its inverse: exact both ways, and the
+// split sees the per-voxel gradients at their own magnitude, whatever the batch size.
+template <bool SCALED>
 __global__ __launch_bounds__(1024) void conv9h_kernel(const float* __restrict__ X, int ldx, int U,
                                                       const float* __restrict__ K9, int flip,
                                                       const float* __restrict__ b, float* __restrict__ Y,
                                                       int ldy, int act, const float* __restrict__ mask,
-                                                      int ldm, int64_t N, Gather g0) {
+                                                      int ldm, int64_t N, Gather g0,
+                                                      const double* __restrict__ sums) {
     extern __shared__ __align__(16) float img[];  // [9][s 2][m 4][hi, lo][lane 64][8 halves], then bias[64]
     float* bias = img + 9 * 4096;
     // the nine tap kernels into the weight image: thread (a, b) of a 16 x 64 patch reads W[tap][a][b] (rows of U
     // floats, coalesced; 36 independent loads per thread, all in flight at once -- walking the IMAGE in order
     // instead made 72 dependent scattered reads per thread, half of the launch) and scatters its two halves
-    {
+#ifndef QB_CONV9H_ABL   // timing experiments only (scripts/dev/variant.sh): 1 no weight image, 2 no MFMAs, 4 one tap's loads, 8 no split
+#define QB_CONV9H_ABL 0
+#endif
+    if (!(QB_CONV9H_ABL & 1)) {
         const int tb = threadIdx.x & 63, ta = threadIdx.x >> 6;
         const float bv = b && threadIdx.x < 64 && (int)threadIdx.x < U ? b[threadIdx.x] : 0.0f;   // in flight with the weights
         float wv[9][4];
@@ -934,6 +943,17 @@ __global__ __launch_bounds__(1024) void conv9h_kernel(const float* __restrict__ 
 #pragma unroll
     for (int q = 0; q < 4; ++q) col[q] = 16 * q + 4 * g < U ? 4u * (16 * q + 4 * g) : kOutside;
     const float in_floor = act & ACT_RELU_IN ? 0.0f : -INFINITY;   // relu on the rows as they arrive, or nothing
+    float s_in = 1.0f, s_out = 1.0f;
+    if constexpr (SCALED) {
+        const float sm = (float)sums[2];
+        if (sm >= 1.0f && sm < 1e30f) {
+            int e;
+            (void)frexpf(sm, &e);          // sm = m 2^e, m in [0.5, 1)
+            s_in = ldexpf(1.0f, e - 1);
+            s_out = ldexpf(1.0f, 1 - e);
+        }
+    }
+    const float lo_unscale = QB_LO_UNSCALE * s_out;
     for (int64_t tile = (int64_t)blockIdx.x * 16 + wave; tile < ntile; tile += (int64_t)gridDim.x * 16) {
         const int64_t v = tile * 16 + i;
         const bool ok = v < N;
@@ -971,7 +991,10 @@ __global__ __launch_bounds__(1024) void conv9h_kernel(const float* __restrict__ 
         load_tap(0, rows[0], some[0]);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap < 8) load_tap(tap + 1, rows[(tap + 1) & 1], some[(tap + 1) & 1]);
+            if (tap < 8 && !(QB_CONV9H_ABL & 4)) load_tap(tap + 1, rows[(tap + 1) & 1], some[(tap + 1) & 1]);
+            if ((QB_CONV9H_ABL & 4) && tap < 8) { some[(tap + 1) & 1] = some[0];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rows[(tap + 1) & 1][q] = rows[tap & 1][q]; }
             if (!some[tap & 1]) continue;  // the whole tile reads padding
             const float4(&rw)[4] = rows[tap & 1];
             qb::f16x8 bhi[2], blo[2];
@@ -980,7 +1003,11 @@ __global__ __launch_bounds__(1024) void conv9h_kernel(const float* __restrict__ 
                 float x8[8] = {rw[2 * st].x, rw[2 * st].y, rw[2 * st].z, rw[2 * st].w,
                                rw[2 * st + 1].x, rw[2 * st + 1].y, rw[2 * st + 1].z, rw[2 * st + 1].w};
 #pragma unroll
-                for (int j8 = 0; j8 < 8; ++j8) x8[j8] = max_1op(x8[j8], in_floor);
+                for (int j8 = 0; j8 < 8; ++j8) x8[j8] = SCALED ? x8[j8] * s_in : max_1op(x8[j8], in_floor);
+                if (QB_CONV9H_ABL & 8) {
+                    bhi[st] = __builtin_bit_cast(qb::f16x8, rw[2 * st]);
+                    blo[st] = __builtin_bit_cast(qb::f16x8, rw[2 * st + 1]);
+                } else
                 qb::split8<false>(x8, bhi[st], blo[st]);
             }
             const float* A = img + tap * 4096;
@@ -990,6 +1017,10 @@ __global__ __launch_bounds__(1024) void conv9h_kernel(const float* __restrict__ 
                 for (int m = 0; m < 4; ++m) {
                     const qb::f16x8 whi = qb::lds_frag(A, (st * 4 + m) * 2 + 0, lane);
                     const qb::f16x8 wlo = qb::lds_frag(A, (st * 4 + m) * 2 + 1, lane);
+                    if (QB_CONV9H_ABL & 2) {
+                        out[m][0] += (float)whi[0] * (float)bhi[st][0] + (float)wlo[1] * (float)blo[st][1];
+                        continue;
+                    }
                     out[m] = QB_MFMA_F16(whi, bhi[st], out[m]);
                     cross[m] = QB_MFMA_F16(whi, blo[st], cross[m]);
                     cross[m] = QB_MFMA_F16(wlo, bhi[st], cross[m]);
@@ -1005,7 +1036,8 @@ __global__ __launch_bounds__(1024) void conv9h_kernel(const float* __restrict__ 
             float yv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                yv[r] = fmaf(cross[m][r], QB_LO_UNSCALE, out[m][r]) + bj[r];
+                yv[r] = SCALED ? fmaf(cross[m][r], lo_unscale, out[m][r] * s_out) + bj[r]
+                               : fmaf(cross[m][r], QB_LO_UNSCALE, out[m][r]) + bj[r];
                 if (act & ACT_RELU) yv[r] = fmaxf(yv[r], 0.0f);
             }
             if (j + 3 < U) {
@@ -2489,8 +2521,9 @@ struct Launcher {
     }
     // 3x3x1 'same' convolution as nine gathered GEMMs: Y = act(sum_taps X[nbr] K[tap] + b).
     // flip = 1 is the adjoint wrt the input (taps mirrored, kernels transposed).
+    // delta_sums (backward-data launches): the device double[3] whose [2] is the sum(mask) the deltas were divided by
     void conv3x3(const float* X, const float* K9, int U, const float* b, float* Y, int act, int flip,
-                 const float* mask, const qbold_geometry& gm) {
+                 const float* mask, const qbold_geometry& gm, const double* delta_sums = nullptr) {
         if (U <= 64 && ld == kLd && !(ctx->kernel_sel & 256)) {  // one launch, accumulators in registers
             const int64_t nb = (N + 255) / 256;
             const int64_t cap = (int64_t)ctx->num_cus;
@@ -2501,10 +2534,13 @@ struct Launcher {
                                    reinterpret_cast<uintptr_t>(mask)) & 15) == 0;
             if (aligned && U % 4 == 0 && N < (1 << 23) && !(ctx->kernel_sel & 65536) && !(act & (ACT_GELU | ACT_GELU_IN))) {   // split-f16 matrix pipe (bit 65536 / gelu / odd widths: the exact-f32 form)
                 const size_t smh = sizeof(float) * (9 * 4096 + 64);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9h_kernel),
+                const bool scaled = delta_sums && !(act & ACT_RELU_IN);
+                auto kern = scaled ? conv9h_kernel<true> : conv9h_kernel<false>;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smh);
-                hipLaunchKernelGGL(conv9h_kernel, dim3((unsigned)(nb < cap ? (nb > 0 ? nb : 1) : cap)), dim3(1024), smh, s,
-                                   X, ld, U, K9, flip, b, Y, ld, act, mask, ld, N, make_gather(gm.X, gm.Y, gm.Z, 0, 0));
+                hipLaunchKernelGGL(kern, dim3((unsigned)(nb < cap ? (nb > 0 ? nb : 1) : cap)), dim3(1024), smh, s,
+                                   X, ld, U, K9, flip, b, Y, ld, act, mask, ld, N, make_gather(gm.X, gm.Y, gm.Z, 0, 0),
+                                   delta_sums);
                 gather = make_gather(0, 0, 0, 0, 0);
                 return;
             }
@@ -3126,7 +3162,7 @@ static int train_bwd_gelu(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             gelu_of(b_in, Gb);
             if (gm) {
                 k.xtd9(t, U, dD, partial, slabs9, gb + c.Wr2, gb + c.br2, *gm);
-                k.conv3x3(dD, wb + c.Wr2, U, nullptr, dE, ACT_NONE, 1, nullptr, *gm);     // d t (post-activation)
+                k.conv3x3(dD, wb + c.Wr2, U, nullptr, dE, ACT_NONE, 1, nullptr, *gm, sums);     // d t (post-activation)
                 k.conv3x3(Gb, wb + c.Wr1, U, wb + c.br1, Z, ACT_NONE, 0, nullptr, *gm);   // z_t, model.py:152
             } else {
                 k.xtd(t, U, dD, U, partial, slabs, gb + c.Wr2 + ctr, U, gb + c.br2, 0);
@@ -3136,7 +3172,7 @@ static int train_bwd_gelu(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             times_dgelu(dE, Z);                                                           // d z_t
             if (gm) {
                 k.xtd9(Gb, U, dE, partial, slabs9, gb + c.Wr1, gb + c.br1, *gm, 0);
-                k.conv3x3(dE, wb + c.Wr1, U, nullptr, dB, ACT_NONE, 1, nullptr, *gm);     // d gelu(b_in)
+                k.conv3x3(dE, wb + c.Wr1, U, nullptr, dB, ACT_NONE, 1, nullptr, *gm, sums);     // d gelu(b_in)
             } else {
                 k.xtd(Gb, U, dE, U, partial, slabs, gb + c.Wr1 + ctr, U, gb + c.br1, 0, 0);
                 k.xw(dE, ld, U, wb + c.Wr1 + ctr, U, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
@@ -3247,7 +3283,7 @@ static int train_bwd_norm(const qbold_ctx* ctx, const qbold_encoder_shape* shape
         normalizer(p, 1, Z);                                                          // a2 (and p's statistics)
         if (gm) {
             k.xtd9(Z, U, dD, partial, slabs9, gb + c.Wr2, gb + c.br2, *gm);
-            k.conv3x3(dD, wb + c.Wr2, U, nullptr, dE, ACT_NONE, 1, nullptr, *gm);     // d a2
+            k.conv3x3(dD, wb + c.Wr2, U, nullptr, dE, ACT_NONE, 1, nullptr, *gm, sums);     // d a2
         } else {
             k.xtd(Z, U, dD, U, partial, slabs, gb + c.Wr2 + ctr, U, gb + c.br2, 0);
             k.xw(dD, ld, U, wb + c.Wr2 + ctr, U, 1, nullptr, dE, U, ACT_NONE, 0, nullptr);
@@ -3258,7 +3294,7 @@ static int train_bwd_norm(const qbold_ctx* ctx, const qbold_encoder_shape* shape
         normalizer(b_in, 0, A1);
         if (gm) {
             k.xtd9(A1, U, dE, partial, slabs9, gb + c.Wr1, gb + c.br1, *gm, 0);
-            k.conv3x3(dE, wb + c.Wr1, U, nullptr, dB, ACT_NONE, 1, nullptr, *gm);     // d a1
+            k.conv3x3(dE, wb + c.Wr1, U, nullptr, dB, ACT_NONE, 1, nullptr, *gm, sums);     // d a1
         } else {
             k.xtd(A1, U, dE, U, partial, slabs, gb + c.Wr1 + ctr, U, gb + c.br1, 0, 0);
             k.xw(dE, ld, U, wb + c.Wr1 + ctr, U, 1, nullptr, dB, U, ACT_NONE, 0, nullptr);
@@ -3451,10 +3487,10 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
             if (gm) {
                 // second residual conv (3x3x1): dK2[tap] = t[nbr]^T dD; d t_pre = conv^T(dD) * (t > 0) -> dE
                 k.xtd9(t, U, dD, partial, slabs9, gb + c.Wr2, gb + c.br2, *gm);
-                k.conv3x3(dD, wb + c.Wr2, U, nullptr, dE, ACT_NONE, 1, t, *gm);
+                k.conv3x3(dD, wb + c.Wr2, U, nullptr, dE, ACT_NONE, 1, t, *gm, sums);
                 // first residual conv: input relu(b_in)
                 k.xtd9(b_in, U, dE, partial, slabs9, gb + c.Wr1, gb + c.br1, *gm, 1);
-                k.conv3x3(dE, wb + c.Wr1, U, nullptr, dB, ACT_NONE, 1, b_in, *gm);
+                k.conv3x3(dE, wb + c.Wr1, U, nullptr, dB, ACT_NONE, 1, b_in, *gm, sums);
             } else {
                 const int ctr = c.taps == 9 ? 4 * U * U : 0;
                 // second residual conv: dWr2 = t^T dD; d t_pre = (dD Wr2^T) * (t > 0)  -> dE

@@ -22,16 +22,31 @@ def last_json_line(path):
 
 
 def sha(part):
+    """What the profiling script recorded on the GPU box: the digests of every source file (round 4 on:
+    qbold_vi_amd.build.file_digests), or one fingerprint over all sources (rounds 2 and 3)."""
     p = os.path.join(src, f"source_sha256_{part}.txt")
-    return open(p).read().strip() if os.path.exists(p) else None
+    if not os.path.exists(p):
+        return None
+    text = open(p).read().strip()
+    return json.loads(text) if text.startswith("{") else text
 
 
-def pmc_file(summary_name, kernel, n, algorithmic, fingerprint, extra=None):
+def unit_sha(recorded, units):
+    """(fingerprint, units) over the translation units a kernel lives in and every header: valid while other units change."""
+    if recorded is None or isinstance(recorded, str):
+        return recorded, None
+    sys.path.insert(0, ROOT)
+    from qbold_vi_amd.build import source_fingerprint
+    return source_fingerprint(units, recorded), units
+
+
+def pmc_file(summary_name, kernel, n, algorithmic, recorded, units, extra=None):
+    fingerprint, units = unit_sha(recorded, units)
     s = json.load(open(os.path.join(src, summary_name)))
     c = {k: v["mean"] for k, v in s["pmc"].items()}
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         return None
-    d = {"kernel": kernel, "voxels": n, "source_sha256": fingerprint,
+    d = {"kernel": kernel, "voxels": n, "source_sha256": fingerprint, "source_units": units,
          "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
          "hbm_read_bytes_x2_gfx950": 2 * c["FETCH_SIZE"] * 1024, "hbm_write_bytes": c["WRITE_SIZE"] * 1024,
          "hbm_bytes_per_launch": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024,
@@ -66,13 +81,13 @@ for name in sorted(os.listdir(src)):
 fa, fb = sha("a"), sha("b")
 if fa and os.path.exists(os.path.join(src, f"{tag}_vi_fwd_summary.json")):
     kname = "vi_fwd_kernel<11,2,2,true,false,false" + (",true,false>" if tag >= "r04" else ",true>" if tag >= "r03" else ">")
-    put(f"{tag}_vi_fwd_pmc.json", pmc_file(f"{tag}_vi_fwd_summary.json", kname, n, 96 * n, fa))
+    put(f"{tag}_vi_fwd_pmc.json", pmc_file(f"{tag}_vi_fwd_summary.json", kname, n, 96 * n, fa, ["vi_kernels.hip"]))
 if fb:
     if os.path.exists(os.path.join(src, f"{tag}_config3_wide_fused_summary.json")):
         T = 64
-        enc = pmc_file(f"{tag}_config3_wide_fused_summary.json", "wide_fused_kernel<4, 2, true>", n, (4 * T + 4 * T + 20) * n, fb)
+        enc = pmc_file(f"{tag}_config3_wide_fused_summary.json", "wide_fused_kernel<4, 2, true>", n, (4 * T + 4 * T + 20) * n, fb, ["elbo_kernels.hip", "wide_fused_kernels.hip"])
         elbo = pmc_file(f"{tag}_config3_elbo_summary.json", ("elbo_fwd_gt64_kernel" if tag >= "r04" else "elbo_fwd_lds_kernel") + "<64, 12, true>", n,
-                        (4 * T + 4 * T + 20 + 4 + 20 + 8) * n, fb)
+                        (4 * T + 4 * T + 20 + 4 + 20 + 8) * n, fb, ["elbo_kernels.hip"])
         if enc and elbo:
             enc["step"] = {"launches": ["wide_fused_kernel", "elbo_fwd_gt64_kernel" if tag >= "r04" else "elbo_fwd_lds_kernel"],
                            "hbm_bytes": enc["hbm_bytes_per_launch"] + elbo["hbm_bytes_per_launch"],
@@ -86,11 +101,11 @@ if fb:
     for t, kernel, alg in (("p24", "vi_fwd_kernel<24,2,7,true,false,false" + (",true,false>" if tag >= "r04" else ">"), (4 * 24 + 52) * n),
                            ("bf16", "vi_fwd_kernel<11,2,2,true,false,true" + (",true,false>" if tag >= "r04" else ",true>" if tag >= "r03" else ">"), 96 * n)):
         if os.path.exists(os.path.join(src, f"{tag}_{t}_vi_fwd_summary.json")):
-            put(f"{tag}_{t}_vi_fwd_pmc.json", pmc_file(f"{tag}_{t}_vi_fwd_summary.json", kernel, n, alg, fb))
+            put(f"{tag}_{t}_vi_fwd_pmc.json", pmc_file(f"{tag}_{t}_vi_fwd_summary.json", kernel, n, alg, fb, ["vi_kernels.hip"]))
 fc = sha("c")
 if fc:
     train = {"workload": "scripts/bench_train.py --only voxel: one fine-tuning step on 1,048,576 voxels ([N][64] float32 "
-                         "tensors = 268 MB each)", "source_sha256": fc, "note": NOTE, "kernels": {}}
+                         "tensors = 268 MB each)", "source_sha256": unit_sha(fc, None)[0], "note": NOTE, "kernels": {}}
     for k in ("block_bwd_dw_kernel", "block_bwd_kernel", "encoder_train_fwd_kernel", "xtd_kernel", "elbo_bwd_kernel"):
         f = os.path.join(src, f"{tag}_train_{k}_summary.json")
         if os.path.exists(f):

@@ -71,5 +71,5 @@ else
     done
     python3 bench.py --config 3 --no_cpu_baseline > $P/r04_bench_config3.json 2> $G/r04_bench_c3.err; echo "bench config3 rc=$?"
 fi
-python3 -c "from qbold_vi_amd.build import source_fingerprint; print(source_fingerprint())" > $P/source_sha256_$PART.txt
+python3 -c "import json; from qbold_vi_amd.build import file_digests; print(json.dumps(file_digests()))" > $P/source_sha256_$PART.txt
 ls -la $P

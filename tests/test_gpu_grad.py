@@ -704,3 +704,37 @@ def test_crop_weight_gradients_queued_slab_sums_equal_the_separate_launches(para
         assert torch.isfinite(grads[0]).all() and float(grads[0].abs().max()) > 0, (U, L, geometry)
         assert torch.equal(grads[0], grads[separate]), \
             (U, L, geometry, float((grads[0] - grads[separate]).abs().max()))
+
+
+def test_crop_backward_keeps_its_precision_when_the_deltas_carry_one_over_sum_mask(params):
+    """The crop backward's 3 x 3 x 1 backward-data products run on split-f16 operands (conv9h_kernel).  Deltas that carry
+    the loss's 1 / sum(mask) sit far under f16's normal range: the kernel lifts them by 2^floor(log2 sum(mask)) on arrival
+    and scales its outputs back, both exact.  The gradient with `sums` given must therefore be the gradient without,
+    divided by sum(mask), to float32 rounding -- for a sum(mask) of a large crop batch and for one beyond any batch
+    (unscaled, deltas of 1e-9 lose their high halves altogether: errors of 1e-2)."""
+    from qbold_vi_amd.init import init_encoder_weights
+    from qbold_vi_amd.ops import Context, EncoderWeights, TrainState
+    rng = np.random.default_rng(17)
+    U, L = 60, 2
+    B, X, Y, Z = 3, 12, 10, 4
+    N = B * X * Y * Z
+    w = init_encoder_weights(T=11, U=U, L=L, channelwise_gating=True, resid_init_std=0.05, im_loss_sigma=0.05, seed=3,
+                             spatial_taps=9)
+    x = torch.as_tensor(rng.uniform(0.2, 1.0, (B, X, Y, Z, 11)).astype(np.float32), device="cuda")
+    g_q = torch.as_tensor(rng.normal(size=(N, 5)).astype(np.float32), device="cuda")
+    g_ls = torch.as_tensor(rng.normal(size=(N, 11)).astype(np.float32), device="cuda")
+    ctx = Context(params, True, True)
+    ew = EncoderWeights(ctx, 11, U, L, True, -3.0, spatial_taps=9).set_from_arrays(w)
+    st = TrainState(ctx, ew)
+    st.forward_spatial(x)
+    plain = st.backward_spatial(g_q, g_ls, None).double().clone()
+    for total in (190000.0 * 0.6, 3.0e9):
+        sums = torch.tensor([0.0, 0.0, total], dtype=torch.float64, device="cuda")
+        st.forward_spatial(x)
+        scaled = st.backward_spatial(g_q, g_ls, sums).double().clone() * total
+        for name, pieces in ew._slices().items():
+            for l, (off, shape) in enumerate(pieces):
+                cnt = int(np.prod(shape))
+                a, b = plain[off:off + cnt], scaled[off:off + cnt]
+                assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-30, \
+                    (total, name, l, float((a - b).abs().max()), float(a.abs().max()))
