@@ -168,7 +168,8 @@ int qbold_ctx_set_grad_node0(qbold_ctx* ctx, int on);
 #define QBOLD_KSEL_DW_EXACT_F32 524288      /* 3x3x1 weight gradients as exact f32 products instead of bf16 pieces */
 #define QBOLD_KSEL_HEADS_BWD_LAYERWISE 1048576 /* heads' backward as delta tensor + GEMM + weight-gradient pass */
 #define QBOLD_KSEL_SLAB_SUMS_SEPARATE 2097152 /* crop backward: every weight-gradient slab sum as its own launch instead of the queued ones */
-#define QBOLD_KSEL_ALL (4 | 8 | 256 | 512 | 2048 | 4096 | 8192 | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152)
+#define QBOLD_KSEL_DW_BF16_PIECES 4194304     /* layer-wise weight gradients on three bfloat16 pieces per operand instead of two f16 halves */
+#define QBOLD_KSEL_ALL (4 | 8 | 256 | 512 | 2048 | 4096 | 8192 | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304)
 int qbold_ctx_set_kernel_selection(qbold_ctx* ctx, int mask);
 /* Host-side evaluation of the uploaded table (for tests): F(x) and dF/dx, HOST arrays. */
 int qbold_ctx_table_eval(const qbold_ctx* ctx, const float* host_x, float* host_F, float* host_dF,

@@ -10,7 +10,6 @@
 // training steps are 190-256 k voxels in the reference (train.py:68,103), ~1 GB of activations,
 // and HBM-bound at a few ms per step -- off the voxel-ELBO headline path, correctness first.
 #include <cmath>
-#include <type_traits>
 
 #include "canon_layout.h"
 #include "encoder_core.h"
@@ -1398,6 +1397,91 @@ __device__ __forceinline__ f32x4 bf3_mfma(const Bf3& x, const Bf3Cols& d, f32x4 
     return QB_MFMA_BF16(a20, b02, acc);   // x2 d0 + x0 d2
 }
 
+// ---- the same products on the f16 matrix pipe: a float32 as TWO f16 halves, deltas under a running scale --------
+// x = hi + lo, hi = f16(x), lo = f16(x - hi) UNSCALED (22 significant bits while lo is normal, i.e. |x| >= 2^-3 of
+// the f16 unit; below that an absolute 2^-25).  All four half products are kept and land in ONE accumulator: with
+// K = 32 = 16 voxels x two halves,  [xh | xh] . [dh | dl]  and  [xl | xl] . [dh | dl]  are two MFMAs where the
+// three-piece bf16 form takes three, and a split costs 1.5 vector instructions per value (a packed conversion and
+// one mixed-precision FMA) where the bf16 pieces cost 5.5 -- on kernels whose time is those instructions.
+// What made this form impossible in round 3 -- deltas carry the loss's 1 / sum(mask), far under f16's range, and a
+// per-voxel scale does not factor out of a sum over voxels -- is met by a scale per WAVE that only ever falls: the
+// deltas are multiplied by s (a power of two) before the split and the wave's accumulators hold s x the sums.  A step
+// whose largest |delta| x s reaches 2^14 (one v_max3 per pair, one compare, one scalar branch) takes the slow path
+// once: the wave's maximum sets s so that it lands in [2^11, 2^12) and the accumulators are rescaled (exact).  s
+// starts at 2^60, so the first step with a delta above 1e-14 sets it; the expected number of later events is the
+// number of record highs of a sequence, ~ ln(steps).  Smaller deltas that follow keep 2^-25 x 2^-12 of the
+// largest seen as their absolute error -- nothing in a sum the large ones dominate.  Activations are taken as they
+// are: the forward's own limit (|x| < 65504, include/qbold_hip.h) applies, beyond it the gradient is NaN, not a clamp.
+struct H2 {
+    uint32_t h[2], l[2];   // halves of k slots (0, 1) and (2, 3), two f16 per register
+};
+__device__ __forceinline__ void h2_split(const float (&x)[4], H2& o) {
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+        const float a = x[2 * p2], b = x[2 * p2 + 1];
+        const uint32_t h = __builtin_bit_cast(uint32_t, qb::f16x2{(_Float16)a, (_Float16)b});
+        uint32_t l;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
+        o.h[p2] = h;
+        o.l[p2] = l;
+    }
+}
+// The repeated halves sit on the row operand (short-lived: one tap's or one tile's), the column operand -- kept for
+// a whole step -- is four registers: dh | dl.
+struct H2Rows {
+    uint32_t q[8];   // xh | xh, xl | xl
+};
+__device__ __forceinline__ void h2_rows(const float (&x)[4], H2Rows& o) {
+    H2 t;
+    h2_split(x, t);
+    o.q[0] = t.h[0]; o.q[1] = t.h[1]; o.q[2] = t.h[0]; o.q[3] = t.h[1];
+    o.q[4] = t.l[0]; o.q[5] = t.l[1]; o.q[6] = t.l[0]; o.q[7] = t.l[1];
+}
+__device__ __forceinline__ void h2_cols(const float (&d)[4], float scale, H2& o) {
+    const float ds[4] = {d[0] * scale, d[1] * scale, d[2] * scale, d[3] * scale};
+    h2_split(ds, o);
+}
+__device__ __forceinline__ f32x4 h2_mfma(const H2Rows& x, const H2& d, f32x4 acc) {
+    const qb::f16x8 ah = __builtin_bit_cast(qb::f16x8, u32x4b{x.q[0], x.q[1], x.q[2], x.q[3]});
+    const qb::f16x8 al = __builtin_bit_cast(qb::f16x8, u32x4b{x.q[4], x.q[5], x.q[6], x.q[7]});
+    const qb::f16x8 b = __builtin_bit_cast(qb::f16x8, u32x4b{d.h[0], d.h[1], d.l[0], d.l[1]});
+    acc = QB_MFMA_F16(ah, b, acc);     // xh dh + xh dl
+    return QB_MFMA_F16(al, b, acc);    // xl dh + xl dl
+}
+// the operand forms of the weight-gradient kernels: H16 = two f16 halves under the wave's delta scale, else three
+// bfloat16 pieces (QBOLD_KSEL_DW_BF16_PIECES)
+template <bool H16> struct DwOps;
+template <> struct DwOps<false> {
+    typedef Bf3 Rows;
+    typedef Bf3Cols Cols;
+    static __device__ __forceinline__ void rows(const float (&x)[4], Rows& o) { bf3_split(x, o); }
+    static __device__ __forceinline__ void cols(const float (&d)[4], float, Cols& o) { bf3_cols(d, o); }
+    static __device__ __forceinline__ f32x4 mfma(const Rows& x, const Cols& d, f32x4 acc) { return bf3_mfma(x, d, acc); }
+};
+template <> struct DwOps<true> {
+    typedef H2Rows Rows;
+    typedef H2 Cols;
+    static __device__ __forceinline__ void rows(const float (&x)[4], Rows& o) { h2_rows(x, o); }
+    static __device__ __forceinline__ void cols(const float (&d)[4], float s, Cols& o) { h2_cols(d, s, o); }
+    static __device__ __forceinline__ f32x4 mfma(const Rows& x, const Cols& d, f32x4 acc) { return h2_mfma(x, d, acc); }
+};
+constexpr float kDeltaScale0 = 1.152921504606846976e18f;   // 2^60
+constexpr float kDeltaTrip = 16384.0f;                      // 2^14: f16 ends at 65504
+// the slow path of the wave's delta scale: m = this lane's largest |delta| of the step; returns the factor the
+// accumulators take (new scale / old scale) and sets the new scale
+__device__ __forceinline__ float delta_rescale(float m, float& scale) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (!(m < 1e30f)) return 1.0f;   // inf / NaN deltas: they propagate as they are
+    int e;
+    (void)frexpf(m, &e);             // m = f 2^e, f in [0.5, 1)
+    const float ns = ldexpf(1.0f, 12 - e);   // m ns in [2^11, 2^12)
+    const float f = ns / scale;
+    scale = ns;
+    return f;
+}
+
 // xtd9_kernel on the bf16 matrix pipe, 16 voxels per step, for layers of U <= 64, U % 4 == 0 units.  A lane group takes FOUR
 // CONSECUTIVE voxels: with Z % 4 == 0 they are one z run of one (x, y) column, so a step splits one flat index
 // (32-bit multiply-high divisions), tests one neighbourhood and reads every tap's four rows off one offset
@@ -1422,9 +1506,11 @@ __device__ __forceinline__ void divmod32(uint32_t n, uint32_t d, uint32_t m, uin
     if (p > n) { --q; p -= d; }
     r = n - p;
 }
-template <bool RELU_X>
+template <bool RELU_X, bool H16>
 __global__ __launch_bounds__(512) void xtd9b_kernel(const float* __restrict__ X, const float* __restrict__ D,
                                                     float* __restrict__ partial, int64_t N, Gather gt, int U) {
+    typedef DwOps<H16> Ops;
+    float dscale = H16 ? kDeltaScale0 : 1.0f;
     __shared__ __align__(16) float red[64 * 64 + 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -1477,7 +1563,21 @@ __global__ __launch_bounds__(512) void xtd9b_kernel(const float* __restrict__ X,
     float xb[3][4];
     f32x4 dw[4];
     auto step = [&](const Xtd9Pos& cur, const Xtd9Pos& nxt) {
-        Bf3Cols dp[4];
+        typename Ops::Cols dp[4];
+        if constexpr (H16) {
+            float m = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m = fmaxf(m, fabsf(dw[j][c]));
+            if (__builtin_amdgcn_ballot_w64(m * dscale >= kDeltaTrip) != 0) {
+                const float f = delta_rescale(m, dscale);
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[t][c] *= f;
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float dd[4];
@@ -1486,7 +1586,7 @@ __global__ __launch_bounds__(512) void xtd9b_kernel(const float* __restrict__ X,
                 dd[j] = dw[j][c];
                 dbsum[c] += dd[j];
             }
-            bf3_cols(dd, dp[c]);
+            Ops::cols(dd, dscale, dp[c]);
         }
         load_d(nxt, dw);
 #pragma unroll
@@ -1496,10 +1596,10 @@ __global__ __launch_bounds__(512) void xtd9b_kernel(const float* __restrict__ X,
             float xa[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) xa[j] = RELU_X ? relu_1op(xb[t % 3][j]) : xb[t % 3][j];
-            Bf3 xp;
-            bf3_split(xa, xp);
+            typename Ops::Rows xp;
+            Ops::rows(xa, xp);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[t][c] = bf3_mfma(xp, dp[c], acc[t][c]);
+            for (int c = 0; c < 4; ++c) acc[t][c] = Ops::mfma(xp, dp[c], acc[t][c]);
         }
     };
     Xtd9Pos p0, p1;
@@ -1513,6 +1613,13 @@ __global__ __launch_bounds__(512) void xtd9b_kernel(const float* __restrict__ X,
         step(p0, p1);
         locate(st + 2 * stride, p0);
         step(p1, p0);
+    }
+    if constexpr (H16) {   // the wave's accumulators hold dscale x the sums
+        const float inv = 1.0f / dscale;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[t][c] *= inv;
     }
     // acc[t][c][r] of lane (g, i): input unit 16 qa + 4 g + r, output unit 4 i + c
     float sm[4];
@@ -1562,10 +1669,12 @@ __global__ __launch_bounds__(512) void xtd9b_kernel(const float* __restrict__ X,
 // and padding columns read as zeros without a select.  Eight 16-byte loads per lane are in flight per step where
 // the f32 form has two per 4-voxel step -- at crop-batch sizes (190 k rows) that latency, not the MFMAs, was the
 // kernel's time.  Slabs and their fixed-order sum as xtd_kernel (one 16 KiB tile per wave, added in wave order).
-template <bool RELU_X, bool DREF>   // DREF: D is taken as D * (Dref > 0), the step through a relu folded into the load
+template <bool RELU_X, bool DREF, bool H16>   // DREF: D is taken as D * (Dref > 0), the step through a relu folded into the load
 __global__ __launch_bounds__(512) void xtdb_kernel(const float* __restrict__ X, int kdim, const float* __restrict__ D,
                                                    int ndim, float* __restrict__ partial, int64_t N,
                                                    const float* __restrict__ Dref) {
+    typedef DwOps<H16> Ops;
+    float dscale = H16 ? kDeltaScale0 : 1.0f;
     extern __shared__ float red8[];  // [kXtdTiles][64 * 64 + 64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -1594,8 +1703,22 @@ __global__ __launch_bounds__(512) void xtdb_kernel(const float* __restrict__ X, 
         }
     };
     auto compute = [&](const Raw& w) {
-        Bf3 xp[4];
-        Bf3Cols dp[4];
+        typename Ops::Rows xp[4];
+        typename Ops::Cols dp[4];
+        if constexpr (H16) {   // (a delta the Dref mask removes counts: it can only make the scale more careful)
+            float mx = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) mx = fmaxf(mx, fabsf(w.d[j][m]));
+            if (__builtin_amdgcn_ballot_w64(mx * dscale >= kDeltaTrip) != 0) {
+                const float f = delta_rescale(mx, dscale);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[a][c] *= f;
+            }
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             float xa[4], dd[4];
@@ -1605,13 +1728,13 @@ __global__ __launch_bounds__(512) void xtdb_kernel(const float* __restrict__ X, 
                 dd[j] = DREF ? (w.r[j][m] > 0.0f ? w.d[j][m] : 0.0f) : w.d[j][m];
                 dbsum[m] += dd[j];
             }
-            bf3_split(xa, xp[m]);
-            bf3_cols(dd, dp[m]);
+            Ops::rows(xa, xp[m]);
+            Ops::cols(dd, dscale, dp[m]);
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[a][c] = bf3_mfma(xp[a], dp[c], acc[a][c]);
+            for (int c = 0; c < 4; ++c) acc[a][c] = Ops::mfma(xp[a], dp[c], acc[a][c]);
     };
     Raw b0, b1;   // two sets in rotation, the loop unrolled by two (see xtd_kernel)
     uint32_t st = blockIdx.x * 8u + wave;
@@ -1621,6 +1744,13 @@ __global__ __launch_bounds__(512) void xtdb_kernel(const float* __restrict__ X, 
         compute(b0);
         load(st + 2 * stride, b0);
         compute(b1);
+    }
+    if constexpr (H16) {   // the wave's accumulators hold dscale x the sums
+        const float inv = 1.0f / dscale;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] *= inv;
     }
     // acc[a][c][r] of lane (g, i): row 4 (4 g + r) + a, column 4 i + c
     float* red = red8 + wave * (64 * 64 + 64);
@@ -2209,7 +2339,11 @@ __global__ __launch_bounds__(kDwThreads) void block_bwd_dw_kernel(
     // step: with every register taken it adds spills, and the loads' latency is not what bounds this kernel.  So
     // was moving the four weight-gradient products to the bf16 matrix pipe with xtd9b_kernel's three-piece operands,
     // 3.03 against 2.69 ms per step: 192 MFMAs of 16 cycles replace 256 of 32, but the pieces cost 770 more vector
-    // instructions per tile and 250 bytes of scratch per lane, on a wave that has nothing to overlap them with.)
+    // instructions per tile and 250 bytes of scratch per lane, on a wave that has nothing to overlap them with.
+    // Round 4, the two-half f16 form of xtdb_kernel (128 f16 MFMAs for the 256 f32 ones, fragments as {h, l} pairs in
+    // the same 16 registers, one running delta scale per matrix): 2.58 against 2.30 ms per step WITHOUT the rescaling
+    // path (192 bytes of scratch), 4.50 with it (1,064 bytes: the slow path's reads of 64 accumulation registers sit
+    // inside the tile loop).  Third form of the same answer: this kernel's time is its register file.)
     for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntile; tile += (int64_t)gridDim.x * NW) {
         const int64_t v = tile * 16 + i;
         const bool live = v < N;
@@ -2606,8 +2740,11 @@ struct Launcher {
     }
     void launch_xtdb(const float* X, int kdim, const float* D, int ndim, float* partial, int nblk, int relu_x,
                      const float* dref) const {
-        auto kern = dref ? (relu_x ? xtdb_kernel<true, true> : xtdb_kernel<false, true>)
-                         : (relu_x ? xtdb_kernel<true, false> : xtdb_kernel<false, false>);
+        const bool h16 = !(ctx->kernel_sel & QBOLD_KSEL_DW_BF16_PIECES);
+        auto kern = h16 ? (dref ? (relu_x ? xtdb_kernel<true, true, true> : xtdb_kernel<false, true, true>)
+                                : (relu_x ? xtdb_kernel<true, false, true> : xtdb_kernel<false, false, true>))
+                        : (dref ? (relu_x ? xtdb_kernel<true, true, false> : xtdb_kernel<false, true, false>)
+                                : (relu_x ? xtdb_kernel<true, false, false> : xtdb_kernel<false, false, false>));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)kXtdSmem);
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), kXtdSmem, s, X, kdim, D, ndim, partial, N, dref);
@@ -2640,9 +2777,12 @@ struct Launcher {
         float* own = slab_region(nblk, 9, 9);
         if (!own && njobs > 0) flush_slabs();
         if (own) partial = own;
-        if (pieces)
-            hipLaunchKernelGGL(relu_x ? xtd9b_kernel<true> : xtd9b_kernel<false>, dim3(nblk), dim3(512), 0, s, X, D,
-                               partial, N, make_gather(gm.X, gm.Y, gm.Z, 0, 0), U);
+        if (pieces) {
+            const bool h16 = !(ctx->kernel_sel & QBOLD_KSEL_DW_BF16_PIECES);
+            auto kern = h16 ? (relu_x ? xtd9b_kernel<true, true> : xtd9b_kernel<false, true>)
+                            : (relu_x ? xtd9b_kernel<true, false> : xtd9b_kernel<false, false>);
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), 0, s, X, D, partial, N, make_gather(gm.X, gm.Y, gm.Z, 0, 0), U);
+        }
         else
             hipLaunchKernelGGL(xtd9_kernel, dim3(nblk), dim3(512), 0, s, X, kLd, U, D, kLd, U, partial, N,
                                make_gather(gm.X, gm.Y, gm.Z, 0, 0), relu_x);

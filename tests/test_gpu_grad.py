@@ -656,7 +656,7 @@ def test_voxel_batch_weight_gradients_bf16_pieces_and_one_pass_heads_against_exa
         g_q = torch.as_tensor((rng.normal(size=(N, 5)) * scale).astype(np.float32), device="cuda")
         g_ls = torch.as_tensor((rng.normal(size=(N, 11)) * scale).astype(np.float32), device="cuda")
         grads = {}
-        for sel in (layerwise, layerwise | 524288 | 1048576):
+        for sel in (layerwise, layerwise | 4194304, layerwise | 524288 | 1048576):
             ctx = Context(params, True, True)
             ctx.set_kernel_selection(sel)
             ew = EncoderWeights(ctx, 11, U, L, True, -3.0).set_from_arrays(w)
@@ -665,14 +665,16 @@ def test_voxel_batch_weight_gradients_bf16_pieces_and_one_pass_heads_against_exa
             st.workspace(N).fill_(float("nan"))
             st.forward(x, 2)
             grads[sel] = st.backward(2, g_q, g_ls).double().clone()
-        a, b = grads[layerwise | 524288 | 1048576], grads[layerwise]
-        assert torch.isfinite(b).all(), (U, L, N)
-        for name, pieces in ew._slices().items():
-            for l, (off, shape) in enumerate(pieces):
-                cnt = int(np.prod(shape))
-                ta, tb = a[off:off + cnt], b[off:off + cnt]
-                assert float((ta - tb).abs().max()) <= 3e-6 * float(ta.abs().max()) + 1e-30, \
-                    (U, L, N, name, l, float((ta - tb).abs().max()), float(ta.abs().max()))
+        a = grads[layerwise | 524288 | 1048576]
+        for sel in (layerwise, layerwise | 4194304):   # two f16 halves under the wave's delta scale; three bf16 pieces
+            b = grads[sel]
+            assert torch.isfinite(b).all(), (U, L, N, sel)
+            for name, pieces in ew._slices().items():
+                for l, (off, shape) in enumerate(pieces):
+                    cnt = int(np.prod(shape))
+                    ta, tb = a[off:off + cnt], b[off:off + cnt]
+                    assert float((ta - tb).abs().max()) <= 3e-6 * float(ta.abs().max()) + 1e-30, \
+                        (U, L, N, sel, name, l, float((ta - tb).abs().max()), float(ta.abs().max()))
 
 
 def test_crop_weight_gradients_queued_slab_sums_equal_the_separate_launches(params):

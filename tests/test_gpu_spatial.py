@@ -164,12 +164,14 @@ def test_spatial_gradients_add_over_crops_with_odd_sizes(ctx, oracle32):
 
 
 @pytest.mark.parametrize("B,X,Y,Z,U", [(3, 6, 5, 4, 64), (2, 25, 25, 8, 60), (1, 3, 3, 12, 20), (5, 1, 2, 4, 64)])
-def test_nine_tap_weight_gradients_bf16_pieces_against_exact_f32(params, oracle32, B, X, Y, Z, U):
-    """Layers of U % 4 == 0 units on crops with Z % 4 == 0 take xtd9b_kernel (bf16 matrix pipe, every float32 operand
-    as three bfloat16 pieces, six of the nine piece products); kernel selection 524288 (QBOLD_KSEL_DW_EXACT_F32)
-    keeps xtd9_kernel's exact float32 products.  Everything else in the two passes is the same code on the same
-    data, so the gradients may differ by the dropped piece products (<= 2^-23 per product) and the summation
-    order only.  Head deltas spread over five decades down to 1e-9: no scale is involved anywhere."""
+def test_nine_tap_weight_gradients_f16_halves_and_bf16_pieces_against_exact_f32(params, oracle32, B, X, Y, Z, U):
+    """Layers of U % 4 == 0 units on crops with Z % 4 == 0 take xtd9b_kernel on the matrix pipe: by default every float32
+    operand as two f16 halves, the deltas under the wave's running power-of-two scale (all four half products); with
+    kernel selection 4194304 (QBOLD_KSEL_DW_BF16_PIECES) as three bfloat16 pieces (six of the nine piece products, no
+    scale anywhere); 524288 (QBOLD_KSEL_DW_EXACT_F32) keeps xtd9_kernel's exact float32 products.  Everything else in
+    the passes is the same code on the same data, so the gradients may differ by the dropped bits (<= 2^-22 per product)
+    and the summation order only.  Head deltas spread over five decades down to 1e-9 and no `sums` is given: the scale
+    is found from the data, and has to fall several times on the way."""
     from qbold_vi_amd.ops import Context, TrainState
     N = B * X * Y * Z
     x = dev(crop_batch(oracle32, B, X, Y, Z, seed=9))
@@ -178,7 +180,7 @@ def test_nine_tap_weight_gradients_bf16_pieces_against_exact_f32(params, oracle3
     g_q = dev((rng.normal(size=(N, 5)) * scale).astype(np.float32))
     g_ls = dev((rng.normal(size=(N, 11)) * scale).astype(np.float32))
     grads = {}
-    for sel in (0, 524288):
+    for sel in (0, 4194304, 524288):
         c = Context(params, full_model=True, include_blood=True)
         c.set_grad_node0(False)
         c.set_kernel_selection(sel)
@@ -186,13 +188,16 @@ def test_nine_tap_weight_gradients_bf16_pieces_against_exact_f32(params, oracle3
         st = TrainState(c, ew)
         st.forward_spatial(x)
         grads[sel] = st.backward_spatial(g_q, g_ls, None).double().clone()
-    a, b = grads[524288], grads[0]
-    assert torch.isfinite(b).all()
-    for name, pieces in ew._slices().items():
-        for l, (off, shape) in enumerate(pieces):
-            cnt = int(np.prod(shape))
-            ta, tb = a[off:off + cnt], b[off:off + cnt]
-            assert float((ta - tb).abs().max()) <= 2e-6 * float(ta.abs().max()) + 1e-30, \
-                (name, l, float((ta - tb).abs().max()), float(ta.abs().max()))
-    # the nine-tap kernels really differ between the two selections (the piece path ran)
-    assert not torch.equal(a, b)
+    a = grads[524288]
+    for sel in (0, 4194304):
+        b = grads[sel]
+        assert torch.isfinite(b).all()
+        for name, pieces in ew._slices().items():
+            for l, (off, shape) in enumerate(pieces):
+                cnt = int(np.prod(shape))
+                ta, tb = a[off:off + cnt], b[off:off + cnt]
+                assert float((ta - tb).abs().max()) <= 2e-6 * float(ta.abs().max()) + 1e-30, \
+                    (sel, name, l, float((ta - tb).abs().max()), float(ta.abs().max()))
+    b = grads[0]
+    # the nine-tap kernels really differ between the selections (the matrix-pipe paths ran)
+    assert not torch.equal(a, b) and not torch.equal(grads[4194304], b)

