@@ -157,7 +157,7 @@ int qbold_ctx_set_grad_node0(qbold_ctx* ctx, int on);
 #define QBOLD_KSEL_X_TABLE 8                 /* ELBO kernels: x-indexed F table per (draw, tau) instead of the per-tau OEF-indexed one */
 #define QBOLD_KSEL_CONV_PER_TAP 256          /* 3x3x1 convolution as nine gathered GEMM launches */
 #define QBOLD_KSEL_GENERAL_GEMM 512          /* layer GEMMs on the general xw_kernel */
-#define QBOLD_KSEL_SEPARATE_GATE 2048        /* gate blend as its own launch */
+#define QBOLD_KSEL_SEPARATE_GATE 2048        /* gate blend as its own launch; layer-wise backward: gate backward and the gating conv's backward-data product as two */
 #define QBOLD_KSEL_SEPARATE_BWD_DATA 4096    /* a block's two backward-data GEMMs as two launches */
 #define QBOLD_KSEL_SEPARATE_FORK 8192        /* skip / t of a block as two GEMMs */
 #define QBOLD_KSEL_PER_HEAD_BWD 16384        /* one backward pass per head */

@@ -2059,6 +2059,122 @@ __global__ void gate_bwd_kernel(const float* __restrict__ d_b, const float* __re
 }
 
 
+// gate_bwd_kernel and the gating conv's backward-data product in one launch, for channel-wise gates on [N][64] rows
+// (U = G <= 64, U % 4 == 0): the crop backward's first two kernels read d b, gl, skip, r and wrote d s', d r, d gl,
+// then re-read d gl and d r to add d gl Wg^T -- ten tensor passes, here seven.  A wave takes 16 voxels.  In the
+// product's INPUT layout (lane (i, g): voxel i, units 16 q + 4 g ..) it forms d gl and d s' from the four rows and
+// stores them; d gl feeds the 64 exact-f32 MFMAs of xw64_kernel as it is formed.  d r = d b g + d gl Wg^T leaves in the
+// product's OUTPUT layout (lane (i, g): voxels 4 g + r, units 4 i ..), where d b and gl are read a second time (the
+// rows the tile just brought in: cache hits) and the gate evaluated again -- requested before the MFMAs.
+__global__ __launch_bounds__(256) void gate_bwd_wg_kernel(const float* __restrict__ d_b, const float* __restrict__ gl,
+                                                          const float* __restrict__ skip, const float* __restrict__ r,
+                                                          const float* __restrict__ Wg, float* __restrict__ d_skip_pre,
+                                                          float* __restrict__ d_r, float* __restrict__ d_gl,
+                                                          float offset, int U, int64_t N) {
+    extern __shared__ float Wl[];
+    constexpr int ld = kLd;
+    const int kpad = (U + 15) & ~15;
+    stage_in_flight<256>(
+        kpad * 64,
+        [&](int e) {   // Wl[k][j] = Wg[j][k]: d r = d gl Wg^T
+            const int k = clamp_hi(e >> 6, U), j = clamp_hi(e & 63, U);
+            return Wg[j * U + k];
+        },
+        [&](int e, float v) {
+            const int k = e >> 6, j = e & 63;
+            Wl[k * kWs + 16 * (j & 3) + (j >> 2)] = k < U && j < U ? v : 0.0f;   // tile m of lane i = column 4 i + m
+        });
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int64_t ntile = (N + 15) / 16;
+    const int nq = (U + 15) >> 4;
+    const int j = 4 * i;
+    struct Rows {
+        float4 db[4], gl[4], sk[4], r[4];
+    };
+    Rows nxt;
+    auto fetch = [&](int64_t tile, Rows& w) {
+        const int64_t t = tile < ntile ? tile : ntile - 1;
+        const int64_t v = t * 16 + i < N ? t * 16 + i : N - 1;
+        const int64_t o = v * ld + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < nq) {
+                w.db[q] = *reinterpret_cast<const float4*>(d_b + o + 16 * q);
+                w.gl[q] = *reinterpret_cast<const float4*>(gl + o + 16 * q);
+                w.sk[q] = *reinterpret_cast<const float4*>(skip + o + 16 * q);
+                w.r[q] = *reinterpret_cast<const float4*>(r + o + 16 * q);
+            }
+    };
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile < ntile) fetch(tile, nxt);
+    for (; tile < ntile; tile += stride) {
+        const int64_t v0 = tile * 16;
+        const Rows cur = nxt;
+        fetch(tile + stride, nxt);
+        float4 odb[4], ogl[4];   // the output layout's rows of d b and gl
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t v = v0 + 4 * g + rr < N ? v0 + 4 * g + rr : N - 1;
+            const int jj = j < U ? j : 0;
+            odb[rr] = *reinterpret_cast<const float4*>(d_b + v * ld + jj);
+            ogl[rr] = *reinterpret_cast<const float4*>(gl + v * ld + jj);
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const bool row_ok = v0 + i < N;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q >= nq) break;
+            const int k0 = 16 * q + 4 * g;
+            const bool in = k0 < U;   // U % 4 == 0: a float4 of units is inside or outside
+            const float db4[4] = {cur.db[q].x, cur.db[q].y, cur.db[q].z, cur.db[q].w};
+            const float gl4[4] = {cur.gl[q].x, cur.gl[q].y, cur.gl[q].z, cur.gl[q].w};
+            const float sk4[4] = {cur.sk[q].x, cur.sk[q].y, cur.sk[q].z, cur.sk[q].w};
+            const float r4[4] = {cur.r[q].x, cur.r[q].y, cur.r[q].z, cur.r[q].w};
+            float dgl[4], ds[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float gate = qb::sigmoidf_(gl4[c] + offset);
+                ds[c] = in && sk4[c] > 0.0f ? db4[c] * (1.0f - gate) : 0.0f;
+                dgl[c] = in ? db4[c] * (r4[c] - sk4[c]) * gate * (1.0f - gate) : 0.0f;
+            }
+            if (row_ok) {
+                const int64_t o = (v0 + i) * ld + k0;
+                *reinterpret_cast<float4*>(d_gl + o) = make_float4(dgl[0], dgl[1], dgl[2], dgl[3]);
+                *reinterpret_cast<float4*>(d_skip_pre + o) = make_float4(ds[0], ds[1], ds[2], ds[3]);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float* wr = Wl + (k0 + c) * kWs + i;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(dgl[c], wr[16 * m], acc[m]);
+            }
+        }
+        // padding units of the rows (U .. 63): zeros, as gate_bwd_kernel leaves them
+        if (row_ok)
+            for (int q = nq; q < 4; ++q) {
+                const int64_t o = (v0 + i) * ld + 16 * q + 4 * g;
+                *reinterpret_cast<float4*>(d_gl + o) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                *reinterpret_cast<float4*>(d_skip_pre + o) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t v = v0 + 4 * g + rr;
+            if (v >= N) continue;
+            float y[4];
+            const float db4[4] = {odb[rr].x, odb[rr].y, odb[rr].z, odb[rr].w};
+            const float gl4[4] = {ogl[rr].x, ogl[rr].y, ogl[rr].z, ogl[rr].w};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) y[m] = j < U ? fmaf(db4[m], qb::sigmoidf_(gl4[m] + offset), acc[m][rr]) : 0.0f;
+            *reinterpret_cast<float4*>(d_r + v * ld + j) = make_float4(y[0], y[1], y[2], y[3]);
+        }
+    }
+}
+
 // ---- data side of one gated block's backward in ONE launch ------------------------------------------------
 // For voxel batches of the LDS-resident shapes.  Per 16-voxel wave tile (the lane layout of encoder_core.h: a
 // lane holds four consecutive units of its voxel per 16-row tile, so [N][64] rows load and store as float4):
@@ -3619,11 +3735,22 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                 continue;
             }
             // dB = d b_out.  dC = d skip_pre, dD = d r, dE = d gate logits
-            hipLaunchKernelGGL(gate_bwd_kernel, dim3(k.grid()), dim3(256), 0, k.s, dB, gl, skip, r, dC, dD,
-                               dE, shape->gate_offset, U, G, ld, N);
+            const bool gate_fused = G == U && U <= 64 && U % 4 == 0 && ld == kLd && !(ctx->kernel_sel & 2048) &&
+                                    ((reinterpret_cast<uintptr_t>(dB) | reinterpret_cast<uintptr_t>(gl) |
+                                      reinterpret_cast<uintptr_t>(skip) | reinterpret_cast<uintptr_t>(r) |
+                                      reinterpret_cast<uintptr_t>(dC) | reinterpret_cast<uintptr_t>(dD) |
+                                      reinterpret_cast<uintptr_t>(dE)) & 15) == 0;
+            if (gate_fused) {   // gate backward and d r += dE Wg^T in one launch (QBOLD_KSEL_SEPARATE_GATE: two)
+                const size_t smem = sizeof(float) * (size_t)((U + 15) & ~15) * kWs;
+                hipLaunchKernelGGL(gate_bwd_wg_kernel, dim3(k.grid()), dim3(256), smem, k.s, dB, gl, skip, r, wb + c.Wg, dC,
+                                   dD, dE, shape->gate_offset, U, N);
+            } else {
+                hipLaunchKernelGGL(gate_bwd_kernel, dim3(k.grid()), dim3(256), 0, k.s, dB, gl, skip, r, dC, dD,
+                                   dE, shape->gate_offset, U, G, ld, N);
+            }
             // gating conv: dWg = r^T dE; d r += dE Wg^T
             k.xtd(r, U, dE, G, partial, slabs, gb + c.Wg, G, gb + c.bg, 0);
-            k.xw(dE, ld, G, wb + c.Wg, G, 1, nullptr, dD, U, ACT_NONE, 1, nullptr);
+            if (!gate_fused) k.xw(dE, ld, G, wb + c.Wg, G, 1, nullptr, dD, U, ACT_NONE, 1, nullptr);
             if (gm) {
                 // second residual conv (3x3x1): dK2[tap] = t[nbr]^T dD; d t_pre = conv^T(dD) * (t > 0) -> dE
                 k.xtd9(t, U, dD, partial, slabs9, gb + c.Wr2, gb + c.br2, *gm);
