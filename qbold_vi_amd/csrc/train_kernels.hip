@@ -1825,26 +1825,47 @@ constexpr int kMaxSlabJobs = 40;
 struct SlabJobs {
     SlabJob job[kMaxSlabJobs];
 };
+// A thread takes FOUR consecutive elements (one 16-byte load per slab) of one of the sixteen parts, four slabs'
+// loads in flight per trip; per element the additions are slab_reduce_kernel's, in its order.
 __global__ __launch_bounds__(1024) void slab_reduce_jobs_kernel(SlabJobs jobs) {
-    constexpr int kParts = 16;
-    __shared__ double part[kParts][64];
+    constexpr int kParts = 16, kSlab = 64 * 64 + 64;
+    __shared__ double part[kParts][64][4];
     const SlabJob jb = jobs.job[blockIdx.y];
-    const int e = blockIdx.x * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6;
-    double a = 0.0;
-    if (e < 64 * 64 + 64)
-        for (int bk = p; bk < jb.nblk; bk += kParts) a += (double)jb.partial[(int64_t)bk * (64 * 64 + 64) + e];
-    part[p][threadIdx.x & 63] = a;
-    __syncthreads();
-    if (p != 0 || e >= 64 * 64 + 64) return;
-    a = 0.0;
+    const int t = threadIdx.x & 63, p = threadIdx.x >> 6;
+    const int e4 = blockIdx.x * 64 + t;          // float4 index within a slab
+    const bool in = e4 * 4 < kSlab;              // kSlab is a multiple of 4
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    if (in) {
+        const float4* src = reinterpret_cast<const float4*>(jb.partial) + e4;
+        for (int bk = p; bk < jb.nblk; bk += 4 * kParts) {
+            float4 v[4];
 #pragma unroll
-    for (int q = 0; q < kParts; ++q) a += part[q][threadIdx.x];
+            for (int u = 0; u < 4; ++u) {
+                const int b = bk + u * kParts;
+                v[u] = src[(int64_t)(b < jb.nblk ? b : bk) * (kSlab / 4)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (bk + u * kParts < jb.nblk) {
+                    a[0] += (double)v[u].x; a[1] += (double)v[u].y; a[2] += (double)v[u].z; a[3] += (double)v[u].w;
+                }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) part[p][t][c] = a[c];
+    __syncthreads();
+    // thread (t, c = p) of the first four waves finishes element 4 e4 + c
+    if (p >= 4 || !in) return;
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < kParts; ++q) sum += part[q][t][p];
+    const int e = 4 * e4 + p;
     if (e < 64 * 64) {
         const int i = e >> 6, j = (e & 63) - jb.j0;
-        if (i < jb.kdim && j >= 0 && j < jb.ndim) jb.dW[i * jb.ldw + j] = (float)a;
+        if (i < jb.kdim && j >= 0 && j < jb.ndim) jb.dW[i * jb.ldw + j] = (float)sum;
     } else {
         const int j = e - 64 * 64 - jb.j0;
-        if (jb.db && j >= 0 && j < jb.ndim) jb.db[j] = (float)a;
+        if (jb.db && j >= 0 && j < jb.ndim) jb.db[j] = (float)sum;
     }
 }
 
@@ -2722,7 +2743,7 @@ struct Launcher {
     void defer_slabs(float* region, float* region_end) const { bump = bump0 = region; bump_end = region_end; njobs = 0; }
     void flush_slabs() const {
         if (njobs > 0)
-            hipLaunchKernelGGL(slab_reduce_jobs_kernel, dim3((64 * 64 + 64) / 64, njobs), dim3(1024), 0, s, jobs);
+            hipLaunchKernelGGL(slab_reduce_jobs_kernel, dim3(((64 * 64 + 64) / 4 + 63) / 64, njobs), dim3(1024), 0, s, jobs);
         njobs = 0;
         bump = bump0;
     }
