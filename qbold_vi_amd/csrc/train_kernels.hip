@@ -2345,8 +2345,8 @@ __global__ __launch_bounds__(kBlkThreads) void block_bwd_kernel(
 }
 
 
-// slab_reduce_kernel for many slabs (one per wave of block_bwd_dw_kernel: 1,024): 16 elements x 64 interleaved
-// parts per workgroup, so that 260 workgroups share the 17 MB instead of 66; parts added in a fixed order.
+// slab_reduce_kernel for many slabs (one per wave of block_bwd_dw_kernel: 1,024): 64 interleaved parts per
+// workgroup; parts added in a fixed order.
 struct SlabTargets {   // where the sum of matrix q's slabs goes (blockIdx.y = q)
     float* dW[4];
     float* db[4];
@@ -2354,30 +2354,48 @@ struct SlabTargets {   // where the sum of matrix q's slabs goes (blockIdx.y = q
 };
 __global__ __launch_bounds__(1024) void slab_reduce_many_kernel(const float* __restrict__ partial, int nblk,
                                                                  int64_t per_matrix, SlabTargets tg) {
-    constexpr int kParts = 64, kElems = 16, kSlab = 64 * 64 + 64;
-    __shared__ double part[kParts][kElems];
+    // 64 elements x 64 interleaved parts per workgroup: a thread takes four consecutive elements (16-byte loads, a
+    // part's sixteen lanes read 256 contiguous bytes of a slab), four slabs' loads in flight per trip; per element the
+    // additions and their order are the ones of the 16-element form this replaces (parts of stride 64, then the parts)
+    constexpr int kParts = 64, kLanes = 16, kSlab = 64 * 64 + 64;
+    __shared__ double part[kParts][kLanes][4];
     const int q = blockIdx.y;
     partial += (int64_t)q * per_matrix;
     float* __restrict__ dW = tg.dW[q];
     float* __restrict__ db = tg.db[q];
     const int ldw = tg.ldw[q], kdim = tg.kdim[q], ndim = tg.ndim[q];
-    const int le = threadIdx.x & (kElems - 1), p = threadIdx.x / kElems;
-    const int e = blockIdx.x * kElems + le;
-    double a = 0.0;
-    if (e < kSlab)
-        for (int bk = p; bk < nblk; bk += kParts) a += (double)partial[(int64_t)bk * kSlab + e];
-    part[p][le] = a;
+    const int le = threadIdx.x & (kLanes - 1), p = threadIdx.x / kLanes;
+    const int e4 = blockIdx.x * kLanes + le;     // float4 index within a slab (kSlab / 4 = 1040 = 65 x 16)
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    const float4* src = reinterpret_cast<const float4*>(partial) + e4;
+    for (int bk = p; bk < nblk; bk += 4 * kParts) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = bk + u * kParts;
+            v[u] = src[(int64_t)(b < nblk ? b : bk) * (kSlab / 4)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (bk + u * kParts < nblk) {
+                a[0] += (double)v[u].x; a[1] += (double)v[u].y; a[2] += (double)v[u].z; a[3] += (double)v[u].w;
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) part[p][le][c] = a[c];
     __syncthreads();
-    if (p != 0 || e >= kSlab) return;
-    a = 0.0;
+    if (threadIdx.x >= 4 * kLanes) return;   // thread (le, c) finishes element 4 e4 + c
+    const int c = threadIdx.x / kLanes;
+    double sum = 0.0;
 #pragma unroll 8
-    for (int qq = 0; qq < kParts; ++qq) a += part[qq][le];
+    for (int qq = 0; qq < kParts; ++qq) sum += part[qq][le][c];
+    const int e = 4 * e4 + c;
     if (e < 64 * 64) {
         const int i = e >> 6, j = e & 63;
-        if (i < kdim && j < ndim) dW[i * ldw + j] = (float)a;
+        if (i < kdim && j < ndim) dW[i * ldw + j] = (float)sum;
     } else {
         const int j = e - 64 * 64;
-        if (db && j < ndim) db[j] = (float)a;
+        if (db && j < ndim) db[j] = (float)sum;
     }
 }
 
@@ -3730,7 +3748,7 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
                     const int64_t per = (int64_t)nw * (64 * 64 + 64);
                     // the four matrices' slabs in one launch (grid y = matrix): 1,040 workgroups instead of four rounds
                     // of 260 on 256 CUs
-                    const dim3 rg((64 * 64 + 64) / 16, 4);
+                    const dim3 rg((64 * 64 + 64) / 64, 4);
                     SlabTargets tg;
                     tg.dW[0] = gb + c.Wg;        tg.db[0] = gb + c.bg;  tg.ldw[0] = G; tg.kdim[0] = U; tg.ndim[0] = G;
                     tg.dW[1] = gb + c.Wr2 + ctr; tg.db[1] = gb + c.br2; tg.ldw[1] = U; tg.kdim[1] = U; tg.ndim[1] = U;
