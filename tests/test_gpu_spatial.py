@@ -89,15 +89,19 @@ def test_smoothness_loss_and_gradient(ctx, oracle64):
             assert abs(g[idx + (ch,)] - fd) < 1e-3 * (abs(fd) + 1e-2)
 
 
-@pytest.mark.parametrize("U,L,cw", [(24, 2, True), (20, 1, False), (33, 1, True)])
-def test_spatial_weight_gradient_directional(ctx, oracle32, oracle64, U, L, cw):
+@pytest.mark.parametrize("U,L,cw,Z", [(24, 2, True, 2), (20, 1, False, 2), (33, 1, True, 2), (24, 2, True, 4), (60, 2, True, 8)])
+def test_spatial_weight_gradient_directional(ctx, oracle32, oracle64, U, L, cw, Z):
     """d/dw [masked-mean NLL + KL + 5 * TV] through the spatial encoder, against central differences
-    of the float64 oracle along random weight directions (every tap of the 3x3x1 kernels moves)."""
+    of the float64 oracle along random weight directions (every tap of the 3x3x1 kernels moves).  Z = 2: the exact
+    float32 nine-tap kernels; Z % 4 == 0 with U % 4 == 0: the matrix-pipe kernels the training step runs on --
+    conv9h_kernel's backward-data form with its deltas lifted by the sum(mask) the ELBO backward hands over,
+    xtd9b_kernel / xtdb_kernel on two f16 halves under the running delta scale, gate_bwd_wg_kernel, the queued slab
+    sums -- held to the oracle directly, not to the exact kernels."""
     from oracle.oracle import WEIGHT_NAMES
     from qbold_vi_amd.ops import EncoderWeights, TrainState
     from test_gpu_grad import _perturbed, kl_stopgrad
     w, ew = make(ctx, U, L, cw)
-    B, X, Y, Z = 2, 5, 4, 2
+    B, X, Y = 2, 5, 4
     n, S, K, seed, sw = B * X * Y * Z, 2, 4, 9, 5.0
     x = crop_batch(oracle32, B, X, Y, Z, seed=4)
     rng = np.random.default_rng(5)
