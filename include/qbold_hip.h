@@ -423,7 +423,15 @@ int qbold_smoothness(const qbold_ctx* ctx, const float* q, const float* mask, co
  * the split-f16 products of qbold_encoder_train_fwd_fused and takes its relu masks from that recomputation: it is the
  * adjoint of THAT forward.  After the exact-f32 layer-wise qbold_encoder_train_fwd the masks can differ for
  * activations within ~1e-6 of zero (where the relu's derivative is a convention anyway); callers that need the adjoint
- * of the layer-wise forward bit for bit select QBOLD_KSEL_LAYERWISE_BWD. */
+ * of the layer-wise forward bit for bit select QBOLD_KSEL_LAYERWISE_BWD.
+ * Operand range of the layer-wise backward (crops, and voxel batches under QBOLD_KSEL_LAYERWISE_BWD): the 3x3x1
+ * backward-data products and the weight gradients run on split-f16 operands.  Deltas are NOT bound by f16's range:
+ * with `sums` given the backward-data products lift them by 2^floor(log2 sums[2]) (exact), and the weight-gradient
+ * kernels keep a running power-of-two scale per wave that follows the largest |delta| seen (accumulators rescaled,
+ * exact), whatever the caller's normalisation.  Activations are taken as they are: the forward's limit above applies
+ * (an activation beyond 65504 gives non-finite gradients, never a clamp), and an activation below 2^-14 in magnitude
+ * keeps an absolute 2^-25 in the weight gradients.  QBOLD_KSEL_DW_BF16_PIECES (three bfloat16 pieces per operand, no
+ * range at all) and QBOLD_KSEL_DW_EXACT_F32 select the other forms. */
 int qbold_encoder_train_bwd(const qbold_ctx* ctx, const qbold_encoder_shape* shape, const float* weights,
                             int stream_sel, float* workspace, const float* g_q, const float* g_log_sigma,
                             const double* sums, float* grad, int64_t N, void* stream);
