@@ -740,3 +740,42 @@ def test_crop_backward_keeps_its_precision_when_the_deltas_carry_one_over_sum_ma
                 a, b = plain[off:off + cnt], scaled[off:off + cnt]
                 assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-30, \
                     (total, name, l, float((a - b).abs().max()), float(a.abs().max()))
+
+
+@pytest.mark.parametrize("crops", [False, True])
+def test_backward_is_bitwise_reproducible_run_to_run(params, crops):
+    """Every reduction of the training step adds in a fixed order (slabs per wave / workgroup summed by slab index, no
+    float atomics), and the weight-gradient kernels' running delta scale depends on the data's order only: the same
+    inputs give the same gradient bit for bit, launch after launch -- on a voxel batch (one-launch block backward) and on
+    crops (matrix-pipe nine-tap kernels, queued slab sums), with deltas that make the scale fall several times."""
+    from qbold_vi_amd.init import init_encoder_weights
+    from qbold_vi_amd.ops import Context, EncoderWeights, TrainState
+    rng = np.random.default_rng(123)
+    U, L = 60, 2
+    ctx = Context(params, True, True)
+    if crops:
+        B, X, Y, Z = 4, 14, 10, 8
+        N = B * X * Y * Z
+        w = init_encoder_weights(T=11, U=U, L=L, channelwise_gating=True, resid_init_std=0.05, im_loss_sigma=0.05, seed=5,
+                                 spatial_taps=9)
+        ew = EncoderWeights(ctx, 11, U, L, True, -3.0, spatial_taps=9).set_from_arrays(w)
+        x = torch.as_tensor(rng.uniform(0.2, 1.0, (B, X, Y, Z, 11)).astype(np.float32), device="cuda")
+    else:
+        N = 70001
+        w = init_encoder_weights(T=11, U=U, L=L, channelwise_gating=True, resid_init_std=0.3, im_loss_sigma=0.05, seed=5)
+        ew = EncoderWeights(ctx, 11, U, L, True, -3.0).set_from_arrays(w)
+        x = torch.as_tensor(rng.uniform(0.2, 1.0, (N, 11)).astype(np.float32), device="cuda")
+    scale = np.exp(rng.uniform(np.log(1e-8), np.log(1e-3), (N, 1)))
+    g_q = torch.as_tensor((rng.normal(size=(N, 5)) * scale).astype(np.float32), device="cuda")
+    g_ls = torch.as_tensor((rng.normal(size=(N, 11)) * scale).astype(np.float32), device="cuda")
+    st = TrainState(ctx, ew)
+    grads = []
+    for _ in range(3):
+        if crops:
+            st.forward_spatial(x)
+            grads.append(st.backward_spatial(g_q, g_ls, None).clone())
+        else:
+            st.forward(x, 2)
+            grads.append(st.backward(2, g_q, g_ls).clone())
+    assert torch.isfinite(grads[0]).all() and float(grads[0].abs().max()) > 0
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
