@@ -1827,12 +1827,14 @@ struct SlabJobs {
 };
 // A thread takes FOUR consecutive elements (one 16-byte load per slab) of one of the sixteen parts, four slabs'
 // loads in flight per trip; per element the additions are slab_reduce_kernel's, in its order.
-__global__ __launch_bounds__(1024) void slab_reduce_jobs_kernel(SlabJobs jobs) {
-    constexpr int kParts = 16, kSlab = 64 * 64 + 64;
-    __shared__ double part[kParts][64][4];
+__global__ __launch_bounds__(512) void slab_reduce_jobs_kernel(SlabJobs jobs) {
+    // 32 float4 columns x 16 parts per workgroup: 33 workgroups per job, so that a queue of nine jobs (one nine-tap
+    // gradient) is 297 workgroups -- with 64 columns per workgroup it was 153 on 256 CUs
+    constexpr int kParts = 16, kCols = 32, kSlab = 64 * 64 + 64;
+    __shared__ double part[kParts][kCols][4];
     const SlabJob jb = jobs.job[blockIdx.y];
-    const int t = threadIdx.x & 63, p = threadIdx.x >> 6;
-    const int e4 = blockIdx.x * 64 + t;          // float4 index within a slab
+    const int t = threadIdx.x & (kCols - 1), p = threadIdx.x / kCols;
+    const int e4 = blockIdx.x * kCols + t;       // float4 index within a slab
     const bool in = e4 * 4 < kSlab;              // kSlab is a multiple of 4
     double a[4] = {0.0, 0.0, 0.0, 0.0};
     if (in) {
@@ -1854,7 +1856,7 @@ __global__ __launch_bounds__(1024) void slab_reduce_jobs_kernel(SlabJobs jobs) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) part[p][t][c] = a[c];
     __syncthreads();
-    // thread (t, c = p) of the first four waves finishes element 4 e4 + c
+    // thread (t, c = p) of the first four part rows finishes element 4 e4 + c
     if (p >= 4 || !in) return;
     double sum = 0.0;
 #pragma unroll
@@ -2760,7 +2762,7 @@ struct Launcher {
     void defer_slabs(float* region, float* region_end) const { bump = bump0 = region; bump_end = region_end; njobs = 0; }
     void flush_slabs() const {
         if (njobs > 0)
-            hipLaunchKernelGGL(slab_reduce_jobs_kernel, dim3(((64 * 64 + 64) / 4 + 63) / 64, njobs), dim3(1024), 0, s, jobs);
+            hipLaunchKernelGGL(slab_reduce_jobs_kernel, dim3(((64 * 64 + 64) / 4 + 31) / 32, njobs), dim3(512), 0, s, jobs);
         njobs = 0;
         bump = bump0;
     }
