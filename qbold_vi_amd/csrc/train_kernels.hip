@@ -3648,7 +3648,11 @@ static int train_bwd_impl(const qbold_ctx* ctx, const qbold_encoder_shape* shape
     // xtd slabs per launch: one 1024-thread block per CU, at least 16 four-voxel steps per wave
     auto slab_count = [&](int taps) {
         (void)taps;
-        int64_t nb = N / (16 * 16 * 4);
+#ifndef QB_SLAB_VOX
+#define QB_SLAB_VOX 512
+#endif
+        int64_t nb = N / QB_SLAB_VOX;   // (a workgroup per CU from 131 k voxels on: at 1,024 voxels per slab a crop batch of
+                                        // 190 k filled 185 of the 256 CUs)
         const int64_t cap = ctx->num_cus < kSlabBlocks ? ctx->num_cus : kSlabBlocks;
         return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
     };
