@@ -24,6 +24,20 @@ namespace {
 using qb::f32x4;
 #define QB_MFMA16F(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// Cross-workgroup sums that have no scratch to leave partials in (one double per quantity in the caller's buffer) are
+// added as 64-bit FIXED-POINT integers: integer addition is associative, so the result does not depend on the order the
+// workgroups arrive in -- a floating-point atomicAdd would make these the only sums of the library that are not
+// reproducible bit for bit.  fixed_to_double_kernel turns the integers into doubles in place.
+__device__ __forceinline__ void atomic_add_fixed(double* acc, double v, double scale) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)llrint(v * scale));
+}
+__global__ void fixed_to_double_kernel(double* p, int n, double inv_scale) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) p[k] = (double)(*reinterpret_cast<const long long*>(p + k)) * inv_scale;
+}
+constexpr double kTvFixed = 4294967296.0;      // 2^32: a TV sum is < 2^25 (N < 2^23 voxels, four unit differences each)
+constexpr double kStatsFixed = 16777216.0;     // 2^24: |sum log v|, sum 1 / v < 2^35
+
 constexpr int kLd = 64;        // row stride of the activation / delta tensors for U <= 64
 constexpr int kMaxU = 256;     // forward-only layer-wise path (BASELINE config 3)
 constexpr int kWs = 65;        // LDS row stride of a staged weight matrix
@@ -2704,7 +2718,8 @@ __global__ __launch_bounds__(256) void hyper_prior_kernel(const float* __restric
     }
     __syncthreads();
     if (threadIdx.x < 4 && stats)
-        atomicAdd(stats + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+        atomic_add_fixed(stats + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x],
+                         kStatsFixed);
 }
 
 // copy g_q [N][5] and g_ls [N][T] into one [N][ld] delta tensor (cols 0-4, 5..5+T-1), scaled.  Only the
@@ -3893,7 +3908,7 @@ __global__ void smoothness_kernel(const float* __restrict__ q, const float* __re
     if (threadIdx.x == 0) {
         double a = 0.0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += red[w];
-        atomicAdd(tv_sum, a);
+        atomic_add_fixed(tv_sum, a, kTvFixed);
     }
 }
 }  // namespace
@@ -3911,6 +3926,7 @@ extern "C" int qbold_smoothness(const qbold_ctx* ctx, const float* q, const floa
     int64_t cap = (int64_t)ctx->num_cus * 8;
     hipLaunchKernelGGL(smoothness_kernel, dim3((int)(nb < cap ? nb : cap)), dim3(256), 0, s, q, mask, *geom,
                        weight, g_q, tv_sum, N);
+    hipLaunchKernelGGL(fixed_to_double_kernel, dim3(1), dim3(64), 0, s, tv_sum, 1, 1.0 / kTvFixed);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }
@@ -3948,6 +3964,7 @@ extern "C" int qbold_hyper_prior_bwd(const qbold_ctx* ctx, const float* q, const
     hipLaunchKernelGGL(hyper_prior_kernel, dim3((int)(nb < cap ? nb : cap)), dim3(256), 0, s, q, (float)ao, (float)bo,
                        (float)(lgamma(ao) - ao * log(bo)), (float)ad, (float)bd, (float)(lgamma(ad) - ad * log(bd)),
                        scale, g_q, loss_v, stats, N);
+    if (stats) hipLaunchKernelGGL(fixed_to_double_kernel, dim3(1), dim3(64), 0, s, stats, 4, 1.0 / kStatsFixed);
     QB_HIP(hipGetLastError());
     return QBOLD_OK;
 }
