@@ -420,6 +420,7 @@ __global__ __launch_bounds__(256) void xw64_heads_kernel(const float* __restrict
                                                          int64_t N) {
     extern __shared__ float Wl[];
     const int ndim = 5 + T;
+    const bool compact = ndim <= 16;
     const int kpad = (kdim + 15) & ~15;
     stage_in_flight<256>(
         kpad * 64,
@@ -430,7 +431,9 @@ __global__ __launch_bounds__(256) void xw64_heads_kernel(const float* __restrict
         },
         [&](int e, float v) {
             const int k = e >> 6, j = e & 63;
-            Wl[k * kWs + 16 * (j & 3) + (j >> 2)] = k < kdim && j < ndim ? v : 0.0f;   // tile m of lane i = column 4 i + m
+            // tile m of lane i = column 4 i + m; with at most 16 columns (T <= 11) they all sit in tile 0, lane i = column i:
+            // one MFMA per k step instead of four, and every lane has a column to store
+            Wl[k * kWs + (compact ? j : 16 * (j & 3) + (j >> 2))] = k < kdim && j < ndim ? v : 0.0f;
         });
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(256) void xw64_heads_kernel(const float* __restrict
     float bj[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) bj[m] = j + m < 5 ? bf[j + m] : (j + m < ndim ? bs[j + m - 5] : 0.0f);
+    const float bi = i < 5 ? bf[i] : (i < ndim ? bs[i - 5] : 0.0f);   // compact: this lane's one column
     float4 nxt[4];
     auto fetch = [&](int64_t tile) {
         const int64_t t = tile < ntile ? tile : ntile - 1;
@@ -471,9 +475,25 @@ __global__ __launch_bounds__(256) void xw64_heads_kernel(const float* __restrict
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float* wr = Wl + (k0 + c) * kWs + i;
+                if (compact) {
+                    acc[0] = QB_MFMA16F(ac[c], wr[0], acc[0]);
+                    continue;
+                }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[m] = QB_MFMA16F(ac[c], wr[16 * m], acc[m]);
             }
+        }
+        if (compact) {
+            if (i >= ndim) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t v = v0 + 4 * g + r;
+                if (v >= N) continue;
+                const float y = acc[0][r] + bi;
+                if (i < 5) out_q[v * 5 + i] = y;
+                else out_ls[v * T + (i - 5)] = y;
+            }
+            continue;
         }
         if (j >= ndim) continue;
 #pragma unroll
